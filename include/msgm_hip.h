@@ -1,0 +1,193 @@
+/*
+ * msgm_hip.h — C ABI of libmsgm_hip.so: the MI355X (gfx950) hot path of
+ * sdeflow-light / MSGM (score-matching train step + reverse-SDE sampling).
+ *
+ * The reference (vressegu/sdeflow-light) is pure Python/PyTorch and has no
+ * FFI; each entry point below replaces the *sequence of eager ATen ops* the
+ * cited reference lines launch.  The reference-side binding a maintainer
+ * would add is a ctypes stub — see INTEGRATION.md.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless
+ *     the name ends in _host; all float tensors are contiguous fp32;
+ *   - returns MSGM_OK (0) or a negative MSGM_E* code; never throws, never
+ *     allocates, never synchronises; work is enqueued on `stream` only, so
+ *     every call is hipGraph-capturable;
+ *   - caller owns all buffers, including workspaces (sizes from *_workspace);
+ *   - re-entrant / thread-safe: no mutable globals.
+ *
+ * Randomness: kernels that draw noise take either an explicit noise buffer
+ * (parity mode: the oracle is fed the same numbers) or, when that pointer is
+ * NULL, a device-resident Philox state `rng` = {seed, offset} (uint64[2]).
+ * Draws are counter-based: value = philox(seed, offset + stream_id, element),
+ * so they do not depend on the launch geometry.  msgm_rng_advance bumps
+ * `offset` on the stream (graph-safe).
+ */
+#ifndef MSGM_HIP_H
+#define MSGM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* msgm_stream_t;   /* hipStream_t */
+
+enum {
+  MSGM_OK = 0,
+  MSGM_E_BADARG = -1,       /* null pointer / non-positive size                  */
+  MSGM_E_UNSUPPORTED = -2,  /* shape outside what the kernel was built for       */
+  MSGM_E_WORKSPACE = -3,    /* workspace too small                               */
+  MSGM_E_LAUNCH = -4        /* hipGetLastError() != hipSuccess after the launch  */
+};
+
+/* SDE family of the base process (reference: SDEs.py:161-215 SGMsde,
+ * :221-509 MSGMsde dense / sparse tensor). */
+enum { MSGM_SDE_SGM = 0, MSGM_SDE_MSGM_SPARSE = 1, MSGM_SDE_MSGM_DENSE = 2 };
+
+/* Which process the integrator stage evaluates (SDEs.py:30-47 forward_SDE,
+ * :538-588 PluginReverseSDE). */
+enum { MSGM_PROC_REVERSE = 0, MSGM_PROC_FORWARD = 1 };
+
+typedef struct {
+  int32_t kind;        /* MSGM_SDE_*                                              */
+  float beta_min;      /* SDEs.py:58-59                                           */
+  float beta_max;
+  float T;             /* horizon (SDEs.py:57)                                    */
+  float t_epsilon;     /* SDEs.py:60                                              */
+  const float* G;      /* dense (n,n,n) tensor, MSGM_SDE_MSGM_DENSE only          */
+  const float* L_G;    /* dense (n,n) Ito correction (SDEs.py:246)                */
+} msgm_sde_t;
+
+int msgm_version(void);
+const char* msgm_error_string(int code);
+
+/* ---- RNG state ---------------------------------------------------------- */
+/* rng[1] += n (one thread).  Replaces the implicit advance of torch's global
+ * generator after each randn/rand call. */
+int msgm_rng_advance(uint64_t* rng, uint64_t n, msgm_stream_t stream);
+
+/* Fill with U[0,1) / N(0,1) from the Philox stream (used by tests to obtain
+ * the exact numbers a fused kernel will draw, and by latent_sample). */
+int msgm_fill_uniform(float* out, int64_t n, const uint64_t* rng, uint32_t stream_id, msgm_stream_t stream);
+int msgm_fill_normal(float* out, int64_t n, const uint64_t* rng, uint32_t stream_id, msgm_stream_t stream);
+
+/* ---- K1: forward-diffusion perturbation (SGM closed form) ---------------- */
+/* Replaces PluginReverseSDE.sample_t (SDEs.py:684-693) + SDE.sample_Song_et_al
+ * (SDEs.py:134-146) + mean_weight/var (SDEs.py:177-181):
+ *   t_b = clamp(u_b*T), y = mean_weight(t) x0 + sqrt(var(t)) eps.
+ * u (B) and eps (B*d) are read when non-NULL, else drawn from rng streams
+ * 0 (u) and 1 (eps).  t_out (B) always written; eps_out optional. */
+int msgm_perturb_vp(const float* x0, float* y, float* t_out, float* eps_out,
+                    int64_t B, int64_t d, const msgm_sde_t* sde,
+                    const float* u, const float* eps, const uint64_t* rng,
+                    msgm_stream_t stream);
+
+/* Bit-exact per-row stop index k = trunc((nsf*t)/T) (int32), rows with t>=T
+ * forced to nsf.  Replaces SDEs.py:89-101. */
+int msgm_forward_step_index(const float* t, int32_t* k, int64_t B, int32_t nsf, float T,
+                            msgm_stream_t stream);
+
+/* Rademacher probe v = 2[u>=1/2]-1 (SDEs.py:514-515); u NULL => rng stream 2. */
+int msgm_rademacher(float* v, int64_t n, const float* u, const uint64_t* rng, msgm_stream_t stream);
+
+/* ---- K2/K3/K4: one integrator stage -------------------------------------- */
+/* inc = drift(t, x) * delta + sigma(t, x) . dW   (sde_scheme.py:18-40 EMstep
+ * applied to sde.mu / sde.mu_Strato and sde.sigma, SDEs.py:30-47,556-588),
+ * for the three diffusion layouts (diagonal SGM, sparse 3-point stencil,
+ * dense G contraction without materialising (B,n,n)).
+ *   proc    MSGM_PROC_REVERSE: drift = (1-l/2) G(s,x)a - f(s,x) + (1-l) divS(s,x),
+ *           s = T - t, sigma = sqrt(1-l) g(s,x); `a` = score-net output (B,n).
+ *           MSGM_PROC_FORWARD: drift = f_strato (+ 1/2 divS if !strato), sigma = g(t,x).
+ *   strato  0: Ito drift (EM); 1: Stratonovich drift (Heun / RK4).
+ *   dW      Wiener increment (B,n) (already scaled by sqrt(delta)); when NULL,
+ *           dW = sqrt_delta * z with z read from `z` or drawn (rng stream 3).
+ *   out = base + c_out * inc  (base may be NULL => out = c_out * inc; out may
+ *           alias base or x).
+ *   norm0   optional (B): after the update rescale each row of `out` to this
+ *           norm (norm_correction, sde_scheme.py:85-86).
+ * t is a scalar shared by the batch (the integrators fill a (B,1) tensor with
+ * one value, sde_scheme.py:81). */
+int msgm_sde_stage(float* out, const float* base, float c_out,
+                   const float* x, const float* a, const float* dW, const float* z,
+                   float sqrt_delta, const uint64_t* rng, uint64_t rng_step,
+                   float* dW_out,
+                   int64_t B, int64_t n, const msgm_sde_t* sde, int32_t proc, int32_t strato,
+                   float t, float delta, float lmbd, const float* norm0,
+                   msgm_stream_t stream);
+
+/* out = x + (k1 + 2 k2 + 2 k3 + k4)/6 with optional norm correction
+ * (sde_scheme.py:250-253). */
+int msgm_rk4_combine(float* out, const float* x, const float* k1, const float* k2,
+                     const float* k3, const float* k4, int64_t B, int64_t n,
+                     const float* norm0, msgm_stream_t stream);
+
+/* Row L2 norms (B,n)->(B) (torch.norm(x,dim=1), sde_scheme.py:65). */
+int msgm_row_norm(const float* x, float* out, int64_t B, int64_t n, msgm_stream_t stream);
+
+/* Masked capture: rows with stop[b]==index copy x[b,:] -> kept[b,:]
+ * (samplesToKeep branch, sde_scheme.py:89-92, device-resident). */
+int msgm_keep_rows(float* kept, const float* x, const int32_t* stop, int32_t index,
+                   int64_t B, int64_t n, msgm_stream_t stream);
+
+/* ---- K13: Adam on a flat bucket ------------------------------------------ */
+/* torch.optim.Adam defaults (MSGM_higherDim.py:792): p,m,v updated in place
+ * from g * gscale; step count (1-based, after increment) read from
+ * *step_dev when non-NULL else `step`.  Hyper-parameters are doubles because
+ * upstream they are Python floats and the bias corrections are formed in
+ * double before being rounded to fp32. */
+int msgm_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
+                   double lr, double beta1, double beta2, double eps, float gscale,
+                   int64_t step, const int64_t* step_dev, msgm_stream_t stream);
+
+/* *ctr += 1 (one thread) — device-side step counter for graph replays. */
+int msgm_counter_inc(int64_t* ctr, msgm_stream_t stream);
+
+/* ---- K5: fused MLP score net (NN.py:73-120) ------------------------------ */
+/* Parameters are the reference state_dict tensors, PyTorch layout:
+ *   W1 (128, in), b1 (128), W2 (128,128), b2, W3 (128,128), b3, W4 (d,128), b4 (d)
+ * with in = d + 1 (premodule None) or d + 2 (NormalizeLogRadius: [x^, log r, t]).
+ * Supported: hidden 128, d <= 30. */
+typedef struct {
+  const float* W1; const float* b1;
+  const float* W2; const float* b2;
+  const float* W3; const float* b3;
+  const float* W4; const float* b4;
+  int32_t d;            /* input_dim == output_dim                              */
+  int32_t premodule;    /* 0 none, 1 NormalizeLogRadius (NN.py:56-70)            */
+} msgm_mlp_params_t;
+
+/* a = MLP(y, t): y (B,d), t (B) -> a (B,d).  One kernel: all four layers
+ * chained through fp32 MFMA accumulators, activations never leave the CU. */
+int msgm_mlp_forward(const msgm_mlp_params_t* P, const float* y, const float* t, float* a,
+                     int64_t B, msgm_stream_t stream);
+
+/* Fused sampler step for SGM + MLP: a = MLP(x, T - t) then the EM update of
+ * msgm_sde_stage (diag layout) in the same kernel.  x updated in place. */
+int msgm_mlp_em_step(const msgm_mlp_params_t* P, float* x, int64_t B, const msgm_sde_t* sde,
+                     float t, float delta, float lmbd, const float* z, const uint64_t* rng,
+                     uint64_t rng_step, msgm_stream_t stream);
+
+/* Fused SSM training pass for SGM + MLP (replaces SDEs.py:607-646 +
+ * loss.mean().backward(), MSGM_higherDim.py:807-808):
+ *   per sample: a = MLP(y,t), adot = J_a v (forward-mode), loss_b =
+ *   sqrt(beta) v.adot + 1/2 beta |v|^2 + 1/2 |a|^2, then the backward pass of
+ *   mean_b(loss_b) w.r.t. every parameter, all inside one persistent kernel.
+ * Inputs y,t,v are (B,d),(B),(B,d).  Outputs: grads (flat, layout =
+ * [W1,b1,W2,b2,W3,b3,W4,b4], n_params floats), loss_per (B, optional),
+ * loss_sum (1 float, optional).  inv_batch scales the mean (1/global batch).
+ * workspace: msgm_mlp_ssm_workspace(d, premodule) bytes (per-workgroup partial
+ * gradient slabs, reduced deterministically by a second kernel). */
+size_t msgm_mlp_ssm_workspace(int32_t d, int32_t premodule);
+int64_t msgm_mlp_num_params(int32_t d, int32_t premodule);
+int msgm_mlp_ssm_grad(const msgm_mlp_params_t* P, const float* y, const float* t, const float* v,
+                      int64_t B, const msgm_sde_t* sde, float inv_batch,
+                      float* grads, float* loss_per, float* loss_sum,
+                      void* workspace, size_t workspace_bytes, msgm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSGM_HIP_H */

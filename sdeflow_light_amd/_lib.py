@@ -1,0 +1,132 @@
+"""ctypes binding of libmsgm_hip.so (the C ABI declared in include/msgm_hip.h).
+
+Loading is lazy and LOUD: if the shared library is missing or a symbol is
+absent the import of any kernel wrapper raises — there is no CPU / eager
+fallback anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmsgm_hip.so")
+
+MSGM_OK = 0
+SDE_SGM, SDE_MSGM_SPARSE, SDE_MSGM_DENSE = 0, 1, 2
+PROC_REVERSE, PROC_FORWARD = 0, 1
+RNG_STREAM_T, RNG_STREAM_EPS, RNG_STREAM_V, RNG_STREAM_DW, RNG_STREAM_USER = 0, 1, 2, 3, 16
+
+
+class MsgmError(RuntimeError):
+    pass
+
+
+class SdeT(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("beta_min", C.c_float), ("beta_max", C.c_float), ("T", C.c_float),
+                ("t_epsilon", C.c_float), ("G", C.c_void_p), ("L_G", C.c_void_p)]
+
+
+class MlpParamsT(C.Structure):
+    _fields_ = [("W1", C.c_void_p), ("b1", C.c_void_p), ("W2", C.c_void_p), ("b2", C.c_void_p),
+                ("W3", C.c_void_p), ("b3", C.c_void_p), ("W4", C.c_void_p), ("b4", C.c_void_p),
+                ("d", C.c_int32), ("premodule", C.c_int32)]
+
+
+_P, _I64, _I32, _U64, _U32, _F, _D, _SZ = (C.c_void_p, C.c_int64, C.c_int32, C.c_uint64, C.c_uint32, C.c_float,
+                                          C.c_double, C.c_size_t)
+
+# name -> (restype, argtypes); mirrors include/msgm_hip.h one to one
+SIGNATURES = {
+    "msgm_version": (C.c_int, []),
+    "msgm_error_string": (C.c_char_p, [C.c_int]),
+    "msgm_rng_advance": (C.c_int, [_P, _U64, _P]),
+    "msgm_fill_uniform": (C.c_int, [_P, _I64, _P, _U32, _P]),
+    "msgm_fill_normal": (C.c_int, [_P, _I64, _P, _U32, _P]),
+    "msgm_perturb_vp": (C.c_int, [_P, _P, _P, _P, _I64, _I64, C.POINTER(SdeT), _P, _P, _P, _P]),
+    "msgm_forward_step_index": (C.c_int, [_P, _P, _I64, _I32, _F, _P]),
+    "msgm_rademacher": (C.c_int, [_P, _I64, _P, _P, _P]),
+    "msgm_sde_stage": (C.c_int, [_P, _P, _F, _P, _P, _P, _P, _F, _P, _U64, _P, _I64, _I64, C.POINTER(SdeT), _I32, _I32,
+                                 _F, _F, _F, _P, _P]),
+    "msgm_rk4_combine": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
+    "msgm_row_norm": (C.c_int, [_P, _P, _I64, _I64, _P]),
+    "msgm_keep_rows": (C.c_int, [_P, _P, _P, _I32, _I64, _I64, _P]),
+    "msgm_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _D, _D, _D, _D, _F, _I64, _P, _P]),
+    "msgm_counter_inc": (C.c_int, [_P, _P]),
+    "msgm_mlp_forward": (C.c_int, [C.POINTER(MlpParamsT), _P, _P, _P, _I64, _P]),
+    "msgm_mlp_em_step": (C.c_int, [C.POINTER(MlpParamsT), _P, _I64, C.POINTER(SdeT), _F, _F, _F, _P, _P, _U64, _P]),
+    "msgm_mlp_ssm_workspace": (_SZ, [_I32, _I32]),
+    "msgm_mlp_num_params": (_I64, [_I32, _I32]),
+    "msgm_mlp_ssm_grad": (C.c_int, [C.POINTER(MlpParamsT), _P, _P, _P, _I64, C.POINTER(SdeT), _F, _P, _P, _P, _P, _SZ, _P]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """The loaded library; raises MsgmError when it cannot be loaded."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MsgmError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        try:
+            L = C.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise MsgmError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(L, name)
+            except AttributeError as e:
+                raise MsgmError(f"{LIB_PATH} does not export {name}") from e
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != MSGM_OK:
+        raise MsgmError(f"{what} failed: {lib().msgm_error_string(rc).decode()} ({rc})")
+
+
+def ptr(t: Optional[torch.Tensor]):
+    """Device pointer of a contiguous CUDA(=HIP) tensor, or NULL for None."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise MsgmError("libmsgm_hip kernels need device tensors (got a CPU tensor); there is no CPU fallback")
+    if not t.is_contiguous():
+        raise MsgmError("libmsgm_hip kernels need contiguous tensors")
+    return t.data_ptr()
+
+
+def f32(t: torch.Tensor, name: str = "tensor") -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise MsgmError(f"{name} must be float32 (got {t.dtype})")
+    return t
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def sde_struct(kind: int, beta_min: float, beta_max: float, T: float, t_epsilon: float,
+               G: Optional[torch.Tensor] = None, L_G: Optional[torch.Tensor] = None) -> SdeT:
+    return SdeT(kind, float(beta_min), float(beta_max), float(T), float(t_epsilon), ptr(G), ptr(L_G))
+
+
+class PhiloxState:
+    """Device-resident {seed, offset} pair consumed by kernels that draw noise."""
+
+    def __init__(self, seed: int, device, offset: int = 0):
+        # int64 storage, reinterpreted as uint64 by the kernels
+        self.state = torch.tensor([seed & 0x7FFFFFFFFFFFFFFF, offset], dtype=torch.int64, device=device)
+
+    def ptr(self):
+        return self.state.data_ptr()
+
+    def advance(self, n: int = 1) -> None:
+        check(lib().msgm_rng_advance(self.ptr(), n, stream()), "msgm_rng_advance")

@@ -1,0 +1,652 @@
+// mlp_kernels.hip — K5: the MLP score network (NN.py:73-120) as ONE fused
+// kernel per use: forward (sampling), forward + Euler–Maruyama update, and the
+// whole sliced-score-matching training pass (forward + forward-mode tangent +
+// loss + backward), on fp32 MFMA (v_mfma_f32_16x16x4_f32, exact fp32).
+//
+// Design (gfx950, 4 waves / workgroup, 1 workgroup / CU, persistent grid):
+//   * orientation Z[feature][sample] = W[feature][k] . H[k][sample]: the weight
+//     is the MFMA A operand, activations the B operand.  The C/D layout then has
+//     the sample on lane&15 and 4 consecutive features in the 4 accumulator
+//     registers, which is exactly the B-operand layout of the next layer — the
+//     only thing that crosses waves is the activation tile, exchanged through LDS
+//     in [sample][feature] order with b128 reads/writes.
+//   * wave w owns output features [32w, 32w+32) of every layer (2 row tiles).
+//     Its weight fragments are streamed from L2 straight into registers one phase
+//     ahead (the 128x128 weights never sit in LDS); its slice of dW2/dW3 lives in
+//     accumulator registers for the whole kernel.
+//   * a tile is 16 samples = 16 primal + 16 tangent columns (forward-mode dual
+//     numbers: tangent = J.v), so primal and tangent of one sample share a lane
+//     and the Swish first/second derivatives are applied in registers.
+//   * per-workgroup gradient slabs are written once at the end and reduced by a
+//     second (deterministic) kernel — no float atomics.
+#include "common.h"
+
+#define HID 128
+#define ACT_P 132   // LDS pitch of an activation row ([sample][feature])
+#define SM_P 36     // LDS pitch of the small per-sample rows (h0, abar, partials)
+#define DPAD 32     // padded in/out width of the small layers
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// ---- LDS carve (floats) ----------------------------------------------------
+#define OFF_X 0
+#define OFF_Y (OFF_X + 32 * ACT_P)
+#define OFF_Z (OFF_Y + 32 * ACT_P)
+#define OFF_U (OFF_Z + 32 * ACT_P)
+#define OFF_H0 (OFF_U + 32 * ACT_P)
+#define OFF_ABAR (OFF_H0 + 32 * SM_P)
+#define OFF_PART (OFF_ABAR + 32 * SM_P)
+#define OFF_W1 (OFF_PART + 4 * 32 * SM_P)
+#define OFF_W4 (OFF_W1 + HID * SM_P)
+#define OFF_B1 (OFF_W4 + DPAD * ACT_P)
+#define OFF_B2 (OFF_B1 + HID)
+#define OFF_B3 (OFF_B2 + HID)
+#define OFF_B4 (OFF_B3 + HID)
+#define OFF_DB4 (OFF_B4 + DPAD)
+#define OFF_RED (OFF_DB4 + 16 * DPAD)
+#define LDS_FLOATS (OFF_RED + 64)
+#define LDS_BYTES (LDS_FLOATS * 4)
+
+struct MlpArgs {
+  msgm_mlp_params_t P;
+  const float* y;        // (B,d) inputs (x_t for the sampler)
+  const float* t;        // (B) per-sample time, or null => t_scalar
+  const float* v;        // (B,d) probe (train)
+  float* out;            // forward: a (B,d); EM: x updated in place (== y)
+  int64_t B;
+  int in_dim, in4, d4;   // in_dim = d + 1 (+1 with premodule); in4 = ceil(in/4); d4 = ceil(d/4)
+  float t_scalar;
+  // SDE (SGM)
+  float b0, b1, T;
+  // EM step
+  float delta, sqrt_delta, lmbd;
+  const float* z; const uint64_t* rng; uint64_t rng_step;
+  // train
+  float inv_batch;
+  float* loss_per; float* slabs;   // slabs: [gridDim.x][n_params + 1] (last = loss sum)
+  int64_t n_params;
+};
+
+enum { MODE_FWD = 0, MODE_EM = 1, MODE_TRAIN = 2 };
+
+// Swish and its first two derivatives from z.
+__device__ __forceinline__ void swish012(float z, float& s0, float& s1, float& s2) {
+  float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-z));
+  float om = 1.0f - sg;
+  s0 = z * sg;
+  s1 = sg * (1.0f + z * om);
+  s2 = sg * om * (2.0f + z * (1.0f - 2.0f * sg));
+}
+__device__ __forceinline__ float swish0(float z) { return z * __builtin_amdgcn_rcpf(1.0f + __expf(-z)); }
+
+// A fragment of one 128x128 weight for this wave's 32 output rows, k-group g:
+//  !TR: rows = out features of W (forward);  A[r] = W[32w+16it+il][16g+4q+r]
+//   TR: rows = in features (dgrad, A = W^T); A[r] = W[16g+4q+r][32w+16it+il]
+template <bool TR>
+__device__ __forceinline__ f32x4 load_afrag(const float* __restrict__ W, int w, int il, int q, int it, int g) {
+  if (!TR) return *reinterpret_cast<const f32x4*>(W + (32 * w + 16 * it + il) * HID + 16 * g + 4 * q);
+  const float* p = W + (16 * g + 4 * q) * HID + 32 * w + 16 * it + il;
+  return f32x4{p[0], p[HID], p[2 * HID], p[3 * HID]};
+}
+
+// The weights are streamed from L2 into registers PF k-groups ahead of use
+// (a k-group = 16 MFMAs = 512 cycles of matrix pipe per wave), so only
+// (PF+1) x 8 registers hold weights at any time; `pre` carries groups
+// 0..PF-1 of the NEXT gemm across the phase boundary.
+#define PF 2
+struct WPre { f32x4 a[PF][2]; };
+
+template <bool TR>
+__device__ __forceinline__ void prefetch_w(const float* __restrict__ W, int w, int il, int q, WPre& pre) {
+#pragma unroll
+  for (int g = 0; g < PF; ++g) { pre.a[g][0] = load_afrag<TR>(W, w, il, q, 0, g); pre.a[g][1] = load_afrag<TR>(W, w, il, q, 1, g); }
+}
+
+// acc[it][ck] += sum_k A[it][k] * buf[ck*16+il][k]   (K = 128, B operand from LDS)
+// Software-pipelined by hand: the LDS reads of group g+1 and the global loads of
+// group g+PF are issued ahead of the 16 MFMAs of group g; the sched_barrier keeps
+// hipcc from hoisting every load to the top (which spills) or sinking them.
+template <bool TR>
+__device__ __forceinline__ void gemm128(const float* __restrict__ W, const WPre& pre, const float* buf, int w, int il,
+                                        int q, f32x4 (&acc)[2][2]) {
+  f32x4 ring[PF + 1][2];
+#pragma unroll
+  for (int g = 0; g < PF; ++g) { ring[g][0] = pre.a[g][0]; ring[g][1] = pre.a[g][1]; }
+  const float* bp0 = buf + il * ACT_P + 4 * q;
+  const float* bp1 = buf + (16 + il) * ACT_P + 4 * q;
+  f32x4 bn0 = *reinterpret_cast<const f32x4*>(bp0), bn1 = *reinterpret_cast<const f32x4*>(bp1);
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    const f32x4 b0 = bn0, b1 = bn1;
+    if (g + PF < 8) {
+      ring[(g + PF) % (PF + 1)][0] = load_afrag<TR>(W, w, il, q, 0, g + PF);
+      ring[(g + PF) % (PF + 1)][1] = load_afrag<TR>(W, w, il, q, 1, g + PF);
+    }
+    if (g + 1 < 8) {
+      bn0 = *reinterpret_cast<const f32x4*>(bp0 + 16 * (g + 1));
+      bn1 = *reinterpret_cast<const f32x4*>(bp1 + 16 * (g + 1));
+    }
+    const f32x4 a0 = ring[g % (PF + 1)][0], a1 = ring[g % (PF + 1)][1];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      acc[0][0] = mfma16(a0[r], b0[r], acc[0][0]);
+      acc[0][1] = mfma16(a0[r], b1[r], acc[0][1]);
+      acc[1][0] = mfma16(a1[r], b0[r], acc[1][0]);
+      acc[1][1] = mfma16(a1[r], b1[r], acc[1][1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// store this wave's C-layout tile pair to an activation buffer ([sample][feature])
+__device__ __forceinline__ void store_act(float* buf, int w, int il, int q, const f32x4 (&h)[2][2]) {
+#pragma unroll
+  for (int it = 0; it < 2; ++it)
+#pragma unroll
+    for (int ck = 0; ck < 2; ++ck)
+      *reinterpret_cast<f32x4*>(buf + (ck * 16 + il) * ACT_P + 32 * w + 16 * it + 4 * q) = h[it][ck];
+}
+
+// dW[it][kt] += sum_n ZB[feat][n] * HB[k][n] over the 32 dual columns.
+// A (lane il = feature) and B (lane il = k) are read as b32 from [sample][feature]
+// buffers, one (ck,s) step ahead of the MFMAs that consume them.
+template <int KT>
+__device__ __forceinline__ void wgrad(const float* zb, const float* hb, int hb_pitch, int w, int il, int q,
+                                      f32x4 (&dW)[2][KT]) {
+  float na0, na1, nb[KT];
+  {
+    const int n = q;
+    na0 = zb[n * ACT_P + 32 * w + il]; na1 = zb[n * ACT_P + 32 * w + 16 + il];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) nb[kt] = hb[n * hb_pitch + 16 * kt + il];
+  }
+#pragma unroll
+  for (int st = 0; st < 8; ++st) {
+    const float a0 = na0, a1 = na1;
+    float b[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) b[kt] = nb[kt];
+    if (st + 1 < 8) {
+      const int n = ((st + 1) >> 2) * 16 + 4 * ((st + 1) & 3) + q;
+      na0 = zb[n * ACT_P + 32 * w + il]; na1 = zb[n * ACT_P + 32 * w + 16 + il];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) nb[kt] = hb[n * hb_pitch + 16 * kt + il];
+    }
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      dW[0][kt] = mfma16(a0, b[kt], dW[0][kt]);
+      dW[1][kt] = mfma16(a1, b[kt], dW[1][kt]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// dual Swish backward in registers: (gP,gT) cotangents of (hP,hT) -> cotangents of (zP,zT)
+__device__ __forceinline__ void swish_bwd(const f32x4 (&z)[2][2], const f32x4 (&g)[2][2], f32x4 (&zb)[2][2]) {
+#pragma unroll
+  for (int it = 0; it < 2; ++it)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float s0, s1, s2;
+      swish012(z[it][0][r], s0, s1, s2);
+      zb[it][1][r] = g[it][1][r] * s1;
+      zb[it][0][r] = g[it][0][r] * s1 + g[it][1][r] * (s2 * z[it][1][r]);
+    }
+}
+
+template <int MODE, bool WIDE>
+__global__ void __launch_bounds__(256, 1) k_mlp(MlpArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int KT1 = WIDE ? 2 : 1;   // k-tiles of the first layer's input (in_dim <= 16 / 32)
+  constexpr int OT = WIDE ? 2 : 1;    // o-tiles of the last layer's output (d <= 16 / 32)
+  constexpr int SPT = (MODE == MODE_TRAIN) ? 16 : 32;   // samples per tile
+  const int tid = threadIdx.x;
+  const int w = tid >> 6, lane = tid & 63, il = lane & 15, q = lane >> 4;
+  const int d = A.P.d;
+  float* X = lds + OFF_X; float* Y = lds + OFF_Y; float* Z = lds + OFF_Z; float* U = lds + OFF_U;
+  float* H0 = lds + OFF_H0; float* ABAR = lds + OFF_ABAR; float* PART = lds + OFF_PART;
+  float* W1s = lds + OFF_W1; float* W4s = lds + OFF_W4;
+  float* B1s = lds + OFF_B1; float* B2s = lds + OFF_B2; float* B3s = lds + OFF_B3; float* B4s = lds + OFF_B4;
+  float* DB4 = lds + OFF_DB4; float* RED = lds + OFF_RED;
+
+  // ---- one-time staging of the small layers and biases -------------------
+  for (int i = tid; i < HID * SM_P; i += 256) {
+    int r = i / SM_P, c = i - r * SM_P;
+    W1s[i] = (c < A.in_dim) ? A.P.W1[r * A.in_dim + c] : 0.f;
+  }
+  for (int i = tid; i < DPAD * ACT_P; i += 256) {
+    int r = i / ACT_P, c = i - r * ACT_P;
+    W4s[i] = (r < d && c < HID) ? A.P.W4[r * HID + c] : 0.f;
+  }
+  for (int i = tid; i < HID; i += 256) { B1s[i] = A.P.b1[i]; B2s[i] = A.P.b2[i]; B3s[i] = A.P.b3[i]; }
+  if (tid < DPAD) B4s[tid] = tid < d ? A.P.b4[tid] : 0.f;
+  for (int i = tid; i < 16 * DPAD; i += 256) DB4[i] = 0.f;
+  for (int i = tid; i < 32 * SM_P; i += 256) { H0[i] = 0.f; ABAR[i] = 0.f; }
+
+  // persistent accumulators (train)
+  f32x4 dW2[2][8], dW3[2][8], dW1[2][KT1], dW4[2][OT], db1[2], db2[2], db3[2];
+  float loss_acc = 0.f;
+  if (MODE == MODE_TRAIN) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { dW2[it][k] = f32x4{0, 0, 0, 0}; dW3[it][k] = f32x4{0, 0, 0, 0}; }
+#pragma unroll
+      for (int k = 0; k < KT1; ++k) dW1[it][k] = f32x4{0, 0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < OT; ++k) dW4[it][k] = f32x4{0, 0, 0, 0};
+      db1[it] = f32x4{0, 0, 0, 0}; db2[it] = f32x4{0, 0, 0, 0}; db3[it] = f32x4{0, 0, 0, 0};
+    }
+  }
+
+  WPre pre;
+  prefetch_w<false>(A.P.W2, w, il, q, pre);
+  __syncthreads();
+
+  const int64_t n_tiles = (A.B + SPT - 1) / SPT;
+  const float ca = 1.0f - 0.5f * A.lmbd;
+
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t s_base = tile * SPT;
+    // ---- phase 0: h0 (and its tangent) -----------------------------------
+    // premodule none: h0 = [y, t], h0dot = [v, 0]                     NN.py:113-119
+    // NormalizeLogRadius: h0 = [y/r, log r, t], r = |y| + 1e-6          NN.py:56-70
+    if (tid < 32 && (MODE != MODE_TRAIN || tid < 16)) {
+      const int64_t smp = s_base + tid;
+      const bool live = smp < A.B;
+      float* hp = H0 + tid * SM_P;
+      float* ht = H0 + (16 + tid) * SM_P;   // tangent row (train only)
+      float tt = 0.f;
+      if (live) {
+        tt = A.t ? A.t[smp] : A.t_scalar;
+        if (MODE == MODE_EM) tt = A.T - tt;                               // s = T - t  SDEs.py:556-557
+      }
+      const float* yr = A.y + smp * d;
+      const float* vr = (MODE == MODE_TRAIN) ? A.v + smp * d : nullptr;
+      if (A.P.premodule == 0) {
+        for (int i = 0; i < d; ++i) {
+          hp[i] = live ? yr[i] : 0.f;
+          if (MODE == MODE_TRAIN) ht[i] = live ? vr[i] : 0.f;
+        }
+        hp[d] = tt;
+        if (MODE == MODE_TRAIN) ht[d] = 0.f;
+      } else {
+        float ss = 0.f, yv = 0.f;
+        for (int i = 0; i < d; ++i) {
+          float yi = live ? yr[i] : 1.0f;
+          ss += yi * yi;
+          if (MODE == MODE_TRAIN) yv += yi * (live ? vr[i] : 0.f);
+        }
+        const float nr = sqrtf(ss);
+        const float r = nr + 1e-6f;
+        const float rdot = yv / nr;                                        // d|y| along v
+        for (int i = 0; i < d; ++i) {
+          float yi = live ? yr[i] : 1.0f;
+          hp[i] = yi / r;
+          if (MODE == MODE_TRAIN) ht[i] = (live ? vr[i] : 0.f) / r - yi * rdot / (r * r);
+        }
+        hp[d] = logf(r);
+        hp[d + 1] = tt;
+        if (MODE == MODE_TRAIN) { ht[d] = rdot / r; ht[d + 1] = 0.f; }
+      }
+    }
+    __syncthreads();
+
+    // ---- phase 1: layer 1 (K = in_dim, weights from LDS) ------------------
+    f32x4 z1[2][2], z2[2][2], z3[2][2], h[2][2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) { z1[it][0] = f32x4{0, 0, 0, 0}; z1[it][1] = f32x4{0, 0, 0, 0}; }
+    for (int s = 0; s < A.in4; ++s) {
+      const float a0 = W1s[(32 * w + il) * SM_P + 4 * s + q];
+      const float a1 = W1s[(32 * w + 16 + il) * SM_P + 4 * s + q];
+      const float bP = H0[il * SM_P + 4 * s + q];
+      const float bT = H0[(16 + il) * SM_P + 4 * s + q];
+      z1[0][0] = mfma16(a0, bP, z1[0][0]); z1[0][1] = mfma16(a0, bT, z1[0][1]);
+      z1[1][0] = mfma16(a1, bP, z1[1][0]); z1[1][1] = mfma16(a1, bT, z1[1][1]);
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(B1s + 32 * w + 16 * it + 4 * q);
+      z1[it][0] += bb;
+      if (MODE != MODE_TRAIN) z1[it][1] += bb;          // second primal half
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (MODE == MODE_TRAIN) {
+          float s0, s1, s2; swish012(z1[it][0][r], s0, s1, s2);
+          h[it][0][r] = s0; h[it][1][r] = s1 * z1[it][1][r];
+        } else { h[it][0][r] = swish0(z1[it][0][r]); h[it][1][r] = swish0(z1[it][1][r]); }
+      }
+    }
+    store_act(X, w, il, q, h);
+    __syncthreads();
+
+    // ---- phase 2: layer 2 --------------------------------------------------
+#pragma unroll
+    for (int it = 0; it < 2; ++it) { z2[it][0] = f32x4{0, 0, 0, 0}; z2[it][1] = f32x4{0, 0, 0, 0}; }
+    gemm128<false>(A.P.W2, pre, X, w, il, q, z2);
+    prefetch_w<false>(A.P.W3, w, il, q, pre);          // head of the next gemm's weights
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(B2s + 32 * w + 16 * it + 4 * q);
+      z2[it][0] += bb;
+      if (MODE != MODE_TRAIN) z2[it][1] += bb;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (MODE == MODE_TRAIN) {
+          float s0, s1, s2; swish012(z2[it][0][r], s0, s1, s2);
+          h[it][0][r] = s0; h[it][1][r] = s1 * z2[it][1][r];
+        } else { h[it][0][r] = swish0(z2[it][0][r]); h[it][1][r] = swish0(z2[it][1][r]); }
+      }
+    }
+    store_act(Y, w, il, q, h);
+    __syncthreads();
+
+    // ---- phase 3: layer 3, then this wave's K-slice of layer 4 -------------
+#pragma unroll
+    for (int it = 0; it < 2; ++it) { z3[it][0] = f32x4{0, 0, 0, 0}; z3[it][1] = f32x4{0, 0, 0, 0}; }
+    gemm128<false>(A.P.W3, pre, Y, w, il, q, z3);
+    if (MODE == MODE_TRAIN) prefetch_w<true>(A.P.W3, w, il, q, pre);   // W3^T for dgrad
+    else prefetch_w<false>(A.P.W2, w, il, q, pre);                     // next tile's layer 2
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(B3s + 32 * w + 16 * it + 4 * q);
+      z3[it][0] += bb;
+      if (MODE != MODE_TRAIN) z3[it][1] += bb;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (MODE == MODE_TRAIN) {
+          float s0, s1, s2; swish012(z3[it][0][r], s0, s1, s2);
+          h[it][0][r] = s0; h[it][1][r] = s1 * z3[it][1][r];
+        } else { h[it][0][r] = swish0(z3[it][0][r]); h[it][1][r] = swish0(z3[it][1][r]); }
+      }
+    }
+    if (MODE == MODE_TRAIN) store_act(Z, w, il, q, h);   // h3 is the dW4 operand later
+    {
+      // partial[o][col] = sum_{k in this wave's 32 features} W4[o][k] h3[k][col]; B operand = registers
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot) {
+        f32x4 p0 = {0, 0, 0, 0}, p1 = {0, 0, 0, 0};
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const f32x4 a4 = *reinterpret_cast<const f32x4*>(W4s + (16 * ot + il) * ACT_P + 32 * w + 16 * it + 4 * q);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            p0 = mfma16(a4[r], h[it][0][r], p0);
+            p1 = mfma16(a4[r], h[it][1][r], p1);
+          }
+        }
+        *reinterpret_cast<f32x4*>(PART + (w * 32 + il) * SM_P + 16 * ot + 4 * q) = p0;
+        *reinterpret_cast<f32x4*>(PART + (w * 32 + 16 + il) * SM_P + 16 * ot + 4 * q) = p1;
+      }
+    }
+    __syncthreads();
+
+    // ---- phase 4: reduce layer-4 partials; outputs / loss ------------------
+    if (MODE == MODE_FWD || MODE == MODE_EM) {
+      // 32 samples x d outputs
+      for (int idx = tid; idx < 32 * d; idx += 256) {
+        const int c = idx / d, o = idx - c * d;
+        const int64_t smp = s_base + c;
+        if (smp < A.B) {
+          float a = B4s[o];
+#pragma unroll
+          for (int ww = 0; ww < 4; ++ww) a += PART[(ww * 32 + c) * SM_P + o];
+          const int64_t e = smp * d + o;
+          if (MODE == MODE_FWD) {
+            A.out[e] = a;
+          } else {
+            // x += [(1-l/2) sqrt(beta) a + 1/2 beta x] delta + sqrt(1-l) sqrt(beta) dW
+            // (SDEs.py:556-561,587-588; sde_scheme.py:82-84,38-40)
+            const float s = A.T - A.t_scalar;
+            const float beta = sde_beta(A.b0, A.b1, s);
+            const float sb = sqrtf(beta);
+            const float x = A.y[e];
+            const float zz = A.z ? A.z[e] : philox_normal1(A.rng, A.rng_step, RNG_STREAM_DW, (uint64_t)e);
+            const float mu = ca * (sb * a) - (-0.5f * beta * x);
+            A.out[e] = x + (mu * A.delta + (sqrtf(1.0f - A.lmbd) * sb) * (A.sqrt_delta * zz));
+          }
+        }
+      }
+      __syncthreads();   // PART / H0 are rewritten by the next tile
+      continue;
+    }
+
+    if (MODE == MODE_TRAIN) {
+      if (tid < 16) {
+        const int64_t smp = s_base + tid;
+        const bool live = smp < A.B;
+        const float wgt = live ? A.inv_batch : 0.f;
+        float beta = 0.f, sb = 0.f;
+        if (live) { beta = sde_beta(A.b0, A.b1, A.t[smp]); sb = sqrtf(beta); }
+        float lj = 0.f;
+        for (int o = 0; o < d; ++o) {
+          float a = B4s[o], ad = 0.f;
+#pragma unroll
+          for (int ww = 0; ww < 4; ++ww) { a += PART[(ww * 32 + tid) * SM_P + o]; ad += PART[(ww * 32 + 16 + tid) * SM_P + o]; }
+          const float vo = live ? A.v[smp * d + o] : 0.f;
+          // loss_b = sum_o v_o (sqrt(beta) adot_o + 1/2 beta v_o) + 1/2 a_o^2     SDEs.py:631-646
+          lj += vo * (sb * ad + 0.5f * beta * vo) + 0.5f * a * a;
+          const float ab = a * wgt, adb = sb * vo * wgt;
+          ABAR[tid * SM_P + o] = ab;
+          ABAR[(16 + tid) * SM_P + o] = adb;
+          DB4[tid * DPAD + o] += ab;
+        }
+        if (live) { loss_acc += lj; if (A.loss_per) A.loss_per[smp] = lj; }
+      }
+      __syncthreads();
+
+      // ---- phase 5: layer-4 backward, dW4, Swish' on layer 3 --------------
+      f32x4 g[2][2], zb[2][2];
+#pragma unroll
+      for (int it = 0; it < 2; ++it) { g[it][0] = f32x4{0, 0, 0, 0}; g[it][1] = f32x4{0, 0, 0, 0}; }
+      for (int s = 0; s < A.d4; ++s) {
+        const float a0 = W4s[(4 * s + q) * ACT_P + 32 * w + il];
+        const float a1 = W4s[(4 * s + q) * ACT_P + 32 * w + 16 + il];
+        const float bP = ABAR[il * SM_P + 4 * s + q];
+        const float bT = ABAR[(16 + il) * SM_P + 4 * s + q];
+        g[0][0] = mfma16(a0, bP, g[0][0]); g[0][1] = mfma16(a0, bT, g[0][1]);
+        g[1][0] = mfma16(a1, bP, g[1][0]); g[1][1] = mfma16(a1, bT, g[1][1]);
+      }
+      wgrad<OT>(Z, ABAR, SM_P, w, il, q, dW4);          // dW4^T[feat][o] += h3 . abar
+      swish_bwd(z3, g, zb);
+      db3[0] += zb[0][0]; db3[1] += zb[1][0];
+      store_act(U, w, il, q, zb);
+      __syncthreads();
+
+      // ---- phase 6: dgrad layer 3 (W3^T), dW3, Swish' on layer 2 -----------
+#pragma unroll
+      for (int it = 0; it < 2; ++it) { g[it][0] = f32x4{0, 0, 0, 0}; g[it][1] = f32x4{0, 0, 0, 0}; }
+      gemm128<true>(A.P.W3, pre, U, w, il, q, g);
+      prefetch_w<true>(A.P.W2, w, il, q, pre);           // W2^T for the next dgrad
+      wgrad<8>(U, Y, ACT_P, w, il, q, dW3);
+      swish_bwd(z2, g, zb);
+      db2[0] += zb[0][0]; db2[1] += zb[1][0];
+      store_act(Z, w, il, q, zb);                          // h3 is dead after phase 5
+      __syncthreads();
+
+      // ---- phase 7: dgrad layer 2 (W2^T), dW2, Swish' on layer 1 -----------
+#pragma unroll
+      for (int it = 0; it < 2; ++it) { g[it][0] = f32x4{0, 0, 0, 0}; g[it][1] = f32x4{0, 0, 0, 0}; }
+      gemm128<true>(A.P.W2, pre, Z, w, il, q, g);
+      prefetch_w<false>(A.P.W2, w, il, q, pre);          // next tile's layer 2
+      wgrad<8>(Z, X, ACT_P, w, il, q, dW2);
+      swish_bwd(z1, g, zb);
+      db1[0] += zb[0][0]; db1[1] += zb[1][0];
+      store_act(U, w, il, q, zb);                          // zbar3 is dead after phase 6
+      __syncthreads();
+
+      // ---- phase 8: dW1 ------------------------------------------------------
+      wgrad<KT1>(U, H0, SM_P, w, il, q, dW1);
+      __syncthreads();   // H0/ABAR/PART/X.. are rewritten by the next tile
+    }
+  }
+
+  // ---- epilogue (train): write this workgroup's gradient slab -------------
+  if (MODE == MODE_TRAIN) {
+    float* slab = A.slabs + (int64_t)blockIdx.x * (A.n_params + 1);
+    const int in_dim = A.in_dim;
+    const int64_t oW1 = 0, ob1 = oW1 + (int64_t)HID * in_dim, oW2 = ob1 + HID, ob2 = oW2 + HID * HID,
+                  oW3 = ob2 + HID, ob3 = oW3 + HID * HID, oW4 = ob3 + HID, ob4 = oW4 + (int64_t)d * HID;
+    // dW2 / dW3: lane (k = 16kt+il, q), reg r -> row 32w+16it+4q+r
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 32 * w + 16 * it + 4 * q + r, col = 16 * kt + il;
+          slab[oW2 + row * HID + col] = dW2[it][kt][r];
+          slab[oW3 + row * HID + col] = dW3[it][kt][r];
+        }
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int kt = 0; kt < KT1; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 32 * w + 16 * it + 4 * q + r, col = 16 * kt + il;
+          if (col < in_dim) slab[oW1 + (int64_t)row * in_dim + col] = dW1[it][kt][r];
+        }
+    // dW4 held transposed: lane (o = 16ot+il, q), reg r -> feature 32w+16it+4q+r
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int feat = 32 * w + 16 * it + 4 * q + r, o = 16 * ot + il;
+          if (o < d) slab[oW4 + (int64_t)o * HID + feat] = dW4[it][ot][r];
+        }
+    // biases: sum the primal cotangents over the 16 sample lanes
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s1 = db1[it][r], s2 = db2[it][r], s3 = db3[it][r];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); s3 += __shfl_xor(s3, o, 64); }
+        if (il == 0) {
+          const int feat = 32 * w + 16 * it + 4 * q + r;
+          slab[ob1 + feat] = s1; slab[ob2 + feat] = s2; slab[ob3 + feat] = s3;
+        }
+      }
+    __syncthreads();
+    if (tid < d) {
+      float s = 0.f;
+      for (int j = 0; j < 16; ++j) s += DB4[j * DPAD + tid];
+      slab[ob4 + tid] = s;
+    }
+    if (tid < 16) RED[tid] = loss_acc;
+    __syncthreads();
+    if (tid == 0) {
+      float s = 0.f;
+      for (int j = 0; j < 16; ++j) s += RED[j];
+      slab[A.n_params] = s;
+    }
+  }
+}
+
+// grads[p] = sum_wg slab[wg][p]; last element = loss sum (scaled by inv_batch -> mean)
+__global__ void k_slab_reduce(const float* __restrict__ slabs, int n_slabs, int64_t stride, float* __restrict__ grads,
+                              int64_t n_params, float* __restrict__ loss_sum, float inv_batch) {
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p <= n_params; p += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int g = 0; g < n_slabs; ++g) s += slabs[g * stride + p];
+    if (p < n_params) grads[p] = s;
+    else if (loss_sum) loss_sum[0] = s * inv_batch;
+  }
+}
+
+// ============================================================ C ABI
+static inline hipStream_t S(msgm_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+static const int MLP_MAX_GRID = 256;
+
+template <int MODE, bool WIDE>
+static void set_lds_attr() {
+  static const int once = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp<MODE, WIDE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    return 0;
+  }();
+  (void)once;
+}
+
+template <int MODE>
+static int launch_mlp(const MlpArgs& A, int grid, hipStream_t st) {
+  const bool wide = A.in_dim > 16 || A.P.d > 16;
+  if (wide) { set_lds_attr<MODE, true>(); hipLaunchKernelGGL((k_mlp<MODE, true>), dim3(grid), dim3(256), LDS_BYTES, st, A); }
+  else { set_lds_attr<MODE, false>(); hipLaunchKernelGGL((k_mlp<MODE, false>), dim3(grid), dim3(256), LDS_BYTES, st, A); }
+  return msgm_check_launch();
+}
+
+static int fill_common(MlpArgs& A, const msgm_mlp_params_t* P, int64_t B) {
+  if (!P || !P->W1 || !P->b1 || !P->W2 || !P->b2 || !P->W3 || !P->b3 || !P->W4 || !P->b4 || B <= 0) return MSGM_E_BADARG;
+  if (P->d < 1 || P->d > 30 || (P->premodule != 0 && P->premodule != 1)) return MSGM_E_UNSUPPORTED;
+  A.P = *P; A.B = B;
+  A.in_dim = P->d + 1 + (P->premodule ? 1 : 0);
+  A.in4 = (A.in_dim + 3) / 4; A.d4 = (P->d + 3) / 4;
+  return MSGM_OK;
+}
+
+extern "C" {
+
+int64_t msgm_mlp_num_params(int32_t d, int32_t premodule) {
+  const int64_t in_dim = d + 1 + (premodule ? 1 : 0);
+  return HID * in_dim + HID + 2 * ((int64_t)HID * HID + HID) + (int64_t)d * HID + d;
+}
+
+size_t msgm_mlp_ssm_workspace(int32_t d, int32_t premodule) {
+  return (size_t)MLP_MAX_GRID * (size_t)(msgm_mlp_num_params(d, premodule) + 1) * sizeof(float);
+}
+
+int msgm_mlp_forward(const msgm_mlp_params_t* P, const float* y, const float* t, float* a, int64_t B,
+                     msgm_stream_t stream) {
+  MlpArgs A{};
+  int rc = fill_common(A, P, B);
+  if (rc) return rc;
+  if (!y || !t || !a) return MSGM_E_BADARG;
+  A.y = y; A.t = t; A.out = a;
+  const int64_t tiles = (B + 31) / 32;
+  return launch_mlp<MODE_FWD>(A, (int)(tiles < MLP_MAX_GRID ? tiles : MLP_MAX_GRID), S(stream));
+}
+
+int msgm_mlp_em_step(const msgm_mlp_params_t* P, float* x, int64_t B, const msgm_sde_t* sde, float t, float delta,
+                     float lmbd, const float* z, const uint64_t* rng, uint64_t rng_step, msgm_stream_t stream) {
+  MlpArgs A{};
+  int rc = fill_common(A, P, B);
+  if (rc) return rc;
+  if (!x || !sde || (!z && !rng)) return MSGM_E_BADARG;
+  if (sde->kind != MSGM_SDE_SGM) return MSGM_E_UNSUPPORTED;
+  A.y = x; A.out = x; A.t = nullptr; A.t_scalar = t;
+  A.b0 = sde->beta_min; A.b1 = sde->beta_max; A.T = sde->T;
+  A.delta = delta; A.sqrt_delta = (float)sqrt((double)delta); A.lmbd = lmbd;
+  A.z = z; A.rng = rng; A.rng_step = rng_step;
+  const int64_t tiles = (B + 31) / 32;
+  return launch_mlp<MODE_EM>(A, (int)(tiles < MLP_MAX_GRID ? tiles : MLP_MAX_GRID), S(stream));
+}
+
+int msgm_mlp_ssm_grad(const msgm_mlp_params_t* P, const float* y, const float* t, const float* v, int64_t B,
+                      const msgm_sde_t* sde, float inv_batch, float* grads, float* loss_per, float* loss_sum,
+                      void* workspace, size_t workspace_bytes, msgm_stream_t stream) {
+  MlpArgs A{};
+  int rc = fill_common(A, P, B);
+  if (rc) return rc;
+  if (!y || !t || !v || !sde || !grads || !workspace) return MSGM_E_BADARG;
+  if (sde->kind != MSGM_SDE_SGM) return MSGM_E_UNSUPPORTED;
+  if (workspace_bytes < msgm_mlp_ssm_workspace(P->d, P->premodule)) return MSGM_E_WORKSPACE;
+  A.y = y; A.t = t; A.v = v;
+  A.b0 = sde->beta_min; A.b1 = sde->beta_max; A.T = sde->T;
+  A.inv_batch = inv_batch; A.loss_per = loss_per; A.slabs = reinterpret_cast<float*>(workspace);
+  A.n_params = msgm_mlp_num_params(P->d, P->premodule);
+  const int64_t tiles = (B + 15) / 16;
+  const int grid = (int)(tiles < MLP_MAX_GRID ? tiles : MLP_MAX_GRID);
+  rc = launch_mlp<MODE_TRAIN>(A, grid, S(stream));
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_slab_reduce, dim3(grid_for(A.n_params + 1, 256, 256)), dim3(256), 0, S(stream), A.slabs, grid,
+                     A.n_params + 1, grads, A.n_params, loss_sum, inv_batch);
+  return msgm_check_launch();
+}
+
+}  // extern "C"

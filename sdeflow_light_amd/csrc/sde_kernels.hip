@@ -1,0 +1,498 @@
+// sde_kernels.hip — HBM-bound elementwise / row-reduced kernels of the SDE
+// hot path (K1 perturb_vp, K2/K3/K4 integrator stages, K13 Adam, helpers).
+// gfx950 only.  Reference lines are cited per kernel (relative to
+// /root/reference).
+#include "common.h"
+
+// ============================================================ RNG helpers
+__global__ void k_rng_advance(uint64_t* rng, uint64_t n) { rng[1] += n; }
+__global__ void k_counter_inc(int64_t* c) { c[0] += 1; }
+
+template <bool NORMAL>
+__global__ void k_fill(float* __restrict__ out, int64_t n, const uint64_t* __restrict__ rng, uint32_t stream) {
+  int64_t nq = (n + 3) >> 2;
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+    f32x4 r = NORMAL ? philox_normal4(rng, 0, stream, q) : philox_uniform4(rng, 0, stream, q);
+    int64_t e = q << 2;
+    if (e + 3 < n && ((reinterpret_cast<uintptr_t>(out) & 15) == 0)) {
+      *reinterpret_cast<f32x4*>(out + e) = r;
+    } else {
+      for (int k = 0; k < 4 && e + k < n; ++k) out[e + k] = r[k];
+    }
+  }
+}
+
+// ============================================================ K1 perturb_vp
+// t_b = clamp(u_b T) (SDEs.py:688-693), y = eps*sqrt(var(t)) + mean_weight(t)*x0
+// (SDEs.py:139-142).  One thread per element-quad of the flat (B*d) tensor.
+__global__ void k_perturb_vp(const float* __restrict__ x0, float* __restrict__ y, float* __restrict__ t_out,
+                             float* __restrict__ eps_out, int64_t B, int64_t d, float b0, float b1, float T,
+                             float t_eps, const float* __restrict__ u, const float* __restrict__ eps,
+                             const uint64_t* __restrict__ rng) {
+  const int64_t n = B * d;
+  const int64_t nq = (n + 3) >> 2;
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e0 = q << 2;
+    f32x4 ez;
+    if (eps == nullptr) ez = philox_normal4(rng, 0, RNG_STREAM_EPS, q);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t e = e0 + k;
+      if (e >= n) break;
+      const int64_t b = e / d;
+      float ub = u ? u[b] : philox_uniform1(rng, 0, RNG_STREAM_T, (uint64_t)b);
+      float t = ub * T;
+      float m = (t <= t_eps) ? 1.0f : 0.0f;              // mask arithmetic as upstream
+      t = m * t_eps + (1.0f - m) * t;
+      float ee = eps ? eps[e] : ez[k];
+      float mw = vp_mean_weight(b0, b1, t);
+      float sd = sqrtf(vp_var(b0, b1, t));
+      y[e] = ee * sd + mw * x0[e];
+      if (eps_out) eps_out[e] = ee;
+      if (e - b * d == 0) t_out[b] = t;
+    }
+  }
+}
+
+// bit-exact stop index                                        SDEs.py:89-101
+__global__ void k_forward_step_index(const float* __restrict__ t, int32_t* __restrict__ k, int64_t B, int32_t nsf, float T) {
+  for (int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; b < B; b += (int64_t)gridDim.x * blockDim.x) {
+    float tb = t[b];
+    float f = __fdiv_rn(__fmul_rn((float)nsf, tb), T);   // (nsf*t)/T in fp32, no contraction
+    int32_t kk = (int32_t)truncf(f);
+    if (tb >= T) kk = nsf;
+    k[b] = kk;
+  }
+}
+
+__global__ void k_rademacher(float* __restrict__ v, int64_t n, const float* __restrict__ u, const uint64_t* __restrict__ rng) {
+  const int64_t nq = (n + 3) >> 2;
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+    f32x4 r;
+    if (!u) r = philox_uniform4(rng, 0, RNG_STREAM_V, q);
+    for (int k = 0; k < 4; ++k) {
+      int64_t e = (q << 2) + k;
+      if (e >= n) break;
+      float uu = u ? u[e] : r[k];
+      v[e] = (uu >= 0.5f) ? 1.0f : -1.0f;                 // 2*[u>=.5]-1   SDEs.py:515
+    }
+  }
+}
+
+// ============================================================ integrator stage
+struct StageArgs {
+  float* out; const float* base; float c_out;
+  const float* x; const float* a; const float* dW; const float* z; float sqrt_delta;
+  const uint64_t* rng; uint64_t rng_step; float* dW_out;
+  int64_t B; int64_t n;
+  int kind, proc, strato;
+  float b0, b1, T, t, delta, lmbd;
+  const float* G; const float* L_G;
+  const float* norm0;
+};
+
+__device__ __forceinline__ float stage_noise(const StageArgs& A, int64_t e) {
+  if (A.dW) return A.dW[e];
+  float zz = A.z ? A.z[e] : philox_normal1(A.rng, A.rng_step, RNG_STREAM_DW, (uint64_t)e);
+  return A.sqrt_delta * zz;                                // delta**0.5 * randn   sde_scheme.py:84
+}
+
+// SGM (diagonal) flat kernel, no norm correction: 12-16 B/element.
+// Reverse: mu = (1-l/2) sqrt(beta) a + 1/2 beta x (SDEs.py:560-561,183-194 with
+// divSigma = 0); sigma = sqrt(1-l) sqrt(beta).  Forward: mu = -1/2 beta x.
+__global__ void k_stage_diag_flat(StageArgs A) {
+  const int64_t n = A.B * A.n;
+  const int64_t nq = (n + 3) >> 2;
+  const float s = A.proc == MSGM_PROC_REVERSE ? A.T - A.t : A.t;
+  const float beta = sde_beta(A.b0, A.b1, s);
+  const float sb = sqrtf(beta);
+  const float ca = (1.0f - 0.5f * A.lmbd);
+  const float sig = (A.proc == MSGM_PROC_REVERSE ? sqrtf(1.0f - A.lmbd) : 1.0f) * sb;
+  const bool vec = (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(A.x) | reinterpret_cast<uintptr_t>(A.out) |
+                                     reinterpret_cast<uintptr_t>(A.a) | reinterpret_cast<uintptr_t>(A.dW) |
+                                     reinterpret_cast<uintptr_t>(A.z) | reinterpret_cast<uintptr_t>(A.base) |
+                                     reinterpret_cast<uintptr_t>(A.dW_out)) & 15) == 0;
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e0 = q << 2;
+    f32x4 xv, av = {0, 0, 0, 0}, wv, bv = {0, 0, 0, 0};
+    if (vec) {
+      xv = *reinterpret_cast<const f32x4*>(A.x + e0);
+      if (A.proc == MSGM_PROC_REVERSE) av = *reinterpret_cast<const f32x4*>(A.a + e0);
+      if (A.base) bv = (A.base == A.x) ? xv : *reinterpret_cast<const f32x4*>(A.base + e0);
+      if (A.dW) wv = *reinterpret_cast<const f32x4*>(A.dW + e0);
+      else {
+        f32x4 zz = A.z ? *reinterpret_cast<const f32x4*>(A.z + e0) : philox_normal4(A.rng, A.rng_step, RNG_STREAM_DW, q);
+        wv = A.sqrt_delta * zz;
+      }
+    } else {
+      for (int k = 0; k < 4; ++k) {
+        int64_t e = e0 + k;
+        if (e < n) {
+          xv[k] = A.x[e];
+          if (A.proc == MSGM_PROC_REVERSE) av[k] = A.a[e];
+          if (A.base) bv[k] = A.base[e];
+          wv[k] = stage_noise(A, e);
+        }
+      }
+    }
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float mu;
+      if (A.proc == MSGM_PROC_REVERSE) mu = ca * (sb * av[k]) - (-0.5f * beta * xv[k]);
+      else mu = -0.5f * beta * xv[k];
+      float inc = mu * A.delta + sig * wv[k];
+      o[k] = bv[k] + A.c_out * inc;
+    }
+    if (vec) {
+      *reinterpret_cast<f32x4*>(A.out + e0) = o;
+      if (A.dW_out) *reinterpret_cast<f32x4*>(A.dW_out + e0) = wv;
+    } else {
+      for (int k = 0; k < 4; ++k) {
+        int64_t e = e0 + k;
+        if (e < n) { A.out[e] = o[k]; if (A.dW_out) A.dW_out[e] = wv[k]; }
+      }
+    }
+  }
+}
+
+// Row kernel: a group of GS lanes owns one row; handles all three layouts and
+// the optional norm correction (x <- x * norm0/||x||, sde_scheme.py:85-86).
+//  sparse: dx_i = c sb (x_{i+1} w_i - x_{i-1} w_{i-1}), c = sqrt(2)/2, circular
+//          (SDEs.py:369-399,425-430; sde_scheme.py:27-32).
+//  dense : dx_i = sum_{j,k} G[i,j,k] (sb x_j) w_k (SDEs.py:432; sde_scheme.py:36)
+//          and f = L_G (beta x) (SDEs.py:415) — (B,n,n) is never materialised.
+template <int GS>
+__global__ void k_stage_rows(StageArgs A) {
+  const int lane = threadIdx.x & (GS - 1);
+  const int64_t groups_per_block = blockDim.x / GS;
+  const int64_t gid = blockIdx.x * groups_per_block + threadIdx.x / GS;
+  const int64_t gstride = (int64_t)gridDim.x * groups_per_block;
+  const int64_t n = A.n;
+  const float s = A.proc == MSGM_PROC_REVERSE ? A.T - A.t : A.t;
+  const float beta = sde_beta(A.b0, A.b1, s);
+  const float sb = sqrtf(beta);
+  const float l = A.lmbd;
+  const float sig_scale = (A.proc == MSGM_PROC_REVERSE) ? sqrtf(1.0f - l) : 1.0f;
+  const float cV = 0.5f * sqrtf(2.0f);
+  // rows are padded to a multiple of the group count so that shuffles stay convergent
+  const int64_t rows_pad = ((A.B + gstride - 1) / gstride) * gstride;
+  for (int64_t b = gid; b < rows_pad; b += gstride) {
+    const bool live = b < A.B;
+    const float* xr = A.x + b * n;
+    const float* ar = A.a ? A.a + b * n : nullptr;
+    float ss = 0.f;
+    if (live) {
+      for (int64_t i = lane; i < n; i += GS) {
+        const int64_t e = b * n + i;
+        float xi = xr[i];
+        float w_i = stage_noise(A, e);
+        if (A.dW_out) A.dW_out[e] = w_i;
+        float ga = 0.f, gw = 0.f, f = 0.f, div = 0.f, fs = 0.f;
+        if (A.kind == MSGM_SDE_SGM) {
+          f = -0.5f * beta * xi; fs = f; div = 0.f;
+          if (ar) ga = sb * ar[i];
+          gw = sb * w_i;
+        } else if (A.kind == MSGM_SDE_MSGM_SPARSE) {
+          const int64_t ip = (i + 1 == n) ? 0 : i + 1, im = (i == 0) ? n - 1 : i - 1;
+          const float xp = xr[ip], xm = xr[im];
+          const float w_m = stage_noise(A, b * n + im);
+          f = 0.5f * beta * xi; fs = 0.f; div = 2.0f * f;
+          // entries (I=i,J=i+1,K=i,V=+c) and (I=i,J=i-1,K=i-1,V=-c)
+          gw = (cV * (sb * xp)) * w_i + (-cV * (sb * xm)) * w_m;
+          if (ar) ga = (cV * (sb * xp)) * ar[i] + (-cV * (sb * xm)) * ar[im];
+        } else {  // dense
+          float accw = 0.f, acca = 0.f, accf = 0.f;
+          const float* Gi = A.G + i * n * n;
+          for (int64_t j = 0; j < n; ++j) {
+            const float yj = sb * xr[j];
+            accf += A.L_G[i * n + j] * (beta * xr[j]);
+            float rw = 0.f, ra = 0.f;
+            for (int64_t k = 0; k < n; ++k) {
+              const float g = Gi[j * n + k];
+              rw += g * stage_noise(A, b * n + k);
+              if (ar) ra += g * ar[k];
+            }
+            accw += yj * rw; acca += yj * ra;
+          }
+          f = accf; fs = 0.f; div = 2.0f * f; gw = accw; ga = acca;
+        }
+        float mu;
+        if (A.proc == MSGM_PROC_REVERSE) {
+          mu = (1.0f - 0.5f * l) * ga - f + (1.0f - l) * div;          // SDEs.py:560-561
+          if (A.strato) mu = mu - 0.5f * (1.0f - l) * div;             // SDEs.py:583-584
+        } else {
+          mu = fs;                                                      // SDEs.py:42-43
+          if (!A.strato) mu = mu + 0.5f * div;                          // SDEs.py:38-39
+        }
+        float inc = mu * A.delta + sig_scale * gw;                      // sde_scheme.py:40
+        float o = (A.base ? A.base[e] : 0.f) + A.c_out * inc;
+        A.out[e] = o;
+        ss += o * o;
+      }
+    }
+    if (A.norm0) {
+#pragma unroll
+      for (int o = GS >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, GS);
+      if (live) {
+        const float scale = A.norm0[b] / sqrtf(ss);
+        for (int64_t i = lane; i < n; i += GS) A.out[b * n + i] *= scale;   // own writes, same lane
+      }
+    }
+  }
+}
+
+// x + (k1 + 2k2 + 2k3 + k4)/6 with optional norm correction   sde_scheme.py:250-253
+template <int GS>
+__global__ void k_rk4_combine(float* __restrict__ out, const float* __restrict__ x, const float* __restrict__ k1,
+                              const float* __restrict__ k2, const float* __restrict__ k3, const float* __restrict__ k4,
+                              int64_t B, int64_t n, const float* __restrict__ norm0) {
+  const int lane = threadIdx.x & (GS - 1);
+  const int64_t gpb = blockDim.x / GS;
+  const int64_t gid = blockIdx.x * gpb + threadIdx.x / GS;
+  const int64_t gstride = (int64_t)gridDim.x * gpb;
+  const int64_t rows_pad = ((B + gstride - 1) / gstride) * gstride;
+  for (int64_t b = gid; b < rows_pad; b += gstride) {
+    const bool live = b < B;
+    float ss = 0.f;
+    if (live)
+      for (int64_t i = lane; i < n; i += GS) {
+        const int64_t e = b * n + i;
+        float o = x[e] + (k1[e] + 2.0f * k2[e] + 2.0f * k3[e] + k4[e]) / 6.0f;
+        out[e] = o; ss += o * o;
+      }
+    if (norm0) {
+#pragma unroll
+      for (int o = GS >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, GS);
+      if (live) {
+        const float sc = norm0[b] / sqrtf(ss);
+        for (int64_t i = lane; i < n; i += GS) out[b * n + i] *= sc;
+      }
+    }
+  }
+}
+
+template <int GS>
+__global__ void k_row_norm(const float* __restrict__ x, float* __restrict__ out, int64_t B, int64_t n) {
+  const int lane = threadIdx.x & (GS - 1);
+  const int64_t gpb = blockDim.x / GS;
+  const int64_t gid = blockIdx.x * gpb + threadIdx.x / GS;
+  const int64_t gstride = (int64_t)gridDim.x * gpb;
+  const int64_t rows_pad = ((B + gstride - 1) / gstride) * gstride;
+  for (int64_t b = gid; b < rows_pad; b += gstride) {
+    float ss = 0.f;
+    if (b < B) for (int64_t i = lane; i < n; i += GS) { float v = x[b * n + i]; ss += v * v; }
+#pragma unroll
+    for (int o = GS >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, GS);
+    if (b < B && lane == 0) out[b] = sqrtf(ss);
+  }
+}
+
+__global__ void k_keep_rows(float* __restrict__ kept, const float* __restrict__ x, const int32_t* __restrict__ stop,
+                            int32_t index, int64_t B, int64_t n) {
+  const int64_t tot = B * n;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < tot; e += (int64_t)gridDim.x * blockDim.x) {
+    if (stop[e / n] == index) kept[e] = x[e];
+  }
+}
+
+// ============================================================ K13 Adam
+// torch.optim.Adam (defaults, no weight decay / amsgrad): MSGM_higherDim.py:792.
+// Mirrors torch's single-tensor update: m.lerp_(g, 1-b1); v = v*b2 + (1-b2) g g;
+// denom = sqrt(v)/sqrt(bc2) + eps; p += -(lr/bc1) * (m/denom), with the bias
+// corrections formed in double precision as the Python scalars upstream are.
+__global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                       int64_t n, double lr, double b1, double b2, double eps, float gscale, int64_t step,
+                       const int64_t* __restrict__ step_dev) {
+  const int64_t st = step_dev ? step_dev[0] : step;
+  const double bc1 = 1.0 - pow(b1, (double)st);
+  const double bc2 = 1.0 - pow(b2, (double)st);
+  const float step_size = (float)(lr / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  const float w1 = (float)(1.0 - b1), b2f = (float)b2, w2 = (float)(1.0 - b2), epsf = (float)eps;
+  const int64_t nq = (n + 3) >> 2;
+  const bool vec = (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) |
+                                     reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e0 = q << 2;
+    if (vec) {
+      f32x4 pv = *reinterpret_cast<f32x4*>(p + e0), gv = *reinterpret_cast<const f32x4*>(g + e0);
+      f32x4 mv = *reinterpret_cast<f32x4*>(m + e0), vv = *reinterpret_cast<f32x4*>(v + e0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float gg = gv[k] * gscale;
+        mv[k] = mv[k] + w1 * (gg - mv[k]);
+        vv[k] = vv[k] * b2f + w2 * (gg * gg);
+        float denom = sqrtf(vv[k]) / bc2_sqrt + epsf;
+        pv[k] = pv[k] - step_size * (mv[k] / denom);
+      }
+      *reinterpret_cast<f32x4*>(p + e0) = pv; *reinterpret_cast<f32x4*>(m + e0) = mv; *reinterpret_cast<f32x4*>(v + e0) = vv;
+    } else {
+      for (int k = 0; k < 4; ++k) {
+        int64_t e = e0 + k;
+        if (e >= n) break;
+        float gg = g[e] * gscale;
+        float mm = m[e] + w1 * (gg - m[e]);
+        float vv = v[e] * b2f + w2 * (gg * gg);
+        float denom = sqrtf(vv) / bc2_sqrt + epsf;
+        p[e] = p[e] - step_size * (mm / denom); m[e] = mm; v[e] = vv;
+      }
+    }
+  }
+}
+
+// ============================================================ C ABI
+static inline hipStream_t S(msgm_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+template <typename F>
+static int launch_rows(int64_t B, int64_t n, F&& f) {
+  // lanes per row: next power of two >= min(n,64), at least 2
+  int gs = 2;
+  while (gs < 64 && gs < n) gs <<= 1;
+  const int block = 256;
+  int64_t groups = (int64_t)block / gs;
+  int grid = (int)((B + groups - 1) / groups);
+  if (grid > 4096) grid = 4096;
+  if (grid < 1) grid = 1;
+  f(gs, grid, block);
+  return msgm_check_launch();
+}
+
+extern "C" {
+
+int msgm_version(void) { return 100; }
+
+const char* msgm_error_string(int code) {
+  switch (code) {
+    case MSGM_OK: return "ok";
+    case MSGM_E_BADARG: return "bad argument (null pointer, non-positive size or forbidden aliasing)";
+    case MSGM_E_UNSUPPORTED: return "unsupported shape/configuration for this kernel";
+    case MSGM_E_WORKSPACE: return "workspace too small";
+    case MSGM_E_LAUNCH: return "HIP launch error";
+    default: return "unknown error";
+  }
+}
+
+int msgm_rng_advance(uint64_t* rng, uint64_t n, msgm_stream_t stream) {
+  if (!rng) return MSGM_E_BADARG;
+  hipLaunchKernelGGL(k_rng_advance, dim3(1), dim3(1), 0, S(stream), rng, n);
+  return msgm_check_launch();
+}
+
+int msgm_counter_inc(int64_t* ctr, msgm_stream_t stream) {
+  if (!ctr) return MSGM_E_BADARG;
+  hipLaunchKernelGGL(k_counter_inc, dim3(1), dim3(1), 0, S(stream), ctr);
+  return msgm_check_launch();
+}
+
+int msgm_fill_uniform(float* out, int64_t n, const uint64_t* rng, uint32_t stream_id, msgm_stream_t stream) {
+  if (!out || !rng || n <= 0) return MSGM_E_BADARG;
+  hipLaunchKernelGGL(k_fill<false>, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, S(stream), out, n, rng, stream_id);
+  return msgm_check_launch();
+}
+
+int msgm_fill_normal(float* out, int64_t n, const uint64_t* rng, uint32_t stream_id, msgm_stream_t stream) {
+  if (!out || !rng || n <= 0) return MSGM_E_BADARG;
+  hipLaunchKernelGGL(k_fill<true>, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, S(stream), out, n, rng, stream_id);
+  return msgm_check_launch();
+}
+
+int msgm_perturb_vp(const float* x0, float* y, float* t_out, float* eps_out, int64_t B, int64_t d,
+                    const msgm_sde_t* sde, const float* u, const float* eps, const uint64_t* rng,
+                    msgm_stream_t stream) {
+  if (!x0 || !y || !t_out || !sde || B <= 0 || d <= 0) return MSGM_E_BADARG;
+  if ((!u || !eps) && !rng) return MSGM_E_BADARG;
+  if (sde->kind != MSGM_SDE_SGM) return MSGM_E_UNSUPPORTED;   // MSGM has no closed form (SDEs.py:434-436)
+  hipLaunchKernelGGL(k_perturb_vp, dim3(grid_for((B * d + 3) / 4, 256)), dim3(256), 0, S(stream), x0, y, t_out, eps_out,
+                     B, d, sde->beta_min, sde->beta_max, sde->T, sde->t_epsilon, u, eps, rng);
+  return msgm_check_launch();
+}
+
+int msgm_forward_step_index(const float* t, int32_t* k, int64_t B, int32_t nsf, float T, msgm_stream_t stream) {
+  if (!t || !k || B <= 0 || nsf <= 0) return MSGM_E_BADARG;
+  hipLaunchKernelGGL(k_forward_step_index, dim3(grid_for(B, 256)), dim3(256), 0, S(stream), t, k, B, nsf, T);
+  return msgm_check_launch();
+}
+
+int msgm_rademacher(float* v, int64_t n, const float* u, const uint64_t* rng, msgm_stream_t stream) {
+  if (!v || n <= 0 || (!u && !rng)) return MSGM_E_BADARG;
+  hipLaunchKernelGGL(k_rademacher, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, S(stream), v, n, u, rng);
+  return msgm_check_launch();
+}
+
+int msgm_sde_stage(float* out, const float* base, float c_out, const float* x, const float* a, const float* dW,
+                   const float* z, float sqrt_delta, const uint64_t* rng, uint64_t rng_step, float* dW_out,
+                   int64_t B, int64_t n, const msgm_sde_t* sde, int32_t proc, int32_t strato, float t, float delta,
+                   float lmbd, const float* norm0, msgm_stream_t stream) {
+  if (!out || !x || !sde || B <= 0 || n <= 0) return MSGM_E_BADARG;
+  if (!dW && !z && !rng) return MSGM_E_BADARG;
+  if (proc == MSGM_PROC_REVERSE && !a) return MSGM_E_BADARG;
+  if (proc != MSGM_PROC_REVERSE && proc != MSGM_PROC_FORWARD) return MSGM_E_BADARG;
+  if (sde->kind != MSGM_SDE_SGM && (out == x)) return MSGM_E_BADARG;      // stencil / contraction reads neighbours
+  if (sde->kind == MSGM_SDE_MSGM_DENSE && (!sde->G || !sde->L_G)) return MSGM_E_BADARG;
+  if (sde->kind == MSGM_SDE_MSGM_DENSE && n > 64) return MSGM_E_UNSUPPORTED;
+  if (sde->kind < 0 || sde->kind > 2) return MSGM_E_BADARG;
+  StageArgs A{out, base, c_out, x, a, dW, z, sqrt_delta, rng, rng_step, dW_out, B, n, sde->kind, proc, strato,
+              sde->beta_min, sde->beta_max, sde->T, t, delta, lmbd, sde->G, sde->L_G, norm0};
+  if (sde->kind == MSGM_SDE_SGM && !norm0) {
+    hipLaunchKernelGGL(k_stage_diag_flat, dim3(grid_for((B * n + 3) / 4, 256)), dim3(256), 0, S(stream), A);
+    return msgm_check_launch();
+  }
+  return launch_rows(B, n, [&](int gs, int grid, int block) {
+    switch (gs) {
+      case 2: hipLaunchKernelGGL(k_stage_rows<2>, dim3(grid), dim3(block), 0, S(stream), A); break;
+      case 4: hipLaunchKernelGGL(k_stage_rows<4>, dim3(grid), dim3(block), 0, S(stream), A); break;
+      case 8: hipLaunchKernelGGL(k_stage_rows<8>, dim3(grid), dim3(block), 0, S(stream), A); break;
+      case 16: hipLaunchKernelGGL(k_stage_rows<16>, dim3(grid), dim3(block), 0, S(stream), A); break;
+      case 32: hipLaunchKernelGGL(k_stage_rows<32>, dim3(grid), dim3(block), 0, S(stream), A); break;
+      default: hipLaunchKernelGGL(k_stage_rows<64>, dim3(grid), dim3(block), 0, S(stream), A); break;
+    }
+  });
+}
+
+int msgm_rk4_combine(float* out, const float* x, const float* k1, const float* k2, const float* k3, const float* k4,
+                     int64_t B, int64_t n, const float* norm0, msgm_stream_t stream) {
+  if (!out || !x || !k1 || !k2 || !k3 || !k4 || B <= 0 || n <= 0) return MSGM_E_BADARG;
+  return launch_rows(B, n, [&](int gs, int grid, int block) {
+    switch (gs) {
+      case 2: hipLaunchKernelGGL(k_rk4_combine<2>, dim3(grid), dim3(block), 0, S(stream), out, x, k1, k2, k3, k4, B, n, norm0); break;
+      case 4: hipLaunchKernelGGL(k_rk4_combine<4>, dim3(grid), dim3(block), 0, S(stream), out, x, k1, k2, k3, k4, B, n, norm0); break;
+      case 8: hipLaunchKernelGGL(k_rk4_combine<8>, dim3(grid), dim3(block), 0, S(stream), out, x, k1, k2, k3, k4, B, n, norm0); break;
+      case 16: hipLaunchKernelGGL(k_rk4_combine<16>, dim3(grid), dim3(block), 0, S(stream), out, x, k1, k2, k3, k4, B, n, norm0); break;
+      case 32: hipLaunchKernelGGL(k_rk4_combine<32>, dim3(grid), dim3(block), 0, S(stream), out, x, k1, k2, k3, k4, B, n, norm0); break;
+      default: hipLaunchKernelGGL(k_rk4_combine<64>, dim3(grid), dim3(block), 0, S(stream), out, x, k1, k2, k3, k4, B, n, norm0); break;
+    }
+  });
+}
+
+int msgm_row_norm(const float* x, float* out, int64_t B, int64_t n, msgm_stream_t stream) {
+  if (!x || !out || B <= 0 || n <= 0) return MSGM_E_BADARG;
+  return launch_rows(B, n, [&](int gs, int grid, int block) {
+    switch (gs) {
+      case 2: hipLaunchKernelGGL(k_row_norm<2>, dim3(grid), dim3(block), 0, S(stream), x, out, B, n); break;
+      case 4: hipLaunchKernelGGL(k_row_norm<4>, dim3(grid), dim3(block), 0, S(stream), x, out, B, n); break;
+      case 8: hipLaunchKernelGGL(k_row_norm<8>, dim3(grid), dim3(block), 0, S(stream), x, out, B, n); break;
+      case 16: hipLaunchKernelGGL(k_row_norm<16>, dim3(grid), dim3(block), 0, S(stream), x, out, B, n); break;
+      case 32: hipLaunchKernelGGL(k_row_norm<32>, dim3(grid), dim3(block), 0, S(stream), x, out, B, n); break;
+      default: hipLaunchKernelGGL(k_row_norm<64>, dim3(grid), dim3(block), 0, S(stream), x, out, B, n); break;
+    }
+  });
+}
+
+int msgm_keep_rows(float* kept, const float* x, const int32_t* stop, int32_t index, int64_t B, int64_t n,
+                   msgm_stream_t stream) {
+  if (!kept || !x || !stop || B <= 0 || n <= 0) return MSGM_E_BADARG;
+  hipLaunchKernelGGL(k_keep_rows, dim3(grid_for(B * n, 256)), dim3(256), 0, S(stream), kept, x, stop, index, B, n);
+  return msgm_check_launch();
+}
+
+int msgm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                   double eps, float gscale, int64_t step, const int64_t* step_dev, msgm_stream_t stream) {
+  if (!p || !g || !m || !v || n <= 0) return MSGM_E_BADARG;
+  if (!step_dev && step < 1) return MSGM_E_BADARG;
+  hipLaunchKernelGGL(k_adam, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, S(stream), p, g, m, v, n, lr, beta1, beta2,
+                     eps, gscale, step, step_dev);
+  return msgm_check_launch();
+}
+
+}  // extern "C"

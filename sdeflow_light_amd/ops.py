@@ -1,0 +1,186 @@
+"""Thin tensor-level wrappers over the C ABI (one function per entry point).
+
+Every function validates shapes on the host (a faulting kernel can reset the
+GPU for everyone), passes raw device pointers through ctypes, and raises
+``MsgmError`` on a non-zero status.  No arithmetic happens here.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+from ._lib import MsgmError, PhiloxState, check, f32, lib, ptr, stream
+
+
+def _rng_ptr(rng: Optional[PhiloxState]):
+    return None if rng is None else rng.ptr()
+
+
+def _same_shape(a: Optional[torch.Tensor], shape, name: str):
+    if a is not None and tuple(a.shape) != tuple(shape):
+        raise MsgmError(f"{name} has shape {tuple(a.shape)}, expected {tuple(shape)}")
+
+
+def fill_uniform(out: torch.Tensor, rng: PhiloxState, stream_id: int = L.RNG_STREAM_USER) -> torch.Tensor:
+    check(lib().msgm_fill_uniform(ptr(f32(out)), out.numel(), rng.ptr(), stream_id, stream()), "msgm_fill_uniform")
+    return out
+
+
+def fill_normal(out: torch.Tensor, rng: PhiloxState, stream_id: int = L.RNG_STREAM_USER) -> torch.Tensor:
+    check(lib().msgm_fill_normal(ptr(f32(out)), out.numel(), rng.ptr(), stream_id, stream()), "msgm_fill_normal")
+    return out
+
+
+def perturb_vp(x0: torch.Tensor, sde: L.SdeT, u: Optional[torch.Tensor] = None, eps: Optional[torch.Tensor] = None,
+               rng: Optional[PhiloxState] = None, return_eps: bool = False):
+    """(y, t[, eps]) — K1.  x0 (B,d); u (B,) raw uniforms; eps (B,d)."""
+    if x0.dim() != 2:
+        raise MsgmError("x0 must be (B,d)")
+    B, d = x0.shape
+    if u is not None:
+        u = u.reshape(-1)
+        _same_shape(u, (B,), "u")
+    _same_shape(eps, (B, d), "eps")
+    y = torch.empty_like(x0)
+    t = torch.empty(B, dtype=torch.float32, device=x0.device)
+    eo = torch.empty_like(x0) if return_eps else None
+    check(lib().msgm_perturb_vp(ptr(f32(x0)), ptr(y), ptr(t), ptr(eo), B, d, sde, ptr(u), ptr(eps), _rng_ptr(rng),
+                                stream()), "msgm_perturb_vp")
+    return (y, t, eo) if return_eps else (y, t)
+
+
+def forward_step_index(t: torch.Tensor, nsf: int, T: float) -> torch.Tensor:
+    t = t.reshape(-1)
+    k = torch.empty(t.numel(), dtype=torch.int32, device=t.device)
+    check(lib().msgm_forward_step_index(ptr(f32(t)), ptr(k), t.numel(), int(nsf), float(T), stream()),
+          "msgm_forward_step_index")
+    return k
+
+
+def rademacher(shape, device, u: Optional[torch.Tensor] = None, rng: Optional[PhiloxState] = None) -> torch.Tensor:
+    v = torch.empty(shape, dtype=torch.float32, device=device)
+    _same_shape(u, v.shape, "u")
+    check(lib().msgm_rademacher(ptr(v), v.numel(), ptr(u), _rng_ptr(rng), stream()), "msgm_rademacher")
+    return v
+
+
+def sde_stage(out: torch.Tensor, base: Optional[torch.Tensor], c_out: float, x: torch.Tensor,
+              a: Optional[torch.Tensor], sde: L.SdeT, proc: int, strato: bool, t: float, delta: float, lmbd: float = 0.0,
+              dW: Optional[torch.Tensor] = None, z: Optional[torch.Tensor] = None, rng: Optional[PhiloxState] = None,
+              rng_step: int = 0, dW_out: Optional[torch.Tensor] = None, norm0: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One integrator stage (K2/K3/K4): out = base + c_out*(drift*delta + sigma.dW)."""
+    if x.dim() != 2:
+        raise MsgmError("state must be 2-D (B,n)")
+    B, n = x.shape
+    for nm, tt in (("out", out), ("base", base), ("a", a), ("dW", dW), ("z", z), ("dW_out", dW_out)):
+        _same_shape(tt, (B, n), nm)
+    _same_shape(norm0, (B,), "norm0")
+    check(lib().msgm_sde_stage(ptr(f32(out)), ptr(base), float(c_out), ptr(f32(x)), ptr(a), ptr(dW), ptr(z),
+                               float(delta ** 0.5), _rng_ptr(rng), int(rng_step), ptr(dW_out), B, n, sde, int(proc),
+                               int(bool(strato)), float(t), float(delta), float(lmbd), ptr(norm0), stream()),
+          "msgm_sde_stage")
+    return out
+
+
+def rk4_combine(out, x, k1, k2, k3, k4, norm0: Optional[torch.Tensor] = None):
+    B, n = x.shape
+    for nm, tt in (("out", out), ("k1", k1), ("k2", k2), ("k3", k3), ("k4", k4)):
+        _same_shape(tt, (B, n), nm)
+    _same_shape(norm0, (B,), "norm0")
+    check(lib().msgm_rk4_combine(ptr(out), ptr(x), ptr(k1), ptr(k2), ptr(k3), ptr(k4), B, n, ptr(norm0), stream()),
+          "msgm_rk4_combine")
+    return out
+
+
+def row_norm(x: torch.Tensor) -> torch.Tensor:
+    B, n = x.shape
+    out = torch.empty(B, dtype=torch.float32, device=x.device)
+    check(lib().msgm_row_norm(ptr(f32(x)), ptr(out), B, n, stream()), "msgm_row_norm")
+    return out
+
+
+def keep_rows(kept: torch.Tensor, x: torch.Tensor, stop: torch.Tensor, index: int):
+    B, n = x.shape
+    _same_shape(kept, (B, n), "kept")
+    if stop.dtype != torch.int32 or stop.numel() != B:
+        raise MsgmError("stop must be int32 of length B")
+    check(lib().msgm_keep_rows(ptr(kept), ptr(x), ptr(stop), int(index), B, n, stream()), "msgm_keep_rows")
+    return kept
+
+
+def adam_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int, lr: float = 1e-3,
+              beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, gscale: float = 1.0,
+              step_dev: Optional[torch.Tensor] = None):
+    n = p.numel()
+    for nm, tt in (("g", g), ("m", m), ("v", v)):
+        if tt.numel() != n:
+            raise MsgmError(f"{nm} has {tt.numel()} elements, expected {n}")
+    check(lib().msgm_adam_step(ptr(f32(p)), ptr(f32(g)), ptr(f32(m)), ptr(f32(v)), n, lr, beta1, beta2, eps,
+                               float(gscale), int(step), ptr(step_dev), stream()), "msgm_adam_step")
+
+
+def counter_inc(ctr: torch.Tensor):
+    check(lib().msgm_counter_inc(ptr(ctr), stream()), "msgm_counter_inc")
+
+
+# ---------------------------------------------------------------- fused MLP
+def mlp_params(W1, b1, W2, b2, W3, b3, W4, b4, premodule: bool) -> L.MlpParamsT:
+    d = W4.shape[0]
+    in_dim = d + 1 + (1 if premodule else 0)
+    exp = {"W1": (128, in_dim), "b1": (128,), "W2": (128, 128), "b2": (128,), "W3": (128, 128), "b3": (128,),
+           "W4": (d, 128), "b4": (d,)}
+    for nm, tt in (("W1", W1), ("b1", b1), ("W2", W2), ("b2", b2), ("W3", W3), ("b3", b3), ("W4", W4), ("b4", b4)):
+        _same_shape(tt, exp[nm], nm)
+        f32(tt, nm)
+    return L.MlpParamsT(ptr(W1), ptr(b1), ptr(W2), ptr(b2), ptr(W3), ptr(b3), ptr(W4), ptr(b4), d, int(bool(premodule)))
+
+
+def mlp_num_params(d: int, premodule: bool) -> int:
+    return int(lib().msgm_mlp_num_params(d, int(bool(premodule))))
+
+
+def mlp_forward(P: L.MlpParamsT, y: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+    B, d = y.shape
+    if d != P.d:
+        raise MsgmError(f"input has d={d}, the MLP was built for d={P.d}")
+    t = t.reshape(-1)
+    _same_shape(t, (B,), "t")
+    a = torch.empty_like(y)
+    check(lib().msgm_mlp_forward(P, ptr(f32(y)), ptr(f32(t)), ptr(a), B, stream()), "msgm_mlp_forward")
+    return a
+
+
+def mlp_em_step(P: L.MlpParamsT, x: torch.Tensor, sde: L.SdeT, t: float, delta: float, lmbd: float = 0.0,
+                z: Optional[torch.Tensor] = None, rng: Optional[PhiloxState] = None, rng_step: int = 0):
+    B, d = x.shape
+    if d != P.d:
+        raise MsgmError(f"state has d={d}, the MLP was built for d={P.d}")
+    _same_shape(z, (B, d), "z")
+    check(lib().msgm_mlp_em_step(P, ptr(f32(x)), B, sde, float(t), float(delta), float(lmbd), ptr(z), _rng_ptr(rng),
+                                 int(rng_step), stream()), "msgm_mlp_em_step")
+    return x
+
+
+def mlp_ssm_workspace(d: int, premodule: bool, device) -> torch.Tensor:
+    nbytes = int(lib().msgm_mlp_ssm_workspace(d, int(bool(premodule))))
+    return torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+
+
+def mlp_ssm_grad(P: L.MlpParamsT, y: torch.Tensor, t: torch.Tensor, v: torch.Tensor, sde: L.SdeT, inv_batch: float,
+                 grads: torch.Tensor, workspace: torch.Tensor, loss_per: Optional[torch.Tensor] = None,
+                 loss_sum: Optional[torch.Tensor] = None):
+    B, d = y.shape
+    if d != P.d:
+        raise MsgmError(f"input has d={d}, the MLP was built for d={P.d}")
+    t = t.reshape(-1)
+    _same_shape(t, (B,), "t")
+    _same_shape(v, (B, d), "v")
+    _same_shape(loss_per, (B,), "loss_per")
+    if grads.numel() != mlp_num_params(d, bool(P.premodule)):
+        raise MsgmError("grads bucket has the wrong size")
+    check(lib().msgm_mlp_ssm_grad(P, ptr(f32(y)), ptr(f32(t)), ptr(f32(v)), B, sde, float(inv_batch), ptr(f32(grads)),
+                                  ptr(loss_per), ptr(loss_sum), ptr(workspace), workspace.numel() * 4, stream()),
+          "msgm_mlp_ssm_grad")
