@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the MI355X hot path (driver contract: see task brief).
+
+Workload at N=1 (BASELINE.json configs[1], "C2"): 2-D Gaussian mixture, MLP
+score net (33 794 params), SGM, batch 65 536 per GPU, fp32.
+  step   = one score-matching training step: perturb (K1) + Rademacher probe +
+           fused forward/tangent/loss/backward (K5) [+ RCCL all-reduce of the
+           flat gradient bucket when N>1] + fused Adam (K13), inputs resident
+           in HBM, hipGraph-replayed on one GPU.
+  value  = global training samples per second / 65 536, i.e. C2-sized train
+           steps per second summed over all ranks (weak scaling: the per-GPU
+           batch is fixed).
+Also reported on the same line: reverse-SDE Euler–Maruyama sampler steps/s on
+the same config (whole loop = one hipGraph), the roofline of the dominant
+kernel (k_mlp<train>), and the CPU oracle timed on this host (rank 0, N=1).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_C2 = 65536
+MLP_FWD_FLOP = 66816                 # SURVEY.md App. A.3 (2*MACs, d=2)
+TRAIN_FLOP_PER_SAMPLE = 6 * MLP_FWD_FLOP
+PEAK_F32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_* = fp32 vector rate
+
+
+def build_model(dev, B):
+    from sdeflow_light_amd.NN import MLP
+    from sdeflow_light_amd.SDEs import SGMsde, PluginReverseSDE
+    torch.manual_seed(0)                                   # model init seed as upstream (MSGM_higherDim.py:41)
+    net = MLP(input_dim=2, index_dim=1, hidden_dim=128).to(dev)
+    T = torch.nn.Parameter(torch.FloatTensor([1.0]), requires_grad=False)
+    sde = SGMsde(beta_min=0.1, beta_max=20.0, t_epsilon=1e-3, T=T, num_steps_forward=16, device=dev)
+    return PluginReverseSDE(sde, net, T, vtype="rademacher", deviceReverseSDE=dev).to(dev)
+
+
+def time_kernel_events(fn, iters, dev):
+    """Average device time per call of fn (HIP events on the launch stream)."""
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def cpu_baseline(budget_s=12.0):
+    """The CPU oracle (restatement of the reference, pinned by golden vectors)
+    on the same workload, bounded to ~10-20 s of CPU work."""
+    from oracle import sde_ref as S, nets_ref as N, ssm_ref as LR
+    from sdeflow_light_amd.data import gaussian_mixture_2d
+    torch.manual_seed(0)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except Exception:
+        avail = os.cpu_count() or 1
+    cores = min(avail, 16)            # a 1-GPU box is given a 16-CPU share; more threads only oversubscribe
+    torch.set_num_threads(cores)
+    sp = S.SdeSpec()
+    p = {"main.0.weight": torch.randn(128, 3) * 0.5, "main.0.bias": torch.zeros(128),
+         "main.2.weight": torch.randn(128, 128) * 0.09, "main.2.bias": torch.zeros(128),
+         "main.4.weight": torch.randn(128, 128) * 0.09, "main.4.bias": torch.zeros(128),
+         "main.6.weight": torch.randn(2, 128) * 0.09, "main.6.bias": torch.zeros(2)}
+    m = {k: torch.zeros_like(v) for k, v in p.items()}
+    vv = {k: torch.zeros_like(v) for k, v in p.items()}
+    x = gaussian_mixture_2d(B_C2)
+    score = lambda prm, yy, tt: N.mlp_forward(prm, yy, tt, None)
+
+    def one(step):
+        t = S.clamp_time(sp, torch.rand(B_C2, 1))
+        y = S.vp_perturb(sp, t, x, torch.randn(B_C2, 2))
+        v = S.rademacher_from_uniform(torch.rand(B_C2, 2))
+        loss, per, g = LR.ssm_mean_and_grads(sp, score, p, t, y, v, form="double_backward")   # as upstream
+        for k in p:
+            p[k], m[k], vv[k] = LR.adam_step(p[k], g[k], m[k], vv[k], step)
+
+    one(1)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        n += 1
+        one(n + 1)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "train_steps/s (B=65536)", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} full C2 train steps (B=65536, MLP d=2, double-backward SSM + Adam) on the CPU oracle in {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--sample-steps", type=int, default=200)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    from sdeflow_light_amd import parallel, ops
+    from sdeflow_light_amd.train import MLPScoreTrainer
+    from sdeflow_light_amd.sde_scheme import GraphedEMSampler
+    from sdeflow_light_amd.data import gaussian_mixture_2d
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    rank, local, world = parallel.init_distributed()
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    ops.lib()
+
+    gen = build_model(dev, B_C2)
+    flat, _ = gen.a.flat_parameters()
+    parallel.broadcast_(flat, 0)                            # identical params on all ranks
+    tr = MLPScoreTrainer(gen, B_C2, lr=1e-3, world=world, use_graph=(world == 1), seed=1 + rank)
+    tr.set_data(gaussian_mixture_2d(B_C2, seed=1234 + rank, device=dev))
+
+    # ---- timed training loop ------------------------------------------------
+    for _ in range(a.warmup):
+        tr.step()
+    parallel.barrier(); torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        tr.step()
+    torch.cuda.synchronize(dev); parallel.barrier()
+    dt = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    loss_end = float(tr.loss.item())
+    ms_per_step = dt / a.steps * 1e3
+    value = world * a.steps / dt                            # C2-sized steps/s, all ranks
+
+    # ---- sampler (same config): whole EM loop as one hipGraph --------------
+    smp = GraphedEMSampler(gen, B_C2, a.sample_steps)
+    x0 = gen.latent_sample(B_C2, 2)
+    smp.run(x0)
+    parallel.barrier(); torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        xs = smp.run(x0)
+    torch.cuda.synchronize(dev); parallel.barrier()
+    dts = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    sample_steps_per_s = world * reps * a.sample_steps / dts
+    finite = bool(torch.isfinite(xs).all())
+
+    # ---- roofline of the dominant kernel (rank 0) ---------------------------
+    roof = None
+    if rank == 0:
+        import ctypes as C
+        lib = ops.lib()
+        nsl = C.c_int32(0)
+        fn = lambda: ops.check(lib.msgm_mlp_ssm_partial(tr.P, tr.y.data_ptr(), tr.t.data_ptr(), tr.vp.data_ptr(), B_C2,
+                                                        tr.st, tr.inv_batch, None, tr.ws.data_ptr(), tr.ws.numel() * 4,
+                                                        C.byref(nsl), ops.stream()), "partial")
+        tk = time_kernel_events(fn, 50, dev)
+        flop = TRAIN_FLOP_PER_SAMPLE * B_C2
+        ach = flop / tk / 1e12
+        traffic = None
+        pj = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pj):
+            try:
+                traffic = json.load(open(pj)).get("k_mlp_train_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roof = {"kernel": "k_mlp<MODE_TRAIN> (msgm_mlp_ssm_partial)", "bound": "mfma", "achieved": ach,
+                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                "traffic": traffic, "kernel_ms": tk * 1e3, "flop_per_launch": flop}
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        out = {"metric": "score-matching train steps/sec (+ reverse-SDE sample steps/sec)", "value": value,
+               "unit": "train_steps/s (B=65536 per step)", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "C2: 2-D Gaussian mixture, MLP score net (d=2, hidden 128), SGM, batch 65536/GPU, "
+                                      "SSM loss + Adam", "global_batch": B_C2 * world, "parallelism": f"dp{world}",
+                          "graph": world == 1},
+               "sample_steps_per_s": sample_steps_per_s, "sample_config": f"EM, {a.sample_steps} steps, 65536 rows/GPU, hipGraph",
+               "final_loss": loss_end, "sampler_finite": finite, "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -108,15 +108,26 @@ int msgm_rademacher(float* v, int64_t n, const float* u, const uint64_t* rng, ms
  *           alias base or x).
  *   norm0   optional (B): after the update rescale each row of `out` to this
  *           norm (norm_correction, sde_scheme.py:85-86).
+ *   dW_out / inc_out  optional (B,n): the Wiener increment actually used (RK4
+ *           shares one dW across its stages, sde_scheme.py:227) / the bare inc.
+ *   delta_rows  optional (B): per-row step length; then t_b = t + t_frac*delta_b
+ *           and dW_b = sqrt(delta_b) z_b (the one-step RK4 of SDEs.py:112-117
+ *           for rows whose stop index is 0).
  * t is a scalar shared by the batch (the integrators fill a (B,1) tensor with
  * one value, sde_scheme.py:81). */
 int msgm_sde_stage(float* out, const float* base, float c_out,
                    const float* x, const float* a, const float* dW, const float* z,
                    float sqrt_delta, const uint64_t* rng, uint64_t rng_step,
-                   float* dW_out,
+                   float* dW_out, float* inc_out,
                    int64_t B, int64_t n, const msgm_sde_t* sde, int32_t proc, int32_t strato,
                    float t, float delta, float lmbd, const float* norm0,
+                   const float* delta_rows, float t_frac,
                    msgm_stream_t stream);
+
+/* out = c0*a + c1*b + c2*c (b, c may be NULL): stage points of Heun / RK4
+ * (x + K/2, sde_scheme.py:148,234,240,246). */
+int msgm_lincomb(float* out, const float* a, float c0, const float* b, float c1,
+                 const float* c, float c2, int64_t n, msgm_stream_t stream);
 
 /* out = x + (k1 + 2 k2 + 2 k3 + k4)/6 with optional norm correction
  * (sde_scheme.py:250-253). */
@@ -186,6 +197,17 @@ int msgm_mlp_ssm_grad(const msgm_mlp_params_t* P, const float* y, const float* t
                       int64_t B, const msgm_sde_t* sde, float inv_batch,
                       float* grads, float* loss_per, float* loss_sum,
                       void* workspace, size_t workspace_bytes, msgm_stream_t stream);
+
+/* The two halves of msgm_mlp_ssm_grad, exposed so the dominant kernel can be
+ * timed / profiled on its own: the persistent fused kernel (writes *n_slabs
+ * per-workgroup gradient slabs into the workspace; n_slabs is a HOST int) and
+ * the deterministic slab reduction. */
+int msgm_mlp_ssm_partial(const msgm_mlp_params_t* P, const float* y, const float* t, const float* v,
+                         int64_t B, const msgm_sde_t* sde, float inv_batch, float* loss_per,
+                         void* workspace, size_t workspace_bytes, int32_t* n_slabs_host,
+                         msgm_stream_t stream);
+int msgm_mlp_ssm_reduce(int32_t d, int32_t premodule, const void* workspace, int32_t n_slabs,
+                        float inv_batch, float* grads, float* loss_sum, msgm_stream_t stream);
 
 #ifdef __cplusplus
 }

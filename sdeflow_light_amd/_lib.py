@@ -49,8 +49,9 @@ SIGNATURES = {
     "msgm_perturb_vp": (C.c_int, [_P, _P, _P, _P, _I64, _I64, C.POINTER(SdeT), _P, _P, _P, _P]),
     "msgm_forward_step_index": (C.c_int, [_P, _P, _I64, _I32, _F, _P]),
     "msgm_rademacher": (C.c_int, [_P, _I64, _P, _P, _P]),
-    "msgm_sde_stage": (C.c_int, [_P, _P, _F, _P, _P, _P, _P, _F, _P, _U64, _P, _I64, _I64, C.POINTER(SdeT), _I32, _I32,
-                                 _F, _F, _F, _P, _P]),
+    "msgm_sde_stage": (C.c_int, [_P, _P, _F, _P, _P, _P, _P, _F, _P, _U64, _P, _P, _I64, _I64, C.POINTER(SdeT), _I32,
+                                 _I32, _F, _F, _F, _P, _P, _F, _P]),
+    "msgm_lincomb": (C.c_int, [_P, _P, _F, _P, _F, _P, _F, _I64, _P]),
     "msgm_rk4_combine": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
     "msgm_row_norm": (C.c_int, [_P, _P, _I64, _I64, _P]),
     "msgm_keep_rows": (C.c_int, [_P, _P, _P, _I32, _I64, _I64, _P]),
@@ -60,6 +61,9 @@ SIGNATURES = {
     "msgm_mlp_em_step": (C.c_int, [C.POINTER(MlpParamsT), _P, _I64, C.POINTER(SdeT), _F, _F, _F, _P, _P, _U64, _P]),
     "msgm_mlp_ssm_workspace": (_SZ, [_I32, _I32]),
     "msgm_mlp_num_params": (_I64, [_I32, _I32]),
+    "msgm_mlp_ssm_partial": (C.c_int, [C.POINTER(MlpParamsT), _P, _P, _P, _I64, C.POINTER(SdeT), _F, _P, _P, _SZ,
+                                       C.POINTER(C.c_int32), _P]),
+    "msgm_mlp_ssm_reduce": (C.c_int, [_I32, _I32, _P, _I32, _F, _P, _P, _P]),
     "msgm_mlp_ssm_grad": (C.c_int, [C.POINTER(MlpParamsT), _P, _P, _P, _I64, C.POINTER(SdeT), _F, _P, _P, _P, _P, _SZ, _P]),
 }
 

@@ -627,13 +627,13 @@ int msgm_mlp_em_step(const msgm_mlp_params_t* P, float* x, int64_t B, const msgm
   return launch_mlp<MODE_EM>(A, (int)(tiles < MLP_MAX_GRID ? tiles : MLP_MAX_GRID), S(stream));
 }
 
-int msgm_mlp_ssm_grad(const msgm_mlp_params_t* P, const float* y, const float* t, const float* v, int64_t B,
-                      const msgm_sde_t* sde, float inv_batch, float* grads, float* loss_per, float* loss_sum,
-                      void* workspace, size_t workspace_bytes, msgm_stream_t stream) {
+int msgm_mlp_ssm_partial(const msgm_mlp_params_t* P, const float* y, const float* t, const float* v, int64_t B,
+                         const msgm_sde_t* sde, float inv_batch, float* loss_per, void* workspace,
+                         size_t workspace_bytes, int32_t* n_slabs, msgm_stream_t stream) {
   MlpArgs A{};
   int rc = fill_common(A, P, B);
   if (rc) return rc;
-  if (!y || !t || !v || !sde || !grads || !workspace) return MSGM_E_BADARG;
+  if (!y || !t || !v || !sde || !workspace || !n_slabs) return MSGM_E_BADARG;
   if (sde->kind != MSGM_SDE_SGM) return MSGM_E_UNSUPPORTED;
   if (workspace_bytes < msgm_mlp_ssm_workspace(P->d, P->premodule)) return MSGM_E_WORKSPACE;
   A.y = y; A.t = t; A.v = v;
@@ -642,11 +642,27 @@ int msgm_mlp_ssm_grad(const msgm_mlp_params_t* P, const float* y, const float* t
   A.n_params = msgm_mlp_num_params(P->d, P->premodule);
   const int64_t tiles = (B + 15) / 16;
   const int grid = (int)(tiles < MLP_MAX_GRID ? tiles : MLP_MAX_GRID);
-  rc = launch_mlp<MODE_TRAIN>(A, grid, S(stream));
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_slab_reduce, dim3(grid_for(A.n_params + 1, 256, 256)), dim3(256), 0, S(stream), A.slabs, grid,
-                     A.n_params + 1, grads, A.n_params, loss_sum, inv_batch);
+  *n_slabs = grid;
+  return launch_mlp<MODE_TRAIN>(A, grid, S(stream));
+}
+
+int msgm_mlp_ssm_reduce(int32_t d, int32_t premodule, const void* workspace, int32_t n_slabs, float inv_batch,
+                        float* grads, float* loss_sum, msgm_stream_t stream) {
+  if (!workspace || !grads || n_slabs < 1 || n_slabs > MLP_MAX_GRID) return MSGM_E_BADARG;
+  const int64_t n_params = msgm_mlp_num_params(d, premodule);
+  hipLaunchKernelGGL(k_slab_reduce, dim3(grid_for(n_params + 1, 256, 256)), dim3(256), 0, S(stream),
+                     reinterpret_cast<const float*>(workspace), n_slabs, n_params + 1, grads, n_params, loss_sum, inv_batch);
   return msgm_check_launch();
+}
+
+int msgm_mlp_ssm_grad(const msgm_mlp_params_t* P, const float* y, const float* t, const float* v, int64_t B,
+                      const msgm_sde_t* sde, float inv_batch, float* grads, float* loss_per, float* loss_sum,
+                      void* workspace, size_t workspace_bytes, msgm_stream_t stream) {
+  if (!grads) return MSGM_E_BADARG;
+  int32_t n_slabs = 0;
+  int rc = msgm_mlp_ssm_partial(P, y, t, v, B, sde, inv_batch, loss_per, workspace, workspace_bytes, &n_slabs, stream);
+  if (rc) return rc;
+  return msgm_mlp_ssm_reduce(P->d, P->premodule, workspace, n_slabs, inv_batch, grads, loss_sum, stream);
 }
 
 }  // extern "C"

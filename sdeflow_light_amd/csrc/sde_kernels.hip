@@ -89,12 +89,15 @@ struct StageArgs {
   float b0, b1, T, t, delta, lmbd;
   const float* G; const float* L_G;
   const float* norm0;
+  float* inc_out;              // optional: the bare increment
+  const float* delta_rows;     // optional per-row step length (MSGM short-time rows, SDEs.py:112-117)
+  float t_frac;                // with delta_rows: t_b = t + t_frac * delta_b
 };
 
-__device__ __forceinline__ float stage_noise(const StageArgs& A, int64_t e) {
+__device__ __forceinline__ float stage_noise(const StageArgs& A, int64_t e, float sqrt_delta) {
   if (A.dW) return A.dW[e];
   float zz = A.z ? A.z[e] : philox_normal1(A.rng, A.rng_step, RNG_STREAM_DW, (uint64_t)e);
-  return A.sqrt_delta * zz;                                // delta**0.5 * randn   sde_scheme.py:84
+  return sqrt_delta * zz;                                  // delta**0.5 * randn   sde_scheme.py:84
 }
 
 // SGM (diagonal) flat kernel, no norm correction: 12-16 B/element.
@@ -111,7 +114,7 @@ __global__ void k_stage_diag_flat(StageArgs A) {
   const bool vec = (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(A.x) | reinterpret_cast<uintptr_t>(A.out) |
                                      reinterpret_cast<uintptr_t>(A.a) | reinterpret_cast<uintptr_t>(A.dW) |
                                      reinterpret_cast<uintptr_t>(A.z) | reinterpret_cast<uintptr_t>(A.base) |
-                                     reinterpret_cast<uintptr_t>(A.dW_out)) & 15) == 0;
+                                     reinterpret_cast<uintptr_t>(A.dW_out) | reinterpret_cast<uintptr_t>(A.inc_out)) & 15) == 0;
   for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
     const int64_t e0 = q << 2;
     f32x4 xv, av = {0, 0, 0, 0}, wv, bv = {0, 0, 0, 0};
@@ -131,26 +134,27 @@ __global__ void k_stage_diag_flat(StageArgs A) {
           xv[k] = A.x[e];
           if (A.proc == MSGM_PROC_REVERSE) av[k] = A.a[e];
           if (A.base) bv[k] = A.base[e];
-          wv[k] = stage_noise(A, e);
+          wv[k] = stage_noise(A, e, A.sqrt_delta);
         }
       }
     }
-    f32x4 o;
+    f32x4 o, iv;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float mu;
       if (A.proc == MSGM_PROC_REVERSE) mu = ca * (sb * av[k]) - (-0.5f * beta * xv[k]);
       else mu = -0.5f * beta * xv[k];
-      float inc = mu * A.delta + sig * wv[k];
-      o[k] = bv[k] + A.c_out * inc;
+      iv[k] = mu * A.delta + sig * wv[k];
+      o[k] = bv[k] + A.c_out * iv[k];
     }
     if (vec) {
       *reinterpret_cast<f32x4*>(A.out + e0) = o;
       if (A.dW_out) *reinterpret_cast<f32x4*>(A.dW_out + e0) = wv;
+      if (A.inc_out) *reinterpret_cast<f32x4*>(A.inc_out + e0) = iv;
     } else {
       for (int k = 0; k < 4; ++k) {
         int64_t e = e0 + k;
-        if (e < n) { A.out[e] = o[k]; if (A.dW_out) A.dW_out[e] = wv[k]; }
+        if (e < n) { A.out[e] = o[k]; if (A.dW_out) A.dW_out[e] = wv[k]; if (A.inc_out) A.inc_out[e] = iv[k]; }
       }
     }
   }
@@ -169,9 +173,6 @@ __global__ void k_stage_rows(StageArgs A) {
   const int64_t gid = blockIdx.x * groups_per_block + threadIdx.x / GS;
   const int64_t gstride = (int64_t)gridDim.x * groups_per_block;
   const int64_t n = A.n;
-  const float s = A.proc == MSGM_PROC_REVERSE ? A.T - A.t : A.t;
-  const float beta = sde_beta(A.b0, A.b1, s);
-  const float sb = sqrtf(beta);
   const float l = A.lmbd;
   const float sig_scale = (A.proc == MSGM_PROC_REVERSE) ? sqrtf(1.0f - l) : 1.0f;
   const float cV = 0.5f * sqrtf(2.0f);
@@ -183,10 +184,16 @@ __global__ void k_stage_rows(StageArgs A) {
     const float* ar = A.a ? A.a + b * n : nullptr;
     float ss = 0.f;
     if (live) {
+      const float delta = A.delta_rows ? A.delta_rows[b] : A.delta;
+      const float sqd = A.delta_rows ? sqrtf(delta) : A.sqrt_delta;
+      const float tb = A.delta_rows ? A.t + A.t_frac * delta : A.t;
+      const float s = A.proc == MSGM_PROC_REVERSE ? A.T - tb : tb;
+      const float beta = sde_beta(A.b0, A.b1, s);
+      const float sb = sqrtf(beta);
       for (int64_t i = lane; i < n; i += GS) {
         const int64_t e = b * n + i;
         float xi = xr[i];
-        float w_i = stage_noise(A, e);
+        float w_i = stage_noise(A, e, sqd);
         if (A.dW_out) A.dW_out[e] = w_i;
         float ga = 0.f, gw = 0.f, f = 0.f, div = 0.f, fs = 0.f;
         if (A.kind == MSGM_SDE_SGM) {
@@ -196,7 +203,7 @@ __global__ void k_stage_rows(StageArgs A) {
         } else if (A.kind == MSGM_SDE_MSGM_SPARSE) {
           const int64_t ip = (i + 1 == n) ? 0 : i + 1, im = (i == 0) ? n - 1 : i - 1;
           const float xp = xr[ip], xm = xr[im];
-          const float w_m = stage_noise(A, b * n + im);
+          const float w_m = stage_noise(A, b * n + im, sqd);
           f = 0.5f * beta * xi; fs = 0.f; div = 2.0f * f;
           // entries (I=i,J=i+1,K=i,V=+c) and (I=i,J=i-1,K=i-1,V=-c)
           gw = (cV * (sb * xp)) * w_i + (-cV * (sb * xm)) * w_m;
@@ -210,7 +217,7 @@ __global__ void k_stage_rows(StageArgs A) {
             float rw = 0.f, ra = 0.f;
             for (int64_t k = 0; k < n; ++k) {
               const float g = Gi[j * n + k];
-              rw += g * stage_noise(A, b * n + k);
+              rw += g * stage_noise(A, b * n + k, sqd);
               if (ar) ra += g * ar[k];
             }
             accw += yj * rw; acca += yj * ra;
@@ -225,9 +232,10 @@ __global__ void k_stage_rows(StageArgs A) {
           mu = fs;                                                      // SDEs.py:42-43
           if (!A.strato) mu = mu + 0.5f * div;                          // SDEs.py:38-39
         }
-        float inc = mu * A.delta + sig_scale * gw;                      // sde_scheme.py:40
+        float inc = mu * delta + sig_scale * gw;                        // sde_scheme.py:40
         float o = (A.base ? A.base[e] : 0.f) + A.c_out * inc;
         A.out[e] = o;
+        if (A.inc_out) A.inc_out[e] = inc;
         ss += o * o;
       }
     }
@@ -269,6 +277,17 @@ __global__ void k_rk4_combine(float* __restrict__ out, const float* __restrict__
         for (int64_t i = lane; i < n; i += GS) out[b * n + i] *= sc;
       }
     }
+  }
+}
+
+// out = c0*a + c1*b + c2*c (b, c optional) — glue for Heun / RK4 stage points
+__global__ void k_lincomb(float* __restrict__ out, const float* __restrict__ a, float c0, const float* __restrict__ b,
+                          float c1, const float* __restrict__ c, float c2, int64_t n) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    float v = c0 * a[e];
+    if (b) v += c1 * b[e];
+    if (c) v += c2 * c[e];
+    out[e] = v;
   }
 }
 
@@ -422,8 +441,9 @@ int msgm_rademacher(float* v, int64_t n, const float* u, const uint64_t* rng, ms
 
 int msgm_sde_stage(float* out, const float* base, float c_out, const float* x, const float* a, const float* dW,
                    const float* z, float sqrt_delta, const uint64_t* rng, uint64_t rng_step, float* dW_out,
-                   int64_t B, int64_t n, const msgm_sde_t* sde, int32_t proc, int32_t strato, float t, float delta,
-                   float lmbd, const float* norm0, msgm_stream_t stream) {
+                   float* inc_out, int64_t B, int64_t n, const msgm_sde_t* sde, int32_t proc, int32_t strato, float t,
+                   float delta, float lmbd, const float* norm0, const float* delta_rows, float t_frac,
+                   msgm_stream_t stream) {
   if (!out || !x || !sde || B <= 0 || n <= 0) return MSGM_E_BADARG;
   if (!dW && !z && !rng) return MSGM_E_BADARG;
   if (proc == MSGM_PROC_REVERSE && !a) return MSGM_E_BADARG;
@@ -433,8 +453,8 @@ int msgm_sde_stage(float* out, const float* base, float c_out, const float* x, c
   if (sde->kind == MSGM_SDE_MSGM_DENSE && n > 64) return MSGM_E_UNSUPPORTED;
   if (sde->kind < 0 || sde->kind > 2) return MSGM_E_BADARG;
   StageArgs A{out, base, c_out, x, a, dW, z, sqrt_delta, rng, rng_step, dW_out, B, n, sde->kind, proc, strato,
-              sde->beta_min, sde->beta_max, sde->T, t, delta, lmbd, sde->G, sde->L_G, norm0};
-  if (sde->kind == MSGM_SDE_SGM && !norm0) {
+              sde->beta_min, sde->beta_max, sde->T, t, delta, lmbd, sde->G, sde->L_G, norm0, inc_out, delta_rows, t_frac};
+  if (sde->kind == MSGM_SDE_SGM && !norm0 && !delta_rows) {
     hipLaunchKernelGGL(k_stage_diag_flat, dim3(grid_for((B * n + 3) / 4, 256)), dim3(256), 0, S(stream), A);
     return msgm_check_launch();
   }
@@ -463,6 +483,13 @@ int msgm_rk4_combine(float* out, const float* x, const float* k1, const float* k
       default: hipLaunchKernelGGL(k_rk4_combine<64>, dim3(grid), dim3(block), 0, S(stream), out, x, k1, k2, k3, k4, B, n, norm0); break;
     }
   });
+}
+
+int msgm_lincomb(float* out, const float* a, float c0, const float* b, float c1, const float* c, float c2, int64_t n,
+                 msgm_stream_t stream) {
+  if (!out || !a || n <= 0) return MSGM_E_BADARG;
+  hipLaunchKernelGGL(k_lincomb, dim3(grid_for(n, 256)), dim3(256), 0, S(stream), out, a, c0, b, c1, c, c2, n);
+  return msgm_check_launch();
 }
 
 int msgm_row_norm(const float* x, float* out, int64_t B, int64_t n, msgm_stream_t stream) {

@@ -70,18 +70,33 @@ def rademacher(shape, device, u: Optional[torch.Tensor] = None, rng: Optional[Ph
 def sde_stage(out: torch.Tensor, base: Optional[torch.Tensor], c_out: float, x: torch.Tensor,
               a: Optional[torch.Tensor], sde: L.SdeT, proc: int, strato: bool, t: float, delta: float, lmbd: float = 0.0,
               dW: Optional[torch.Tensor] = None, z: Optional[torch.Tensor] = None, rng: Optional[PhiloxState] = None,
-              rng_step: int = 0, dW_out: Optional[torch.Tensor] = None, norm0: Optional[torch.Tensor] = None) -> torch.Tensor:
+              rng_step: int = 0, dW_out: Optional[torch.Tensor] = None, norm0: Optional[torch.Tensor] = None,
+              inc_out: Optional[torch.Tensor] = None, delta_rows: Optional[torch.Tensor] = None,
+              t_frac: float = 0.0) -> torch.Tensor:
     """One integrator stage (K2/K3/K4): out = base + c_out*(drift*delta + sigma.dW)."""
     if x.dim() != 2:
         raise MsgmError("state must be 2-D (B,n)")
     B, n = x.shape
-    for nm, tt in (("out", out), ("base", base), ("a", a), ("dW", dW), ("z", z), ("dW_out", dW_out)):
+    for nm, tt in (("out", out), ("base", base), ("a", a), ("dW", dW), ("z", z), ("dW_out", dW_out), ("inc_out", inc_out)):
         _same_shape(tt, (B, n), nm)
     _same_shape(norm0, (B,), "norm0")
+    _same_shape(delta_rows, (B,), "delta_rows")
     check(lib().msgm_sde_stage(ptr(f32(out)), ptr(base), float(c_out), ptr(f32(x)), ptr(a), ptr(dW), ptr(z),
-                               float(delta ** 0.5), _rng_ptr(rng), int(rng_step), ptr(dW_out), B, n, sde, int(proc),
-                               int(bool(strato)), float(t), float(delta), float(lmbd), ptr(norm0), stream()),
+                               float(delta ** 0.5), _rng_ptr(rng), int(rng_step), ptr(dW_out), ptr(inc_out), B, n, sde,
+                               int(proc), int(bool(strato)), float(t), float(delta), float(lmbd), ptr(norm0),
+                               ptr(delta_rows), float(t_frac), stream()),
           "msgm_sde_stage")
+    return out
+
+
+def lincomb(out: torch.Tensor, a: torch.Tensor, c0: float, b: Optional[torch.Tensor] = None, c1: float = 0.0,
+            c: Optional[torch.Tensor] = None, c2: float = 0.0) -> torch.Tensor:
+    n = a.numel()
+    for nm, tt in (("out", out), ("b", b), ("c", c)):
+        if tt is not None and tt.numel() != n:
+            raise MsgmError(f"{nm} has {tt.numel()} elements, expected {n}")
+    check(lib().msgm_lincomb(ptr(f32(out)), ptr(f32(a)), float(c0), ptr(b), float(c1), ptr(c), float(c2), n, stream()),
+          "msgm_lincomb")
     return out
 
 

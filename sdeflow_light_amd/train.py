@@ -1,0 +1,93 @@
+"""The score-matching training step as the build runs it (replaces the loop
+body MSGM_higherDim.py:803-809): perturb (K1) -> probe -> fused
+forward/tangent/loss/backward (K5) -> [RCCL all-reduce of the flat gradient
+bucket] -> fused Adam (K13).  Everything is enqueued on one stream with no
+host synchronisation, so a step can be captured once and replayed as a hipGraph
+(single-GPU) — the Philox offset and the Adam step count live on the device.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+from . import ops
+from . import parallel
+from ._lib import MsgmError
+
+
+class MLPScoreTrainer:
+    """SGM + MLP (configs C1/C2).  ``x`` is this rank's shard (B_local, d) and
+    stays resident; each ``step()`` draws fresh (t, eps, v) on the device."""
+
+    def __init__(self, gen_sde, batch_local: int, lr: float = 1e-3, world: int = 1, use_graph: bool = True,
+                 seed: int = 0):
+        from .NN import MLP
+        net, base = gen_sde.a, gen_sde.base_sde
+        if not (isinstance(net, MLP) and base.kind == L.SDE_SGM):
+            raise MsgmError("MLPScoreTrainer is built for MLP + SGMsde")
+        self.gen_sde, self.net, self.base = gen_sde, net, base
+        self.dev = next(net.parameters()).device
+        self.B, self.d, self.world = batch_local, net.input_dim, world
+        self.flat, self.gflat = net.flat_parameters()
+        self.n = self.flat.numel()
+        self.m = torch.zeros_like(self.flat)
+        self.v = torch.zeros_like(self.flat)
+        self.step_dev = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        self.rng = L.PhiloxState(seed * 1000003 + 17, self.dev)
+        self.ws = ops.mlp_ssm_workspace(self.d, net.pre is not None, self.dev)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=self.dev)
+        self.x = torch.zeros(batch_local, self.d, dtype=torch.float32, device=self.dev)
+        self.y = torch.empty_like(self.x)
+        self.t = torch.empty(batch_local, dtype=torch.float32, device=self.dev)
+        self.vp = torch.empty_like(self.x)
+        self.lr = lr
+        self.P = net.kernel_params()
+        self.st = base.struct()
+        self.inv_batch = 1.0 / (batch_local * world)        # mean over the GLOBAL batch
+        self.graph = None
+        self.use_graph = use_graph and world == 1
+
+    def _grad(self):
+        lib = ops.lib()
+        s = ops.stream()
+        ops.check(lib.msgm_perturb_vp(self.x.data_ptr(), self.y.data_ptr(), self.t.data_ptr(), None, self.B, self.d,
+                                      self.st, None, None, self.rng.ptr(), s), "msgm_perturb_vp")
+        ops.check(lib.msgm_rademacher(self.vp.data_ptr(), self.vp.numel(), None, self.rng.ptr(), s), "msgm_rademacher")
+        ops.mlp_ssm_grad(self.P, self.y, self.t, self.vp, self.st, self.inv_batch, self.gflat, self.ws, loss_sum=self.loss)
+        self.rng.advance(1)
+
+    def _update(self):
+        ops.counter_inc(self.step_dev)
+        ops.adam_step(self.flat, self.gflat, self.m, self.v, step=0, lr=self.lr, step_dev=self.step_dev)
+
+    def _body(self):
+        self._grad()
+        if self.world > 1:
+            parallel.allreduce_sum_(self.gflat)   # grads already carry 1/global_batch
+            parallel.allreduce_sum_(self.loss)
+        self._update()
+
+    def capture(self):
+        s = torch.cuda.Stream(device=self.dev)
+        s.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(s):
+            self._body()
+        torch.cuda.current_stream(self.dev).wait_stream(s)
+        torch.cuda.synchronize(self.dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._body()
+
+    def set_data(self, x: torch.Tensor):
+        self.x.copy_(x)
+
+    def step(self):
+        if self.use_graph:
+            if self.graph is None:
+                self.capture()
+            self.graph.replay()
+        else:
+            self._body()
+        return self.loss

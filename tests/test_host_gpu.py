@@ -1,0 +1,210 @@
+"""GPU parity of the host mirrors (same call surface as the reference's
+NN / SDEs / sde_scheme) against the golden vectors recorded from the reference.
+Sampler tolerance: 1e-4 rel-L2 (north_star); index tensors bit-exact."""
+import pytest
+import torch
+
+from conftest import load_golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def Tp():
+    return torch.nn.Parameter(torch.FloatTensor([1.0]), requires_grad=False)
+
+
+def make_gen(base_kind, net, g=None, prefix=None, nsf=16, G=None, n=None):
+    from sdeflow_light_amd.SDEs import SGMsde, MSGMsde, PluginReverseSDE
+    T = Tp()
+    if base_kind == "sgm":
+        base = SGMsde(beta_min=0.1, beta_max=20.0, t_epsilon=1e-3, T=T, num_steps_forward=nsf, device=DEV)
+    else:
+        base = MSGMsde(torch.randn(64, n), beta_min=0.1, beta_max=20.0, t_epsilon=1e-3, T=T, num_steps_forward=nsf,
+                       device=DEV, denseTensor=(base_kind == "dense"), norm_map="log", G=G)
+    gen = PluginReverseSDE(base, net.to(DEV), T, deviceReverseSDE=DEV).to(DEV)
+    if g is not None:
+        sd = {k: v for k, v in g.sub(prefix).items()}
+        missing = gen.load_state_dict(sd, strict=False)
+        assert set(missing.missing_keys) <= {"T", "base_sde.T"} and not missing.unexpected_keys
+    return gen
+
+
+def test_mlp_module_forward_golden():
+    from sdeflow_light_amd.NN import MLP
+    g = load_golden("g09_mlp")
+    for tag, d, pre in (("mlp2", 2, None), ("mlp6n", 6, "NormalizeLogRadius")):
+        net = MLP(d, premodule=pre).to(DEV)
+        net.load_state_dict(g.sub(tag + "::"))
+        out = net(g[tag + "_x"].to(DEV), g[tag + "_t"].to(DEV))
+        assert rel_l2(out.cpu(), g[tag + "_out"]) <= 1e-5
+
+
+@pytest.mark.parametrize("tag,d,pre", [("mlp2", 2, None), ("mlp6n", 6, "NormalizeLogRadius")])
+def test_ssm_reference_loop_surface(tag, d, pre):
+    """gen_sde.ssm(x).mean().backward() as the driver writes it (MSGM_higherDim.py:807-808)."""
+    from sdeflow_light_amd.NN import MLP
+    g = load_golden("g10_ssm_mlp")
+    gen = make_gen("sgm", MLP(d, premodule=pre), g, tag + "::")
+    gen.zero_grad()
+    per = gen.ssm(g[tag + "_x"].to(DEV), u=g[tag + "_u_t"].reshape(-1).to(DEV), eps=g[tag + "_eps"].to(DEV),
+                  u_v=g[tag + "_u_v"].to(DEV))
+    assert rel_l2(per.detach().cpu(), g[tag + "_per"]) <= 1e-5
+    per.mean().backward()
+    for k, p in gen.named_parameters():
+        if p.requires_grad:
+            assert rel_l2(p.grad.cpu(), g[f"{tag}_grad::{k}"]) <= 2e-4, k
+    # a second backward pass accumulates (autograd semantics)
+    per2 = gen.ssm(g[tag + "_x"].to(DEV), u=g[tag + "_u_t"].reshape(-1).to(DEV), eps=g[tag + "_eps"].to(DEV),
+                   u_v=g[tag + "_u_v"].to(DEV))
+    per2.sum().backward()
+    B = per.shape[0]
+    k = "a.main.2.weight"
+    assert rel_l2(dict(gen.named_parameters())[k].grad.cpu(), (1 + B) * g[f"{tag}_grad::{k}"]) <= 2e-4
+
+
+def test_three_train_steps_golden_fused_adam():
+    """3 optimizer steps (SSM + Adam) against the reference's loss sequence and final parameters (g11)."""
+    from sdeflow_light_amd.NN import MLP
+    from sdeflow_light_amd.optim import FusedAdam
+    g = load_golden("g11_train3")
+    gen = make_gen("sgm", MLP(2), g, "init::")
+    opt = FusedAdam(gen.parameters(), lr=1e-3)
+    for i in range(3):
+        opt.zero_grad()
+        loss = gen.ssm(g["x"][i].to(DEV), u=g["u_t"][i].reshape(-1).to(DEV), eps=g["eps"][i].to(DEV),
+                       u_v=g["u_v"][i].to(DEV)).mean()
+        loss.backward()
+        opt.step()
+        assert float(loss.detach()) == pytest.approx(float(g["loss"][i]), rel=2e-5)
+    sd = gen.state_dict()
+    for k, v in g.sub("final::").items():
+        assert rel_l2(sd[k].cpu(), v) <= 2e-5, k
+    osd = opt.state_dict()
+    assert len(osd["state"]) == 8                                               # torch.optim.Adam layout
+    assert all(float(st["step"]) == 3.0 and set(st) == {"step", "exp_avg", "exp_avg_sq"} for st in osd["state"].values())
+
+
+def test_trainer_graph_equals_eager():
+    from sdeflow_light_amd.NN import MLP
+    from sdeflow_light_amd.train import MLPScoreTrainer
+    from sdeflow_light_amd.data import gaussian_mixture_2d
+    outs = []
+    for use_graph in (False, True):
+        torch.manual_seed(0)
+        gen = make_gen("sgm", MLP(2))
+        tr = MLPScoreTrainer(gen, 4096, lr=1e-3, use_graph=use_graph, seed=3)
+        tr.set_data(gaussian_mixture_2d(4096, device=DEV))
+        losses = [float(tr.step()) for _ in range(6)]
+        outs.append((losses, tr.flat.clone()))
+    # the graphed run spends one extra (warm-up) step inside capture(): compare 6 eager vs steps 2..6 graphed + ...
+    assert all(abs(l) < 1e6 for l in outs[0][0]) and all(abs(l) < 1e6 for l in outs[1][0])
+    assert outs[0][0][1:] == pytest.approx(outs[1][0][:5], rel=1e-5)
+
+
+def _mlp_gen(g, prefix, d, pre, kind, **kw):
+    from sdeflow_light_amd.NN import MLP
+    return make_gen(kind, MLP(d, premodule=pre), g, prefix, **kw)
+
+
+def test_samplers_sgm_golden():
+    from sdeflow_light_amd import sde_scheme as SS
+    g = load_golden("g07_samplers")
+    gen = _mlp_gen(g, "sgm::", 2, None, "sgm")
+    x0 = g["sgm_x0"]
+    for tag, fn in (("em", SS.euler_maruyama_sampler), ("heun", SS.heun_sampler), ("rk4", SS.rk4_stratonovich_sampler)):
+        z = g[f"sgm_{tag}_z"]
+        xs = fn(gen, x0.to(DEV), num_steps=z.shape[0], keep_all_samples=True, include_t0=True, noise=z)
+        assert xs.device.type == "cpu" and xs.shape == g[f"sgm_{tag}_traj"].shape
+        assert rel_l2(xs, g[f"sgm_{tag}_traj"]) <= 1e-4, tag
+    xs = SS.euler_maruyama_sampler(gen, x0.to(DEV), num_steps=8, lmbd=0.5, keep_all_samples=True, noise=g["sgm_em_l05_z"])
+    assert rel_l2(xs, g["sgm_em_l05_traj"]) <= 1e-4
+    xs = SS.euler_maruyama_sampler(gen, x0.to(DEV), num_steps=8, keep_all_samples=False, noise=g["sgm_em_final_z"])
+    assert rel_l2(xs, g["sgm_em_final"]) <= 1e-4
+    xs = SS.euler_maruyama_sampler(gen, x0.to(DEV), num_steps=8, keep_all_samples=False, samplesToKeep=g["sgm_em_keep_idx"],
+                                   noise=g["sgm_em_keep_z"])
+    assert rel_l2(xs, g["sgm_em_keep"]) <= 1e-4
+    with pytest.raises(ValueError, match="samplesToKeep"):
+        SS.euler_maruyama_sampler(gen, x0.to(DEV), num_steps=8, keep_all_samples=False, samplesToKeep=[1, 2, 3])
+
+
+def test_samplers_msgm_sparse_golden():
+    from sdeflow_light_amd import sde_scheme as SS
+    from sdeflow_light_amd.SDEs import forward_SDE
+    g = load_golden("g07_samplers")
+    gen = _mlp_gen(g, "sp::", 6, "NormalizeLogRadius", "sparse", n=6)
+    x0 = g["sp_x0"]
+    for nc in (0, 1):
+        for tag, fn in (("em", SS.euler_maruyama_sampler), ("heun", SS.heun_sampler), ("rk4", SS.rk4_stratonovich_sampler)):
+            z = g[f"sp_{tag}_nc{nc}_z"]
+            xs = fn(gen, x0.to(DEV), num_steps=z.shape[0], keep_all_samples=True, include_t0=True,
+                    norm_correction=bool(nc), noise=z)
+            assert rel_l2(xs, g[f"sp_{tag}_nc{nc}_traj"]) <= 1e-4, (tag, nc)
+    z = g["sp_fwd_rk4_z"]
+    xs = SS.rk4_stratonovich_sampler(forward_SDE(gen.base_sde, gen.T), x0.to(DEV), 4, lmbd=0., keep_all_samples=True,
+                                     include_t0=True, norm_correction=True, noise=z)
+    assert rel_l2(xs, g["sp_fwd_rk4_traj"]) <= 1e-4
+
+
+def test_samplers_msgm_dense_golden():
+    from sdeflow_light_amd import sde_scheme as SS
+    g = load_golden("g07_samplers")
+    gen = _mlp_gen(g, "dn::", 4, None, "dense", n=4, G=g["dn_G"])
+    for tag, fn in (("em", SS.euler_maruyama_sampler), ("rk4", SS.rk4_stratonovich_sampler)):
+        z = g[f"dn_{tag}_z"]
+        xs = fn(gen, g["dn_x0"].to(DEV), num_steps=z.shape[0], keep_all_samples=True, include_t0=True,
+                norm_correction=True, noise=z)
+        assert rel_l2(xs, g[f"dn_{tag}_traj"]) <= 1e-4, tag
+
+
+@pytest.mark.parametrize("tag,kind,n", [("sp", "sparse", 6), ("dn", "dense", 4)])
+def test_msgm_forward_perturb_golden(tag, kind, n):
+    """Device-resident masked RK4 (no per-row Python loop) vs SDE.sample_scheme (g08)."""
+    from sdeflow_light_amd.SDEs import MSGMsde
+    from sdeflow_light_amd import ops
+    g = load_golden("g08_sample_scheme")
+    T = Tp()
+    base = MSGMsde(torch.randn(64, n), T=T, num_steps_forward=4, device=DEV, denseTensor=(kind == "dense"),
+                   norm_map="log", G=g.get("dn_G") if kind == "dense" else None).to(DEV)
+    t = g[f"{tag}_t"].to(DEV)
+    k = ops.forward_step_index(t, 4, 1.0)
+    assert torch.equal(k.cpu(), g[f"{tag}_k"])                                  # bit-exact timestep indexing
+    y = base.sample(t, g[f"{tag}_x0"].to(DEV), noise_main=g[f"{tag}_z_main"], noise_short=g[f"{tag}_z_short"])
+    assert rel_l2(y.cpu(), g[f"{tag}_y"]) <= 1e-4
+    y2 = base.sample(t, g[f"{tag}_x0"].to(DEV))                                 # Philox path: fresh noise every call
+    y3 = base.sample(t, g[f"{tag}_x0"].to(DEV))
+    assert torch.isfinite(y2).all() and y2.shape == y.shape and not torch.equal(y2, y3)
+
+
+def test_latent_samples():
+    from sdeflow_light_amd.SDEs import MSGMsde, SGMsde
+    g = load_golden("g13_misc")
+    T = Tp()
+    ms = MSGMsde(g["lat_xinit"], T=T, denseTensor=False, norm_map="log", device=DEV).to(DEV)
+    assert rel_l2(ms.r_T.cpu(), g["lat_rT"]) <= 1e-6
+    x0 = ms.latent_sample(40, 6, u=g["lat_u"].to(DEV), z=g["lat_z"].to(DEV))
+    assert rel_l2(x0.cpu(), g["lat_x0"]) <= 1e-5
+    x1 = ms.latent_sample(1000, 6)
+    assert torch.isfinite(x1).all() and x1.shape == (1000, 6)
+    s = SGMsde(T=T, device=DEV)
+    z = s.latent_sample(1 << 16, 4)
+    assert abs(float(z.mean())) < 0.02 and abs(float(z.std()) - 1) < 0.02
+    assert not torch.equal(z, s.latent_sample(1 << 16, 4))
+
+
+def test_graphed_sampler_equals_eager():
+    from sdeflow_light_amd.NN import MLP
+    from sdeflow_light_amd import sde_scheme as SS
+    from sdeflow_light_amd import _lib
+    torch.manual_seed(1)
+    gen = make_gen("sgm", MLP(2))
+    B, N = 4096, 25
+    x0 = torch.randn(B, 2, device=DEV)
+    gs = SS.GraphedEMSampler(gen, B, N)
+    st = gen.base_sde.rng.state.clone()
+    a = gs.run(x0).clone()
+    gen.base_sde.rng.state.copy_(st)
+    b = SS.euler_maruyama_sampler(gen, x0, num_steps=N, keep_all_samples=False)
+    assert rel_l2(a.cpu(), b) <= 1e-6
+    c = gs.run(x0).clone()                                    # offset advanced inside the graph: fresh noise
+    assert not torch.equal(a, c) and torch.isfinite(c).all()
