@@ -85,6 +85,12 @@ int msgm_perturb_vp(const float* x0, float* y, float* t_out, float* eps_out,
                     const float* u, const float* eps, const uint64_t* rng,
                     msgm_stream_t stream);
 
+/* Training-step prologue in ONE launch: msgm_perturb_vp + msgm_rademacher with
+ * in-kernel Philox draws (streams 0,1,2), plus `*step_ctr += 1` (optimizer step
+ * count, may be NULL).  Draws are identical to the two separate kernels. */
+int msgm_ssm_prep(const float* x0, float* y, float* t_out, float* v, int64_t B, int64_t d,
+                  const msgm_sde_t* sde, const uint64_t* rng, int64_t* step_ctr, msgm_stream_t stream);
+
 /* Bit-exact per-row stop index k = trunc((nsf*t)/T) (int32), rows with t>=T
  * forced to nsf.  Replaces SDEs.py:89-101. */
 int msgm_forward_step_index(const float* t, int32_t* k, int64_t B, int32_t nsf, float T,
@@ -208,6 +214,14 @@ int msgm_mlp_ssm_partial(const msgm_mlp_params_t* P, const float* y, const float
                          msgm_stream_t stream);
 int msgm_mlp_ssm_reduce(int32_t d, int32_t premodule, const void* workspace, int32_t n_slabs,
                         float inv_batch, float* grads, float* loss_sum, msgm_stream_t stream);
+
+/* Slab reduction fused with the Adam update of msgm_adam_step (single-GPU step:
+ * nothing sits between them) and, when rng_advance != NULL, rng_advance[1] += 1.
+ * grads may be NULL. */
+int msgm_mlp_ssm_reduce_adam(int32_t d, int32_t premodule, const void* workspace, int32_t n_slabs,
+                             float inv_batch, float* grads, float* loss_sum, float* params, float* m,
+                             float* v, double lr, double beta1, double beta2, double eps,
+                             const int64_t* step_dev, uint64_t* rng_advance, msgm_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -47,6 +47,7 @@ SIGNATURES = {
     "msgm_fill_uniform": (C.c_int, [_P, _I64, _P, _U32, _P]),
     "msgm_fill_normal": (C.c_int, [_P, _I64, _P, _U32, _P]),
     "msgm_perturb_vp": (C.c_int, [_P, _P, _P, _P, _I64, _I64, C.POINTER(SdeT), _P, _P, _P, _P]),
+    "msgm_ssm_prep": (C.c_int, [_P, _P, _P, _P, _I64, _I64, C.POINTER(SdeT), _P, _P, _P]),
     "msgm_forward_step_index": (C.c_int, [_P, _P, _I64, _I32, _F, _P]),
     "msgm_rademacher": (C.c_int, [_P, _I64, _P, _P, _P]),
     "msgm_sde_stage": (C.c_int, [_P, _P, _F, _P, _P, _P, _P, _F, _P, _U64, _P, _P, _I64, _I64, C.POINTER(SdeT), _I32,
@@ -64,6 +65,7 @@ SIGNATURES = {
     "msgm_mlp_ssm_partial": (C.c_int, [C.POINTER(MlpParamsT), _P, _P, _P, _I64, C.POINTER(SdeT), _F, _P, _P, _SZ,
                                        C.POINTER(C.c_int32), _P]),
     "msgm_mlp_ssm_reduce": (C.c_int, [_I32, _I32, _P, _I32, _F, _P, _P, _P]),
+    "msgm_mlp_ssm_reduce_adam": (C.c_int, [_I32, _I32, _P, _I32, _F, _P, _P, _P, _P, _P, _D, _D, _D, _D, _P, _P, _P]),
     "msgm_mlp_ssm_grad": (C.c_int, [C.POINTER(MlpParamsT), _P, _P, _P, _I64, C.POINTER(SdeT), _F, _P, _P, _P, _P, _SZ, _P]),
 }
 

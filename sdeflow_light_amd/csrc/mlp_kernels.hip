@@ -22,6 +22,19 @@
 #include "common.h"
 
 #define HID 128
+
+// Diagnostic build only (-DMLP_STAMPS): per-phase s_memtime sums of workgroup 0 /
+// wave 0, read back with msgm_debug_stamps().  No stamp executes in the shipped .so.
+#ifdef MLP_STAMPS
+__device__ unsigned long long g_stamps[16];
+#define STAMP_DECL unsigned long long st_acc[12] = {0,0,0,0,0,0,0,0,0,0,0,0}; unsigned long long st_prev = __builtin_amdgcn_s_memtime();
+#define STAMP(i) do { unsigned long long _t = __builtin_amdgcn_s_memtime(); st_acc[i] += _t - st_prev; st_prev = _t; } while (0)
+#define STAMP_FLUSH do { if (blockIdx.x == 0 && threadIdx.x == 0) { for (int _i = 0; _i < 12; ++_i) g_stamps[_i] = st_acc[_i]; } } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_FLUSH
+#endif
 #define ACT_P 132   // LDS pitch of an activation row ([sample][feature])
 #define SM_P 36     // LDS pitch of the small per-sample rows (h0, abar, partials)
 #define DPAD 32     // padded in/out width of the small layers
@@ -245,6 +258,7 @@ __global__ void __launch_bounds__(256, 1) k_mlp(MlpArgs A) {
   prefetch_w<false>(A.P.W2, w, il, q, pre);
   __syncthreads();
 
+  STAMP_DECL
   const int64_t n_tiles = (A.B + SPT - 1) / SPT;
   const float ca = 1.0f - 0.5f * A.lmbd;
 
@@ -293,6 +307,7 @@ __global__ void __launch_bounds__(256, 1) k_mlp(MlpArgs A) {
       }
     }
     __syncthreads();
+    STAMP(0);
 
     // ---- phase 1: layer 1 (K = in_dim, weights from LDS) ------------------
     f32x4 z1[2][2], z2[2][2], z3[2][2], h[2][2];
@@ -321,6 +336,7 @@ __global__ void __launch_bounds__(256, 1) k_mlp(MlpArgs A) {
     }
     store_act(X, w, il, q, h);
     __syncthreads();
+    STAMP(1);
 
     // ---- phase 2: layer 2 --------------------------------------------------
 #pragma unroll
@@ -342,6 +358,7 @@ __global__ void __launch_bounds__(256, 1) k_mlp(MlpArgs A) {
     }
     store_act(Y, w, il, q, h);
     __syncthreads();
+    STAMP(2);
 
     // ---- phase 3: layer 3, then this wave's K-slice of layer 4 -------------
 #pragma unroll
@@ -382,6 +399,7 @@ __global__ void __launch_bounds__(256, 1) k_mlp(MlpArgs A) {
       }
     }
     __syncthreads();
+    STAMP(3);
 
     // ---- phase 4: reduce layer-4 partials; outputs / loss ------------------
     if (MODE == MODE_FWD || MODE == MODE_EM) {
@@ -436,6 +454,7 @@ __global__ void __launch_bounds__(256, 1) k_mlp(MlpArgs A) {
         if (live) { loss_acc += lj; if (A.loss_per) A.loss_per[smp] = lj; }
       }
       __syncthreads();
+      STAMP(4);
 
       // ---- phase 5: layer-4 backward, dW4, Swish' on layer 3 --------------
       f32x4 g[2][2], zb[2][2];
@@ -454,6 +473,7 @@ __global__ void __launch_bounds__(256, 1) k_mlp(MlpArgs A) {
       db3[0] += zb[0][0]; db3[1] += zb[1][0];
       store_act(U, w, il, q, zb);
       __syncthreads();
+      STAMP(5);
 
       // ---- phase 6: dgrad layer 3 (W3^T), dW3, Swish' on layer 2 -----------
 #pragma unroll
@@ -465,6 +485,7 @@ __global__ void __launch_bounds__(256, 1) k_mlp(MlpArgs A) {
       db2[0] += zb[0][0]; db2[1] += zb[1][0];
       store_act(Z, w, il, q, zb);                          // h3 is dead after phase 5
       __syncthreads();
+      STAMP(6);
 
       // ---- phase 7: dgrad layer 2 (W2^T), dW2, Swish' on layer 1 -----------
 #pragma unroll
@@ -476,15 +497,18 @@ __global__ void __launch_bounds__(256, 1) k_mlp(MlpArgs A) {
       db1[0] += zb[0][0]; db1[1] += zb[1][0];
       store_act(U, w, il, q, zb);                          // zbar3 is dead after phase 6
       __syncthreads();
+      STAMP(7);
 
       // ---- phase 8: dW1 ------------------------------------------------------
       wgrad<KT1>(U, H0, SM_P, w, il, q, dW1);
       __syncthreads();   // H0/ABAR/PART/X.. are rewritten by the next tile
+      STAMP(8);
     }
   }
 
   // ---- epilogue (train): write this workgroup's gradient slab -------------
   if (MODE == MODE_TRAIN) {
+    STAMP(9);
     float* slab = A.slabs + (int64_t)blockIdx.x * (A.n_params + 1);
     const int in_dim = A.in_dim;
     const int64_t oW1 = 0, ob1 = oW1 + (int64_t)HID * in_dim, oW2 = ob1 + HID, ob2 = oW2 + HID * HID,
@@ -545,18 +569,49 @@ __global__ void __launch_bounds__(256, 1) k_mlp(MlpArgs A) {
       for (int j = 0; j < 16; ++j) s += RED[j];
       slab[A.n_params] = s;
     }
+    STAMP(10);
+    STAMP_FLUSH;
   }
 }
 
-// grads[p] = sum_wg slab[wg][p]; last element = loss sum (scaled by inv_batch -> mean)
-__global__ void k_slab_reduce(const float* __restrict__ slabs, int n_slabs, int64_t stride, float* __restrict__ grads,
-                              int64_t n_params, float* __restrict__ loss_sum, float inv_batch) {
-  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p <= n_params; p += (int64_t)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int g = 0; g < n_slabs; ++g) s += slabs[g * stride + p];
-    if (p < n_params) grads[p] = s;
-    else if (loss_sum) loss_sum[0] = s * inv_batch;
+// grads[p] = sum_wg slab[wg][p]; element n_params = loss sum (x inv_batch -> mean).
+// 64 parameters x 4 slab-groups per block: each thread sums a quarter of the slabs
+// (coalesced along p), the four partials meet in LDS — deterministic order.
+// ADAM: the same thread then applies the fused Adam update to its parameter
+// (single-GPU step: no all-reduce sits between the two), and thread 0 advances the
+// Philox offset (nothing after this kernel reads it within the step).
+template <bool ADAM>
+__global__ void __launch_bounds__(256) k_slab_reduce(const float* __restrict__ slabs, int n_slabs, int64_t stride,
+                                                     float* __restrict__ grads, int64_t n_params,
+                                                     float* __restrict__ loss_sum, float inv_batch,
+                                                     float* __restrict__ prm, float* __restrict__ m, float* __restrict__ v,
+                                                     double lr, double b1, double b2, double eps,
+                                                     const int64_t* __restrict__ step_dev, uint64_t* rng_advance) {
+  __shared__ float part[4][64];
+  const int px = threadIdx.x & 63, gy = threadIdx.x >> 6;
+  const int64_t p = (int64_t)blockIdx.x * 64 + px;
+  float s = 0.f;
+  if (p <= n_params)
+    for (int g = gy; g < n_slabs; g += 4) s += slabs[(int64_t)g * stride + p];
+  part[gy][px] = s;
+  __syncthreads();
+  if (gy == 0 && p <= n_params) {
+    s = (part[0][px] + part[1][px]) + (part[2][px] + part[3][px]);
+    if (p < n_params) {
+      if (grads) grads[p] = s;
+      if (ADAM) {
+        const int64_t st = step_dev[0];
+        const double bc1 = 1.0 - pow(b1, (double)st), bc2 = 1.0 - pow(b2, (double)st);
+        const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+        const float w1 = (float)(1.0 - b1), b2f = (float)b2, w2 = (float)(1.0 - b2);
+        const float mm = m[p] + w1 * (s - m[p]);
+        const float vv = v[p] * b2f + w2 * (s * s);
+        prm[p] = prm[p] - step_size * (mm / (sqrtf(vv) / bc2_sqrt + (float)eps));
+        m[p] = mm; v[p] = vv;
+      }
+    } else if (loss_sum) loss_sum[0] = s * inv_batch;
   }
+  if (ADAM && rng_advance && blockIdx.x == 0 && threadIdx.x == 0) rng_advance[1] += 1;
 }
 
 // ============================================================ C ABI
@@ -650,8 +705,22 @@ int msgm_mlp_ssm_reduce(int32_t d, int32_t premodule, const void* workspace, int
                         float* grads, float* loss_sum, msgm_stream_t stream) {
   if (!workspace || !grads || n_slabs < 1 || n_slabs > MLP_MAX_GRID) return MSGM_E_BADARG;
   const int64_t n_params = msgm_mlp_num_params(d, premodule);
-  hipLaunchKernelGGL(k_slab_reduce, dim3(grid_for(n_params + 1, 256, 256)), dim3(256), 0, S(stream),
-                     reinterpret_cast<const float*>(workspace), n_slabs, n_params + 1, grads, n_params, loss_sum, inv_batch);
+  hipLaunchKernelGGL(k_slab_reduce<false>, dim3((unsigned)((n_params + 1 + 63) / 64)), dim3(256), 0, S(stream),
+                     reinterpret_cast<const float*>(workspace), n_slabs, n_params + 1, grads, n_params, loss_sum, inv_batch,
+                     (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.0, 0.0, 0.0, 0.0, (const int64_t*)nullptr,
+                     (uint64_t*)nullptr);
+  return msgm_check_launch();
+}
+
+int msgm_mlp_ssm_reduce_adam(int32_t d, int32_t premodule, const void* workspace, int32_t n_slabs, float inv_batch,
+                             float* grads, float* loss_sum, float* params, float* m, float* v, double lr, double beta1,
+                             double beta2, double eps, const int64_t* step_dev, uint64_t* rng_advance,
+                             msgm_stream_t stream) {
+  if (!workspace || !params || !m || !v || !step_dev || n_slabs < 1 || n_slabs > MLP_MAX_GRID) return MSGM_E_BADARG;
+  const int64_t n_params = msgm_mlp_num_params(d, premodule);
+  hipLaunchKernelGGL(k_slab_reduce<true>, dim3((unsigned)((n_params + 1 + 63) / 64)), dim3(256), 0, S(stream),
+                     reinterpret_cast<const float*>(workspace), n_slabs, n_params + 1, grads, n_params, loss_sum, inv_batch,
+                     params, m, v, lr, beta1, beta2, eps, step_dev, rng_advance);
   return msgm_check_launch();
 }
 
@@ -664,5 +733,11 @@ int msgm_mlp_ssm_grad(const msgm_mlp_params_t* P, const float* y, const float* t
   if (rc) return rc;
   return msgm_mlp_ssm_reduce(P->d, P->premodule, workspace, n_slabs, inv_batch, grads, loss_sum, stream);
 }
+
+#ifdef MLP_STAMPS
+int msgm_debug_stamps(unsigned long long* out_host) {
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 12) == hipSuccess ? 0 : -4;
+}
+#endif
 
 }  // extern "C"

@@ -54,6 +54,33 @@ __global__ void k_perturb_vp(const float* __restrict__ x0, float* __restrict__ y
   }
 }
 
+// K1 + probe in one launch for the training step: y,t as k_perturb_vp, v = Rademacher
+// (SDEs.py:514-515,637-638), and (thread 0) the optimizer step counter tick.
+__global__ void k_ssm_prep(const float* __restrict__ x0, float* __restrict__ y, float* __restrict__ t_out,
+                           float* __restrict__ v, int64_t B, int64_t d, float b0, float b1, float T, float t_eps,
+                           const uint64_t* __restrict__ rng, int64_t* step_ctr) {
+  const int64_t n = B * d;
+  const int64_t nq = (n + 3) >> 2;
+  if (step_ctr && blockIdx.x == 0 && threadIdx.x == 0) step_ctr[0] += 1;
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e0 = q << 2;
+    const f32x4 ez = philox_normal4(rng, 0, RNG_STREAM_EPS, q);
+    const f32x4 uv = philox_uniform4(rng, 0, RNG_STREAM_V, q);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t e = e0 + k;
+      if (e >= n) break;
+      const int64_t b = e / d;
+      float t = philox_uniform1(rng, 0, RNG_STREAM_T, (uint64_t)b) * T;
+      const float m = (t <= t_eps) ? 1.0f : 0.0f;
+      t = m * t_eps + (1.0f - m) * t;
+      y[e] = ez[k] * sqrtf(vp_var(b0, b1, t)) + vp_mean_weight(b0, b1, t) * x0[e];
+      v[e] = (uv[k] >= 0.5f) ? 1.0f : -1.0f;
+      if (e - b * d == 0) t_out[b] = t;
+    }
+  }
+}
+
 // bit-exact stop index                                        SDEs.py:89-101
 __global__ void k_forward_step_index(const float* __restrict__ t, int32_t* __restrict__ k, int64_t B, int32_t nsf, float T) {
   for (int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; b < B; b += (int64_t)gridDim.x * blockDim.x) {
@@ -424,6 +451,15 @@ int msgm_perturb_vp(const float* x0, float* y, float* t_out, float* eps_out, int
   if (sde->kind != MSGM_SDE_SGM) return MSGM_E_UNSUPPORTED;   // MSGM has no closed form (SDEs.py:434-436)
   hipLaunchKernelGGL(k_perturb_vp, dim3(grid_for((B * d + 3) / 4, 256)), dim3(256), 0, S(stream), x0, y, t_out, eps_out,
                      B, d, sde->beta_min, sde->beta_max, sde->T, sde->t_epsilon, u, eps, rng);
+  return msgm_check_launch();
+}
+
+int msgm_ssm_prep(const float* x0, float* y, float* t_out, float* v, int64_t B, int64_t d, const msgm_sde_t* sde,
+                  const uint64_t* rng, int64_t* step_ctr, msgm_stream_t stream) {
+  if (!x0 || !y || !t_out || !v || !sde || !rng || B <= 0 || d <= 0) return MSGM_E_BADARG;
+  if (sde->kind != MSGM_SDE_SGM) return MSGM_E_UNSUPPORTED;
+  hipLaunchKernelGGL(k_ssm_prep, dim3(grid_for((B * d + 3) / 4, 256)), dim3(256), 0, S(stream), x0, y, t_out, v, B, d,
+                     sde->beta_min, sde->beta_max, sde->T, sde->t_epsilon, rng, step_ctr);
   return msgm_check_launch();
 }
 

@@ -49,25 +49,31 @@ class MLPScoreTrainer:
         self.graph = None
         self.use_graph = use_graph and world == 1
 
-    def _grad(self):
-        lib = ops.lib()
-        s = ops.stream()
-        ops.check(lib.msgm_perturb_vp(self.x.data_ptr(), self.y.data_ptr(), self.t.data_ptr(), None, self.B, self.d,
-                                      self.st, None, None, self.rng.ptr(), s), "msgm_perturb_vp")
-        ops.check(lib.msgm_rademacher(self.vp.data_ptr(), self.vp.numel(), None, self.rng.ptr(), s), "msgm_rademacher")
-        ops.mlp_ssm_grad(self.P, self.y, self.t, self.vp, self.st, self.inv_batch, self.gflat, self.ws, loss_sum=self.loss)
-        self.rng.advance(1)
-
-    def _update(self):
-        ops.counter_inc(self.step_dev)
-        ops.adam_step(self.flat, self.gflat, self.m, self.v, step=0, lr=self.lr, step_dev=self.step_dev)
-
     def _body(self):
-        self._grad()
-        if self.world > 1:
+        """3 launches on one GPU: prep (K1 + probe + step tick) -> fused SSM kernel ->
+        slab reduction fused with Adam (+ Philox advance).  With N>1 ranks the
+        reduction and Adam are split around the RCCL all-reduce of the flat bucket."""
+        import ctypes as C
+        lib, s = ops.lib(), ops.stream()
+        ops.check(lib.msgm_ssm_prep(self.x.data_ptr(), self.y.data_ptr(), self.t.data_ptr(), self.vp.data_ptr(), self.B,
+                                    self.d, self.st, self.rng.ptr(), self.step_dev.data_ptr(), s), "msgm_ssm_prep")
+        nsl = C.c_int32(0)
+        ops.check(lib.msgm_mlp_ssm_partial(self.P, self.y.data_ptr(), self.t.data_ptr(), self.vp.data_ptr(), self.B,
+                                           self.st, self.inv_batch, None, self.ws.data_ptr(), self.ws.numel() * 4,
+                                           C.byref(nsl), s), "msgm_mlp_ssm_partial")
+        pre = int(self.net.pre is not None)
+        if self.world == 1:
+            ops.check(lib.msgm_mlp_ssm_reduce_adam(self.d, pre, self.ws.data_ptr(), nsl.value, self.inv_batch,
+                                                   self.gflat.data_ptr(), self.loss.data_ptr(), self.flat.data_ptr(),
+                                                   self.m.data_ptr(), self.v.data_ptr(), self.lr, 0.9, 0.999, 1e-8,
+                                                   self.step_dev.data_ptr(), self.rng.ptr(), s), "msgm_mlp_ssm_reduce_adam")
+        else:
+            ops.check(lib.msgm_mlp_ssm_reduce(self.d, pre, self.ws.data_ptr(), nsl.value, self.inv_batch,
+                                              self.gflat.data_ptr(), self.loss.data_ptr(), s), "msgm_mlp_ssm_reduce")
             parallel.allreduce_sum_(self.gflat)   # grads already carry 1/global_batch
             parallel.allreduce_sum_(self.loss)
-        self._update()
+            ops.adam_step(self.flat, self.gflat, self.m, self.v, step=0, lr=self.lr, step_dev=self.step_dev)
+            self.rng.advance(1)
 
     def capture(self):
         s = torch.cuda.Stream(device=self.dev)

@@ -208,3 +208,43 @@ def test_graphed_sampler_equals_eager():
     assert rel_l2(a.cpu(), b) <= 1e-6
     c = gs.run(x0).clone()                                    # offset advanced inside the graph: fresh noise
     assert not torch.equal(a, c) and torch.isfinite(c).all()
+
+
+def test_trainer_fused_launches_match_separate_kernels():
+    """prep (K1+probe+tick) and reduce+Adam fused launches == the separate C-ABI kernels, two steps, ragged batch."""
+    from sdeflow_light_amd.NN import MLP
+    from sdeflow_light_amd.train import MLPScoreTrainer
+    from sdeflow_light_amd.data import gaussian_mixture_2d
+    from sdeflow_light_amd import ops, _lib
+    torch.manual_seed(0)
+    B = 1003
+    gen = make_gen("sgm", MLP(2))
+    tr = MLPScoreTrainer(gen, B, lr=1e-3, use_graph=False, seed=5)
+    x = gaussian_mixture_2d(B, device=DEV)
+    tr.set_data(x)
+    p = tr.flat.clone()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    rng = _lib.PhiloxState(5 * 1000003 + 17, DEV)
+    st = gen.base_sde.struct()
+    ws = ops.mlp_ssm_workspace(2, False, DEV)
+    shapes = [(128, 3), (128,), (128, 128), (128,), (128, 128), (128,), (2, 128), (2,)]
+    for step in (1, 2):
+        off, views = 0, []
+        for s in shapes:
+            k = 1
+            for q in s:
+                k *= q
+            views.append(p[off:off + k].view(s)); off += k
+        P = ops.mlp_params(*views, premodule=False)
+        y, t = ops.perturb_vp(x, st, rng=rng)
+        vv = ops.rademacher((B, 2), DEV, rng=rng)
+        g = torch.empty_like(p)
+        lsum = torch.empty(1, device=DEV)
+        ops.mlp_ssm_grad(P, y, t, vv, st, 1.0 / B, g, ws, loss_sum=lsum)
+        ops.adam_step(p, g, m, v, step=step, lr=1e-3)
+        rng.advance(1)
+        loss = tr.step()
+        assert float(loss) == pytest.approx(float(lsum), rel=1e-6)
+        assert rel_l2(tr.gflat.cpu(), g.cpu()) <= 1e-6
+        assert rel_l2(tr.flat.cpu(), p.cpu()) <= 1e-7
+    assert int(tr.step_dev) == 2
