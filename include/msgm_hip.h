@@ -215,6 +215,60 @@ int msgm_mlp_ssm_partial(const msgm_mlp_params_t* P, const float* y, const float
 int msgm_mlp_ssm_reduce(int32_t d, int32_t premodule, const void* workspace, int32_t n_slabs,
                         float inv_batch, float* grads, float* loss_sum, msgm_stream_t stream);
 
+/* ---- K6/K11: convolutions as implicit GEMMs (U-Net score nets) ------------- */
+/* Activations are channels-last [N][H][W][C] (1-D: H = 1).  The forward-mode
+ * tangent rides as the second half of the batch (rows n >= n_bias get no bias).
+ * One geometry struct describes forward, dgrad and wgrad of Conv1d/Conv2d
+ * (NNUnet1D.py:17-20,84; model/unet.py:58,92,143,157,356) and ConvTranspose1d
+ * (NNUnet1D.py:98):
+ *   mode 0: input index i = o*stride + k - pad        (strided convolution)
+ *   mode 1: i = (o + pad - k)/stride when divisible   (transposed convolution;
+ *           also the dgrad of mode 0, and vice versa)
+ *   ups 1 : the stored input is nearest-upsampled 2x on the fly (Upsample,
+ *           model/unet.py:60-73). */
+typedef struct {
+  int32_t N, Hi, Wi, Ho, Wo;
+  int32_t KH, KW, strideH, padH, strideW, padW;   /* 1-D: H = 1, KH = 1, strideH = 1, padH = 0 */
+  int32_t mode, ups;
+} msgm_conv_geom_t;
+
+/* out[m][co] (+)= sum_tap sum_c in[src(m,tap)][c] Wp[tap][co][c] (+ bias[co] + samp_bias[n][co] for n < n_bias).
+ * Up to two inputs are concatenated along channels without materialising the
+ * concat (src1 may be NULL).  Wp is the packed weight [taps][CoutP][Ktot]
+ * (msgm_pack_weight; CoutP multiple of 16, each source's channels padded to 16).
+ * A Linear layer is the 1x1 case with H = W = 1. */
+int msgm_conv_forward(const msgm_conv_geom_t* geom, const float* src0, int32_t C0, const float* src1, int32_t C1,
+                      const float* Wp, int32_t Cout, int32_t CoutP, int32_t Ktot, const float* bias,
+                      const float* samp_bias, int32_t n_bias, float* out, int32_t accumulate,
+                      msgm_stream_t stream);
+
+/* dWp[tap][co][koff + c] += sum_m gy[m][co] in[src(m,tap)][c] (float atomics across
+ * position chunks; zero dWp first).  One call per concatenated source. */
+int msgm_conv_wgrad(const msgm_conv_geom_t* geom, const float* gy, const float* src, int32_t C, int32_t koff,
+                    float* dWp, int32_t Cout, int32_t CoutP, int32_t Ktot, msgm_stream_t stream);
+
+/* Wp[t][r][kp_off + c] = W[r*sr + (col_off + c)*sc + t*st] for r < rows, c < ncols
+ * (strides in elements: any of the PyTorch layouts (Cout,Cin,k), (Cin,Cout,k) and
+ * their transposes for dgrad); msgm_unpack_weight is the inverse for gradients. */
+int msgm_pack_weight(const float* W, float* Wp, int32_t rows, int32_t ncols, int32_t col_off, int32_t taps,
+                     int64_t sr, int64_t sc, int64_t st, int32_t rowsP, int32_t Ktot, int32_t kp_off,
+                     msgm_stream_t stream);
+int msgm_unpack_weight(float* dW, const float* dWp, int32_t rows, int32_t ncols, int32_t col_off, int32_t taps,
+                       int64_t sr, int64_t sc, int64_t st, int32_t rowsP, int32_t Ktot, int32_t kp_off,
+                       int32_t accumulate, msgm_stream_t stream);
+
+/* Dual-number activations on a (primal | tangent) stacked tensor of 2*half
+ * elements: act 0 = exact-erf GELU (NNUnet1D.py:18), 1 = SiLU (nn_utils.py:44-46).
+ * forward: hP = f(zP), hT = f'(zP) zT (dual = 0: primal only, `half` elements).
+ * backward (in place on g): gP <- gP f' + gT f'' zT, gT <- gT f'. */
+int msgm_act_dual_forward(int32_t act, const float* z, float* h, int64_t half, int32_t dual, msgm_stream_t stream);
+int msgm_act_dual_backward(int32_t act, const float* z, float* g, int64_t half, msgm_stream_t stream);
+
+/* S[n][c] = sum_pos x[n][pos][c]; out[n][c] = x[n][pos][c]; x[n][pos][c] += sgn*E[n][c]. */
+int msgm_colsum(const float* x, float* S, int32_t N, int32_t P, int32_t C, msgm_stream_t stream);
+int msgm_gather_row(const float* x, float* out, int32_t N, int32_t P, int32_t C, int32_t pos, msgm_stream_t stream);
+int msgm_add_row(float* x, const float* E, int32_t N, int32_t P, int32_t C, int32_t pos, float sgn, msgm_stream_t stream);
+
 /* Slab reduction fused with the Adam update of msgm_adam_step (single-GPU step:
  * nothing sits between them) and, when rng_advance != NULL, rng_advance[1] += 1.
  * grads may be NULL. */

@@ -30,6 +30,10 @@ class SdeT(C.Structure):
                 ("t_epsilon", C.c_float), ("G", C.c_void_p), ("L_G", C.c_void_p)]
 
 
+class ConvGeomT(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("N", "Hi", "Wi", "Ho", "Wo", "KH", "KW", "strideH", "padH", "strideW", "padW", "mode", "ups")]
+
+
 class MlpParamsT(C.Structure):
     _fields_ = [("W1", C.c_void_p), ("b1", C.c_void_p), ("W2", C.c_void_p), ("b2", C.c_void_p),
                 ("W3", C.c_void_p), ("b3", C.c_void_p), ("W4", C.c_void_p), ("b4", C.c_void_p),
@@ -58,6 +62,15 @@ SIGNATURES = {
     "msgm_keep_rows": (C.c_int, [_P, _P, _P, _I32, _I64, _I64, _P]),
     "msgm_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _D, _D, _D, _D, _F, _I64, _P, _P]),
     "msgm_counter_inc": (C.c_int, [_P, _P]),
+    "msgm_conv_forward": (C.c_int, [C.POINTER(ConvGeomT), _P, _I32, _P, _I32, _P, _I32, _I32, _I32, _P, _P, _I32, _P, _I32, _P]),
+    "msgm_conv_wgrad": (C.c_int, [C.POINTER(ConvGeomT), _P, _P, _I32, _I32, _P, _I32, _I32, _I32, _P]),
+    "msgm_pack_weight": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I32, _I32, _I32, _P]),
+    "msgm_unpack_weight": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I32, _I32, _I32, _I32, _P]),
+    "msgm_act_dual_forward": (C.c_int, [_I32, _P, _P, _I64, _I32, _P]),
+    "msgm_act_dual_backward": (C.c_int, [_I32, _P, _P, _I64, _P]),
+    "msgm_colsum": (C.c_int, [_P, _P, _I32, _I32, _I32, _P]),
+    "msgm_gather_row": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P]),
+    "msgm_add_row": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _F, _P]),
     "msgm_mlp_forward": (C.c_int, [C.POINTER(MlpParamsT), _P, _P, _P, _I64, _P]),
     "msgm_mlp_em_step": (C.c_int, [C.POINTER(MlpParamsT), _P, _I64, C.POINTER(SdeT), _F, _F, _F, _P, _P, _U64, _P]),
     "msgm_mlp_ssm_workspace": (_SZ, [_I32, _I32]),

@@ -1,0 +1,537 @@
+// conv_kernels.hip — K6/K11: convolutions of the U-Net score nets as implicit
+// GEMMs on fp32 MFMA (v_mfma_f32_16x16x4_f32), channels-last activations.
+//
+//   forward / dgrad : out[m][co] = sum_tap sum_c  in[src(m,tap)][c] * Wp[tap][co][c]
+//   wgrad           : dWp[tap][co][c] += sum_m gy[m][co] * in[src(m,tap)][c]
+//
+// m runs over output positions (n, oh, ow) (1-D: H = 1).  src() is either the
+// gather of a strided convolution (mode 0: i = o*s + k - p) or of a transposed
+// one (mode 1: i = (o + p - k)/s when divisible) — which also is the dgrad of the
+// other.  Optional nearest-2x upsampling of the input is folded into the gather
+// (model/unet.py:60-73), and up to two inputs are concatenated along channels
+// without materialising the concat (NNUnet1D.py:175, model/unet.py:514).
+// Weight is the MFMA A operand, activations the B operand; a lane loads 4
+// consecutive channels (16 B) of one position, so the C/D layout writes 4
+// consecutive output channels of one position: everything stays channels-last.
+// No LDS: fragments stream L2 -> registers through a 3-deep software pipeline;
+// occupancy (<= 128 VGPR) hides the rest.  The forward-mode tangent is simply the
+// second half of the batch (n >= n_bias): convolutions are linear, only the bias
+// distinguishes the halves.
+#include "common.h"
+
+#define CONV_MAX_SRC 2
+
+__device__ __forceinline__ f32x4 mfma16c(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+struct ConvGeom {
+  int N, Hi, Wi, Ho, Wo;      // Hi/Wi: stored input size (before the optional 2x upsample)
+  int KH, KW, strideH, padH, strideW, padW;
+  int mode;                   // 0 conv gather, 1 transposed gather
+  int ups;                    // 1: input is nearest-upsampled 2x on the fly
+};
+
+struct ConvArgs {
+  ConvGeom g;
+  const float* src[CONV_MAX_SRC];
+  int C[CONV_MAX_SRC];        // channels of each source
+  int koff[CONV_MAX_SRC];     // offset of each source in the packed K axis (multiple of 16)
+  int nsrc;
+  const float* Wp;            // [taps][CoutP][Ktot], zero padded
+  int Cout, CoutP, Ktot;
+  const float* bias;          // [Cout] or null          (rows n < n_bias only)
+  const float* samp_bias;     // [n_bias][Cout] or null   (rows n < n_bias only)
+  int n_bias;
+  float* out;                 // [N][Ho][Wo][Cout]
+  int accumulate;             // out += result (fused residual / skip add)
+};
+
+// input coordinate of output coordinate o for tap k; returns false when the tap falls outside
+__device__ __forceinline__ bool src_coord(const ConvGeom& g, int o, int k, int in_size_up, int stride, int pad, int& i) {
+  int v;
+  if (g.mode == 0) {
+    v = o * stride + k - pad;
+  } else {
+    const int t = o + pad - k;
+    if (t < 0) return false;
+    if (stride == 2) { if (t & 1) return false; v = t >> 1; }
+    else if (stride == 1) v = t;
+    else { if (t % stride) return false; v = t / stride; }
+  }
+  if (v < 0 || v >= in_size_up) return false;
+  i = g.ups ? (v >> 1) : v;
+  return true;
+}
+
+template <int MT, int NT>
+__global__ void __launch_bounds__(256) k_conv_gemm(ConvArgs A) {
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, il = lane & 15, q = lane >> 4;
+  const ConvGeom g = A.g;
+  const int HoWo = g.Ho * g.Wo;
+  const int Mtot = g.N * HoWo;
+  const int m0 = (blockIdx.x * 4 + w) * (NT * 16);
+  if (m0 >= Mtot) return;                       // no barriers in this kernel
+  const int co0 = blockIdx.y * (MT * 16);
+  const int Hup = g.ups ? 2 * g.Hi : g.Hi, Wup = g.ups ? 2 * g.Wi : g.Wi;
+
+  int pn[NT], poh[NT], pow_[NT];
+  bool pin[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    int m = m0 + 16 * nt + il;
+    pin[nt] = m < Mtot;
+    if (!pin[nt]) m = Mtot - 1;
+    pn[nt] = m / HoWo;
+    const int r = m - pn[nt] * HoWo;
+    poh[nt] = r / g.Wo;
+    pow_[nt] = r - poh[nt] * g.Wo;
+  }
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0, 0, 0, 0};
+
+  const int taps = g.KH * g.KW;
+  int groups[CONV_MAX_SRC];
+  int per_tap = 0;
+#pragma unroll
+  for (int s = 0; s < CONV_MAX_SRC; ++s) { groups[s] = s < A.nsrc ? (A.C[s] + 15) >> 4 : 0; per_tap += groups[s]; }
+  const int total = taps * per_tap;
+
+  // ---- loader state (runs PF iterations ahead of the MFMAs) ----------------
+  int l_tap = 0, l_s = 0, l_g = 0;
+  const float* bptr[NT];
+  bool bval[NT];
+  auto setup = [&](int tap, int s) {
+    const int kh = tap / g.KW, kw = tap - kh * g.KW;
+    const int C = A.C[s];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      int ih = 0, iw = 0;
+      const bool ok = pin[nt] && src_coord(g, poh[nt], kh, Hup, g.strideH, g.padH, ih) && src_coord(g, pow_[nt], kw, Wup, g.strideW, g.padW, iw);
+      bval[nt] = ok;
+      bptr[nt] = A.src[s] + ((size_t)(pn[nt] * g.Hi + ih) * g.Wi + iw) * C;
+    }
+  };
+  setup(0, 0);
+  auto load = [&](f32x4 (&fa)[MT], f32x4 (&fb)[NT]) {
+    if (l_tap < taps) {
+      const int C = A.C[l_s];
+      const int cb = 16 * l_g + 4 * q;
+      const float* wp = A.Wp + ((size_t)(l_tap * A.CoutP + co0 + il) * A.Ktot + A.koff[l_s] + cb);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) fa[mt] = *reinterpret_cast<const f32x4*>(wp + (size_t)16 * mt * A.Ktot);
+      if ((C & 3) == 0) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          fb[nt] = (bval[nt] && cb < C) ? *reinterpret_cast<const f32x4*>(bptr[nt] + cb) : f32x4{0, 0, 0, 0};
+      } else {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          f32x4 v = {0, 0, 0, 0};
+          if (bval[nt]) {
+            if (cb + 0 < C) v[0] = bptr[nt][cb + 0];
+            if (cb + 1 < C) v[1] = bptr[nt][cb + 1];
+            if (cb + 2 < C) v[2] = bptr[nt][cb + 2];
+            if (cb + 3 < C) v[3] = bptr[nt][cb + 3];
+          }
+          fb[nt] = v;
+        }
+      }
+      if (++l_g == groups[l_s]) {
+        l_g = 0;
+        if (++l_s == A.nsrc) { l_s = 0; ++l_tap; }
+        if (l_tap < taps) setup(l_tap, l_s);
+      }
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) fa[mt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) fb[nt] = f32x4{0, 0, 0, 0};
+    }
+  };
+
+  f32x4 a0[MT], b0[NT], a1[MT], b1[NT], a2[MT], b2[NT];
+  load(a0, b0);
+  load(a1, b1);
+  for (int it = 0; it < total; ++it) {
+    load(a2, b2);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16c(a0[mt][r], b0[nt][r], acc[mt][nt]);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { a0[mt] = a1[mt]; a1[mt] = a2[mt]; }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { b0[nt] = b1[nt]; b1[nt] = b2[nt]; }
+  }
+
+  // ---- epilogue: lane (position il of tile nt, q) holds channels co0+16mt+4q+r
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    if (!pin[nt]) continue;
+    const int m = m0 + 16 * nt + il;
+    const bool primal = pn[nt] < A.n_bias;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int co = co0 + 16 * mt + 4 * q;
+      if (co >= A.Cout) continue;
+      f32x4 v = acc[mt][nt];
+      float* op = A.out + (size_t)m * A.Cout + co;
+      const bool full = (co + 3 < A.Cout) && ((A.Cout & 3) == 0);
+      if (primal && A.bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (co + r < A.Cout) v[r] += A.bias[co + r];
+      }
+      if (primal && A.samp_bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (co + r < A.Cout) v[r] += A.samp_bias[(size_t)pn[nt] * A.Cout + co + r];
+      }
+      if (full) {
+        if (A.accumulate) v += *reinterpret_cast<const f32x4*>(op);
+        *reinterpret_cast<f32x4*>(op) = v;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (co + r < A.Cout) op[r] = A.accumulate ? op[r] + v[r] : v[r];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ wgrad
+struct WgradArgs {
+  ConvGeom g;
+  const float* gy;            // [N][Ho][Wo][Cout]
+  const float* src;           // one source [N][Hi][Wi][C]
+  int C, koff;
+  float* dWp;                 // [taps][CoutP][Ktot], accumulated with float atomics
+  int Cout, CoutP, Ktot;
+  int chunk;                  // output positions per workgroup
+};
+
+// One workgroup = one (position chunk, tap, co block of 16*MT, c block of 16*KT).
+// Reduction over positions: A lane (co, q) <- gy[m+q][co], B lane (c, q) <- in[src(m+q)][c].
+template <int MT, int KT>
+__global__ void __launch_bounds__(256) k_conv_wgrad(WgradArgs A) {
+  __shared__ float red[4][MT * KT * 256];
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, il = lane & 15, q = lane >> 4;
+  const ConvGeom g = A.g;
+  const int HoWo = g.Ho * g.Wo;
+  const int Mtot = g.N * HoWo;
+  const int cblocks = (A.C + 16 * KT - 1) / (16 * KT);
+  const int coblk = blockIdx.y / cblocks, cblk = blockIdx.y - coblk * cblocks;
+  const int co0 = coblk * 16 * MT, c0 = cblk * 16 * KT;
+  const int tap = blockIdx.z;
+  const int kh = tap / g.KW, kw = tap - kh * g.KW;
+  const int Hup = g.ups ? 2 * g.Hi : g.Hi, Wup = g.ups ? 2 * g.Wi : g.Wi;
+  const int mbeg = blockIdx.x * A.chunk;
+  const int mend = min(mbeg + A.chunk, Mtot);
+
+  f32x4 acc[MT][KT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) acc[mt][kt] = f32x4{0, 0, 0, 0};
+
+  // the four waves interleave groups of 4 positions
+  for (int mg = mbeg + 4 * w; mg < mend; mg += 16) {     // wave-uniform trip count
+    const int m = mg + q;
+    const bool pin = m < mend;
+    float a[MT], b[KT];
+    int ih = 0, iw = 0;
+    bool ok = false;
+    int n = 0;
+    if (pin) {
+      n = m / HoWo;
+      const int r = m - n * HoWo;
+      const int oh = r / g.Wo, ow = r - oh * g.Wo;
+      ok = src_coord(g, oh, kh, Hup, g.strideH, g.padH, ih) && src_coord(g, ow, kw, Wup, g.strideW, g.padW, iw);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int co = co0 + 16 * mt + il;
+      a[mt] = (pin && co < A.Cout) ? A.gy[(size_t)m * A.Cout + co] : 0.f;
+    }
+    const float* sp = A.src + ((size_t)(n * g.Hi + ih) * g.Wi + iw) * A.C;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      const int c = c0 + 16 * kt + il;
+      b[kt] = (ok && c < A.C) ? sp[c] : 0.f;
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) acc[mt][kt] = mfma16c(a[mt], b[kt], acc[mt][kt]);
+  }
+  // cross-wave sum, then one atomic per element per workgroup
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[w][((mt * KT + kt) * 4 + r) * 64 + lane] = acc[mt][kt][r];
+  __syncthreads();
+  if (w == 0) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int idx = ((mt * KT + kt) * 4 + r) * 64 + lane;
+          const float s = (red[0][idx] + red[1][idx]) + (red[2][idx] + red[3][idx]);
+          const int co = co0 + 16 * mt + 4 * q + r, c = c0 + 16 * kt + il;
+          if (co < A.Cout && c < A.C) atomicAdd(A.dWp + ((size_t)(tap * A.CoutP + co) * A.Ktot + A.koff + c), s);
+        }
+  }
+}
+
+// ------------------------------------------------------------------ weight (un)packing
+// Wp[t][r][kp_off + c] = W[r*sr + (col_off + c)*sc + t*st]   (r < rows, c < ncols); zero elsewhere is
+// provided by a memset of Wp before packing.
+__global__ void k_pack_w(const float* __restrict__ W, float* __restrict__ Wp, int rows, int ncols, int col_off, int taps,
+                         int64_t sr, int64_t sc, int64_t st, int rowsP, int Ktot, int kp_off) {
+  const int64_t tot = (int64_t)taps * rows * ncols;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < tot; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % ncols);
+    const int r = (int)((e / ncols) % rows);
+    const int t = (int)(e / ((int64_t)ncols * rows));
+    Wp[((int64_t)t * rowsP + r) * Ktot + kp_off + c] = W[r * sr + (col_off + c) * sc + t * st];
+  }
+}
+// dW[r*sr + (col_off+c)*sc + t*st] (+)= dWp[t][r][kp_off + c]
+__global__ void k_unpack_w(float* __restrict__ dW, const float* __restrict__ dWp, int rows, int ncols, int col_off,
+                           int taps, int64_t sr, int64_t sc, int64_t st, int rowsP, int Ktot, int kp_off, int accumulate) {
+  const int64_t tot = (int64_t)taps * rows * ncols;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < tot; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % ncols);
+    const int r = (int)((e / ncols) % rows);
+    const int t = (int)(e / ((int64_t)ncols * rows));
+    const float v = dWp[((int64_t)t * rowsP + r) * Ktot + kp_off + c];
+    float* d = dW + r * sr + (col_off + c) * sc + t * st;
+    *d = accumulate ? *d + v : v;
+  }
+}
+
+// ------------------------------------------------------------------ pointwise dual kernels
+// GELU (exact erf form, nn.GELU default: NNUnet1D.py:18,20) on a (primal | tangent) stacked
+// batch: hP = g(zP), hT = g'(zP) zT.  half = elements of one half.
+__device__ __forceinline__ void gelu012(float z, float& g0, float& g1, float& g2) {
+  const float Phi = 0.5f * (1.0f + erff(z * 0.70710678118654752f));
+  const float phi = 0.3989422804014327f * __expf(-0.5f * z * z);
+  g0 = z * Phi;
+  g1 = Phi + z * phi;
+  g2 = phi * (2.0f - z * z);
+}
+__device__ __forceinline__ void silu012(float z, float& s0, float& s1, float& s2) {
+  const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-z));
+  const float om = 1.0f - sg;
+  s0 = z * sg;
+  s1 = sg * (1.0f + z * om);
+  s2 = sg * om * (2.0f + z * (1.0f - 2.0f * sg));
+}
+
+template <int ACT>   // 0 GELU, 1 SiLU
+__global__ void k_act_dual_fwd(const float* __restrict__ z, float* __restrict__ h, int64_t half, int dual) {
+  const int64_t nq = half >> 2;   // half is a multiple of 4 (channels-last rows of >= 4... checked on host)
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nq; i += (int64_t)gridDim.x * blockDim.x) {
+    const f32x4 zp = *reinterpret_cast<const f32x4*>(z + 4 * i);
+    f32x4 zt = {0, 0, 0, 0};
+    if (dual) zt = *reinterpret_cast<const f32x4*>(z + half + 4 * i);
+    f32x4 hp, ht;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float a0, a1, a2;
+      if (ACT == 0) gelu012(zp[k], a0, a1, a2); else silu012(zp[k], a0, a1, a2);
+      hp[k] = a0; ht[k] = a1 * zt[k];
+    }
+    *reinterpret_cast<f32x4*>(h + 4 * i) = hp;
+    if (dual) *reinterpret_cast<f32x4*>(h + half + 4 * i) = ht;
+  }
+}
+// cotangents (gP,gT) of (hP,hT) -> cotangents of (zP,zT), written over g
+template <int ACT>
+__global__ void k_act_dual_bwd(const float* __restrict__ z, float* __restrict__ g, int64_t half) {
+  const int64_t nq = half >> 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nq; i += (int64_t)gridDim.x * blockDim.x) {
+    const f32x4 zp = *reinterpret_cast<const f32x4*>(z + 4 * i), zt = *reinterpret_cast<const f32x4*>(z + half + 4 * i);
+    f32x4 gp = *reinterpret_cast<const f32x4*>(g + 4 * i), gt = *reinterpret_cast<const f32x4*>(g + half + 4 * i);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float a0, a1, a2;
+      if (ACT == 0) gelu012(zp[k], a0, a1, a2); else silu012(zp[k], a0, a1, a2);
+      const float np = gp[k] * a1 + gt[k] * (a2 * zt[k]);
+      gt[k] = gt[k] * a1;
+      gp[k] = np;
+    }
+    *reinterpret_cast<f32x4*>(g + 4 * i) = gp;
+    *reinterpret_cast<f32x4*>(g + half + 4 * i) = gt;
+  }
+}
+
+// S[n][c] = sum over positions of x[n][pos][c]  (bias / embedding gradients).  One block per n.
+__global__ void __launch_bounds__(256) k_colsum(const float* __restrict__ x, float* __restrict__ S, int P, int C) {
+  __shared__ float red[256];
+  const int n = blockIdx.x;
+  const float* xn = x + (size_t)n * P * C;
+  for (int cb = 0; cb < C; cb += 256) {
+    const int lanes_c = min(C - cb, 256);
+    const int rows = 256 / lanes_c;                  // position lanes per channel
+    const int c = threadIdx.x % lanes_c, pr = threadIdx.x / lanes_c;
+    float s = 0.f;
+    if (pr < rows)
+      for (int p = pr; p < P; p += rows) s += xn[(size_t)p * C + cb + c];
+    red[threadIdx.x] = (pr < rows) ? s : 0.f;
+    __syncthreads();
+    if (pr == 0) {
+      float t = 0.f;
+      for (int r = 0; r < rows; ++r) t += red[r * lanes_c + c];
+      S[(size_t)n * C + cb + c] = t;
+    }
+    __syncthreads();
+  }
+}
+
+// x[n][pos][c] += sgn * E[n][c] for one position per sample (border terms of the broadcast-embedding
+// channels, NNUnet1D.py:156: zero padding makes taps 0 / 2 miss at l = 0 / L-1).
+__global__ void k_add_row(float* __restrict__ x, const float* __restrict__ E, int N, int P, int C, int pos, float sgn) {
+  const int64_t tot = (int64_t)N * C;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < tot; e += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(e / C), c = (int)(e - (int64_t)n * C);
+    x[((size_t)n * P + pos) * C + c] += sgn * E[e];
+  }
+}
+
+__global__ void k_gather_row(const float* __restrict__ x, float* __restrict__ out, int N, int P, int C, int pos) {
+  const int64_t tot = (int64_t)N * C;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < tot; e += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(e / C), c = (int)(e - (int64_t)n * C);
+    out[e] = x[((size_t)n * P + pos) * C + c];
+  }
+}
+
+// ============================================================ C ABI
+static inline hipStream_t S(msgm_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+static int check_geom(const msgm_conv_geom_t* g) {
+  if (!g || g->N <= 0 || g->Hi <= 0 || g->Wi <= 0 || g->Ho <= 0 || g->Wo <= 0 || g->KH <= 0 || g->KW <= 0 ||
+      g->strideH <= 0 || g->padH < 0 || g->strideW <= 0 || g->padW < 0 || (g->mode != 0 && g->mode != 1) ||
+      (g->ups != 0 && g->ups != 1))
+    return MSGM_E_BADARG;
+  if ((int64_t)g->N * g->Ho * g->Wo >= (1ll << 31) || (int64_t)g->N * g->Hi * g->Wi >= (1ll << 31)) return MSGM_E_UNSUPPORTED;
+  return MSGM_OK;
+}
+static ConvGeom to_geom(const msgm_conv_geom_t* g) {
+  return ConvGeom{g->N, g->Hi, g->Wi, g->Ho, g->Wo, g->KH, g->KW, g->strideH, g->padH, g->strideW, g->padW, g->mode, g->ups};
+}
+
+extern "C" {
+
+int msgm_conv_forward(const msgm_conv_geom_t* geom, const float* src0, int32_t C0, const float* src1, int32_t C1,
+                      const float* Wp, int32_t Cout, int32_t CoutP, int32_t Ktot, const float* bias,
+                      const float* samp_bias, int32_t n_bias, float* out, int32_t accumulate, msgm_stream_t stream) {
+  int rc = check_geom(geom);
+  if (rc) return rc;
+  if (!src0 || !Wp || !out || C0 <= 0 || Cout <= 0 || (src1 && C1 <= 0)) return MSGM_E_BADARG;
+  const int k0 = ((C0 + 15) / 16) * 16, k1 = src1 ? ((C1 + 15) / 16) * 16 : 0;
+  if (Ktot != k0 + k1 || CoutP % 16 || CoutP < Cout) return MSGM_E_BADARG;
+  ConvArgs A{};
+  A.g = to_geom(geom);
+  A.src[0] = src0; A.C[0] = C0; A.koff[0] = 0;
+  A.src[1] = src1; A.C[1] = src1 ? C1 : 0; A.koff[1] = k0;
+  A.nsrc = src1 ? 2 : 1;
+  A.Wp = Wp; A.Cout = Cout; A.CoutP = CoutP; A.Ktot = Ktot;
+  A.bias = bias; A.samp_bias = samp_bias; A.n_bias = n_bias; A.out = out; A.accumulate = accumulate;
+  const int64_t Mtot = (int64_t)geom->N * geom->Ho * geom->Wo;
+  if (CoutP >= 64 && CoutP % 64 == 0) {
+    dim3 grid((unsigned)((Mtot + 4 * 32 - 1) / (4 * 32)), (unsigned)(CoutP / 64));
+    hipLaunchKernelGGL((k_conv_gemm<4, 2>), grid, dim3(256), 0, S(stream), A);
+  } else if (CoutP % 32 == 0) {
+    dim3 grid((unsigned)((Mtot + 4 * 64 - 1) / (4 * 64)), (unsigned)(CoutP / 32));
+    hipLaunchKernelGGL((k_conv_gemm<2, 4>), grid, dim3(256), 0, S(stream), A);
+  } else {
+    dim3 grid((unsigned)((Mtot + 4 * 64 - 1) / (4 * 64)), (unsigned)(CoutP / 16));
+    hipLaunchKernelGGL((k_conv_gemm<1, 4>), grid, dim3(256), 0, S(stream), A);
+  }
+  return msgm_check_launch();
+}
+
+int msgm_conv_wgrad(const msgm_conv_geom_t* geom, const float* gy, const float* src, int32_t C, int32_t koff,
+                    float* dWp, int32_t Cout, int32_t CoutP, int32_t Ktot, msgm_stream_t stream) {
+  int rc = check_geom(geom);
+  if (rc) return rc;
+  if (!gy || !src || !dWp || C <= 0 || Cout <= 0 || koff < 0 || koff + C > Ktot) return MSGM_E_BADARG;
+  WgradArgs A{to_geom(geom), gy, src, C, koff, dWp, Cout, CoutP, Ktot, 0};
+  const int64_t Mtot = (int64_t)geom->N * geom->Ho * geom->Wo;
+  const int taps = geom->KH * geom->KW;
+  const int coblocks = (Cout + 31) / 32, cblocks = (C + 63) / 64;
+  // aim at ~2048 workgroups overall, at least 256 positions each
+  int64_t nchunks = 2048 / (int64_t)(coblocks * cblocks * taps);
+  if (nchunks < 1) nchunks = 1;
+  int64_t chunk = (Mtot + nchunks - 1) / nchunks;
+  if (chunk < 256) chunk = 256;
+  chunk = ((chunk + 15) / 16) * 16;
+  nchunks = (Mtot + chunk - 1) / chunk;
+  A.chunk = (int)chunk;
+  dim3 grid((unsigned)nchunks, (unsigned)(coblocks * cblocks), (unsigned)taps);
+  hipLaunchKernelGGL((k_conv_wgrad<2, 4>), grid, dim3(256), 0, S(stream), A);
+  return msgm_check_launch();
+}
+
+int msgm_pack_weight(const float* W, float* Wp, int32_t rows, int32_t ncols, int32_t col_off, int32_t taps, int64_t sr,
+                     int64_t sc, int64_t st, int32_t rowsP, int32_t Ktot, int32_t kp_off, msgm_stream_t stream) {
+  if (!W || !Wp || rows <= 0 || ncols <= 0 || taps <= 0 || rowsP < rows || kp_off + ncols > Ktot) return MSGM_E_BADARG;
+  hipLaunchKernelGGL(k_pack_w, dim3(grid_for((int64_t)rows * ncols * taps, 256)), dim3(256), 0, S(stream), W, Wp, rows,
+                     ncols, col_off, taps, sr, sc, st, rowsP, Ktot, kp_off);
+  return msgm_check_launch();
+}
+
+int msgm_unpack_weight(float* dW, const float* dWp, int32_t rows, int32_t ncols, int32_t col_off, int32_t taps, int64_t sr,
+                       int64_t sc, int64_t st, int32_t rowsP, int32_t Ktot, int32_t kp_off, int32_t accumulate,
+                       msgm_stream_t stream) {
+  if (!dW || !dWp || rows <= 0 || ncols <= 0 || taps <= 0 || rowsP < rows || kp_off + ncols > Ktot) return MSGM_E_BADARG;
+  hipLaunchKernelGGL(k_unpack_w, dim3(grid_for((int64_t)rows * ncols * taps, 256)), dim3(256), 0, S(stream), dW, dWp, rows,
+                     ncols, col_off, taps, sr, sc, st, rowsP, Ktot, kp_off, accumulate);
+  return msgm_check_launch();
+}
+
+int msgm_act_dual_forward(int32_t act, const float* z, float* h, int64_t half, int32_t dual, msgm_stream_t stream) {
+  if (!z || !h || half <= 0 || (half & 3) || (act != 0 && act != 1)) return MSGM_E_BADARG;
+  const int grid = grid_for(half / 4, 256);
+  if (act == 0) hipLaunchKernelGGL(k_act_dual_fwd<0>, dim3(grid), dim3(256), 0, S(stream), z, h, half, dual);
+  else hipLaunchKernelGGL(k_act_dual_fwd<1>, dim3(grid), dim3(256), 0, S(stream), z, h, half, dual);
+  return msgm_check_launch();
+}
+
+int msgm_act_dual_backward(int32_t act, const float* z, float* g, int64_t half, msgm_stream_t stream) {
+  if (!z || !g || half <= 0 || (half & 3) || (act != 0 && act != 1)) return MSGM_E_BADARG;
+  const int grid = grid_for(half / 4, 256);
+  if (act == 0) hipLaunchKernelGGL(k_act_dual_bwd<0>, dim3(grid), dim3(256), 0, S(stream), z, g, half);
+  else hipLaunchKernelGGL(k_act_dual_bwd<1>, dim3(grid), dim3(256), 0, S(stream), z, g, half);
+  return msgm_check_launch();
+}
+
+int msgm_colsum(const float* x, float* Sout, int32_t N, int32_t P, int32_t C, msgm_stream_t stream) {
+  if (!x || !Sout || N <= 0 || P <= 0 || C <= 0) return MSGM_E_BADARG;
+  hipLaunchKernelGGL(k_colsum, dim3(N), dim3(256), 0, S(stream), x, Sout, P, C);
+  return msgm_check_launch();
+}
+
+int msgm_gather_row(const float* x, float* out, int32_t N, int32_t P, int32_t C, int32_t pos, msgm_stream_t stream) {
+  if (!x || !out || N <= 0 || P <= 0 || C <= 0 || pos < 0 || pos >= P) return MSGM_E_BADARG;
+  hipLaunchKernelGGL(k_gather_row, dim3(grid_for((int64_t)N * C, 256)), dim3(256), 0, S(stream), x, out, N, P, C, pos);
+  return msgm_check_launch();
+}
+
+int msgm_add_row(float* x, const float* E, int32_t N, int32_t P, int32_t C, int32_t pos, float sgn, msgm_stream_t stream) {
+  if (!x || !E || N <= 0 || P <= 0 || C <= 0 || pos < 0 || pos >= P) return MSGM_E_BADARG;
+  hipLaunchKernelGGL(k_add_row, dim3(grid_for((int64_t)N * C, 256)), dim3(256), 0, S(stream), x, E, N, P, C, pos, sgn);
+  return msgm_check_launch();
+}
+
+}  // extern "C"

@@ -199,3 +199,110 @@ def mlp_ssm_grad(P: L.MlpParamsT, y: torch.Tensor, t: torch.Tensor, v: torch.Ten
     check(lib().msgm_mlp_ssm_grad(P, ptr(f32(y)), ptr(f32(t)), ptr(f32(v)), B, sde, float(inv_batch), ptr(f32(grads)),
                                   ptr(loss_per), ptr(loss_sum), ptr(workspace), workspace.numel() * 4, stream()),
           "msgm_mlp_ssm_grad")
+
+
+# ---------------------------------------------------------------- convolutions (implicit GEMM)
+def conv_geom(N, Hi, Wi, Ho, Wo, KH, KW, stride, pad, mode=0, ups=0) -> L.ConvGeomT:
+    """stride / pad apply to W and — when the kernel has height (KH > 1) — to H; a 1-D conv (H = 1) never pads H."""
+    sH, pH = (int(stride), int(pad)) if KH > 1 else (int(stride) if Hi > 1 else 1, 0)
+    return L.ConvGeomT(int(N), int(Hi), int(Wi), int(Ho), int(Wo), int(KH), int(KW), sH, pH, int(stride), int(pad), int(mode),
+                       int(ups))
+
+
+def pad16(c: int) -> int:
+    return ((int(c) + 15) // 16) * 16
+
+
+def conv_forward(geom: L.ConvGeomT, src0: torch.Tensor, C0: int, Wp: torch.Tensor, Cout: int, out: torch.Tensor,
+                 src1: Optional[torch.Tensor] = None, C1: int = 0, bias: Optional[torch.Tensor] = None,
+                 samp_bias: Optional[torch.Tensor] = None, n_bias: int = 0, accumulate: bool = False,
+                 CoutP: Optional[int] = None) -> torch.Tensor:
+    """out[N][Ho][Wo][Cout] (+)= implicit-GEMM convolution of channels-last inputs (K6/K11)."""
+    CoutP = pad16(Cout) if CoutP is None else CoutP
+    Ktot = pad16(C0) + (pad16(C1) if src1 is not None else 0)
+    taps = geom.KH * geom.KW
+    if src0.numel() != geom.N * geom.Hi * geom.Wi * C0:
+        raise MsgmError(f"src0 has {src0.numel()} elements, geometry says {geom.N * geom.Hi * geom.Wi * C0}")
+    if src1 is not None and src1.numel() != geom.N * geom.Hi * geom.Wi * C1:
+        raise MsgmError("src1 does not match the geometry")
+    if out.numel() != geom.N * geom.Ho * geom.Wo * Cout:
+        raise MsgmError(f"out has {out.numel()} elements, geometry says {geom.N * geom.Ho * geom.Wo * Cout}")
+    if Wp.numel() < taps * CoutP * Ktot:
+        raise MsgmError("packed weight too small")
+    if bias is not None and bias.numel() != Cout:
+        raise MsgmError("bias size")
+    if samp_bias is not None and samp_bias.numel() != n_bias * Cout:
+        raise MsgmError("samp_bias must be [n_bias][Cout]")
+    check(lib().msgm_conv_forward(geom, ptr(f32(src0)), C0, ptr(src1), C1, ptr(f32(Wp)), Cout, CoutP, Ktot, ptr(bias),
+                                  ptr(samp_bias), int(n_bias), ptr(f32(out)), int(bool(accumulate)), stream()),
+          "msgm_conv_forward")
+    return out
+
+
+def conv_wgrad(geom: L.ConvGeomT, gy: torch.Tensor, src: torch.Tensor, C: int, koff: int, dWp: torch.Tensor, Cout: int,
+               CoutP: int, Ktot: int):
+    taps = geom.KH * geom.KW
+    if gy.numel() != geom.N * geom.Ho * geom.Wo * Cout or src.numel() != geom.N * geom.Hi * geom.Wi * C:
+        raise MsgmError("wgrad operands do not match the geometry")
+    if dWp.numel() < taps * CoutP * Ktot:
+        raise MsgmError("packed gradient too small")
+    check(lib().msgm_conv_wgrad(geom, ptr(f32(gy)), ptr(f32(src)), C, koff, ptr(f32(dWp)), Cout, CoutP, Ktot, stream()),
+          "msgm_conv_wgrad")
+
+
+def pack_weight(W: torch.Tensor, w_off: int, Wp: torch.Tensor, rows, ncols, col_off, taps, sr, sc, st, rowsP, Ktot, kp_off):
+    need = w_off + (rows - 1) * sr + (col_off + ncols - 1) * sc + (taps - 1) * st + 1
+    if need > W.numel() or Wp.numel() < taps * rowsP * Ktot:
+        raise MsgmError("pack_weight out of range")
+    check(lib().msgm_pack_weight(ptr(f32(W)) + 4 * w_off, ptr(f32(Wp)), rows, ncols, col_off, taps, sr, sc, st, rowsP, Ktot,
+                                 kp_off, stream()), "msgm_pack_weight")
+
+
+def unpack_weight(dW: torch.Tensor, w_off: int, dWp: torch.Tensor, rows, ncols, col_off, taps, sr, sc, st, rowsP, Ktot,
+                  kp_off, accumulate=False):
+    need = w_off + (rows - 1) * sr + (col_off + ncols - 1) * sc + (taps - 1) * st + 1
+    if need > dW.numel() or dWp.numel() < taps * rowsP * Ktot:
+        raise MsgmError("unpack_weight out of range")
+    check(lib().msgm_unpack_weight(ptr(f32(dW)) + 4 * w_off, ptr(f32(dWp)), rows, ncols, col_off, taps, sr, sc, st, rowsP,
+                                   Ktot, kp_off, int(bool(accumulate)), stream()), "msgm_unpack_weight")
+
+
+ACT_GELU, ACT_SILU = 0, 1
+
+
+def act_dual_forward(act: int, z: torch.Tensor, h: torch.Tensor, dual: bool) -> torch.Tensor:
+    half = z.numel() // 2 if dual else z.numel()
+    if h.numel() != z.numel() or half % 4:
+        raise MsgmError("act_dual_forward: sizes must match and be multiples of 4 per half")
+    check(lib().msgm_act_dual_forward(act, ptr(f32(z)), ptr(f32(h)), half, int(bool(dual)), stream()), "msgm_act_dual_forward")
+    return h
+
+
+def act_dual_backward(act: int, z: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+    half = z.numel() // 2
+    if g.numel() != z.numel() or half % 4 or z.numel() % 2:
+        raise MsgmError("act_dual_backward: sizes must match and be multiples of 4 per half")
+    check(lib().msgm_act_dual_backward(act, ptr(f32(z)), ptr(f32(g)), half, stream()), "msgm_act_dual_backward")
+    return g
+
+
+def colsum(x: torch.Tensor, N: int, P: int, C: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if x.numel() < N * P * C:
+        raise MsgmError("colsum: tensor too small")
+    out = torch.empty(N, C, dtype=torch.float32, device=x.device) if out is None else out
+    check(lib().msgm_colsum(ptr(f32(x)), ptr(out), N, P, C, stream()), "msgm_colsum")
+    return out
+
+
+def gather_row(x: torch.Tensor, N: int, P: int, C: int, pos: int) -> torch.Tensor:
+    if x.numel() < N * P * C:
+        raise MsgmError("gather_row: tensor too small")
+    out = torch.empty(N, C, dtype=torch.float32, device=x.device)
+    check(lib().msgm_gather_row(ptr(f32(x)), ptr(out), N, P, C, pos, stream()), "msgm_gather_row")
+    return out
+
+
+def add_row(x: torch.Tensor, E: torch.Tensor, N: int, P: int, C: int, pos: int, sgn: float):
+    if x.numel() < N * P * C or E.numel() != N * C:
+        raise MsgmError("add_row: size mismatch")
+    check(lib().msgm_add_row(ptr(f32(x)), ptr(f32(E)), N, P, C, pos, float(sgn), stream()), "msgm_add_row")

@@ -1,0 +1,201 @@
+"""GPU parity of the implicit-GEMM convolution kernels (K6/K11) and the
+dual-number activations against plain PyTorch fp32 CPU ops (the torch fp32
+reference of a floating-point kernel).  Tolerance 1e-5 rel-L2 (fp32 MFMA is an
+exact-fp32 fma chain; only the summation order differs)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def cl1(x):   # (N,C,L) -> [N][L][C]
+    return x.permute(0, 2, 1).contiguous()
+
+
+def cl2(x):   # (N,C,H,W) -> [N][H][W][C]
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def mk(weight, bias, kind, k, stride, pad, srcC, embC=0, ups=False):
+    from sdeflow_light_amd.convnet import ConvOp
+    w = torch.nn.Parameter(weight.to(DEV))
+    b = torch.nn.Parameter(bias.to(DEV)) if bias is not None else None
+    w.grad = torch.zeros_like(w)
+    if b is not None:
+        b.grad = torch.zeros_like(b)
+    op = ConvOp(w, b, kind, k, stride, pad, srcC, embC, ups)
+    op.pack()
+    op.zero_grad_images()
+    return op
+
+
+@pytest.mark.parametrize("N,Cin,Cout,L,k,s,p", [(3, 32, 32, 100, 3, 1, 1), (2, 1, 32, 64, 3, 1, 1), (2, 64, 128, 37, 3, 1, 1),
+                                                 (2, 32, 32, 101, 4, 2, 1), (2, 128, 128, 64, 4, 2, 1), (2, 32, 1, 50, 1, 1, 0),
+                                                 (5, 96, 48, 33, 3, 1, 1), (2, 3, 32, 40, 3, 1, 1)])
+def test_conv1d_fwd_bwd(N, Cin, Cout, L, k, s, p):
+    torch.manual_seed(N * 100 + Cin)
+    x = torch.randn(N, Cin, L, requires_grad=True)
+    W = torch.randn(Cout, Cin, k) * 0.2
+    b = torch.randn(Cout) * 0.1
+    Wt, bt = W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = F.conv1d(x, Wt, bt, stride=s, padding=p)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    op = mk(W, b, "conv", (k,), s, p, [Cin])
+    xs = cl1(x.detach()).to(DEV)
+    out, Ho, Lo = op.forward([xs], N, 1, L, n_bias=N)
+    assert (Ho, Lo) == (1, y.shape[-1])
+    assert rel_l2(out.view(N, Lo, Cout).cpu(), cl1(y.detach())) <= 1e-5
+    (dx,) = op.backward(cl1(gy).to(DEV), [xs], N, 1, L, n_bias=N)
+    assert rel_l2(dx.view(N, L, Cin).cpu(), cl1(x.grad)) <= 1e-5
+    op.unpack_grads()
+    assert rel_l2(op.weight.grad.cpu(), Wt.grad) <= 1e-5
+    assert rel_l2(op.bias.grad.cpu(), bt.grad) <= 1e-5
+    # tangent rows (second half of the batch) get no bias
+    out2, _, _ = op.forward([torch.cat([xs, xs])], 2 * N, 1, L, n_bias=N)
+    o2 = out2.view(2 * N, Lo, Cout).cpu()
+    assert rel_l2(o2[:N], cl1(y.detach())) <= 1e-5
+    assert rel_l2(o2[N:], cl1(F.conv1d(x.detach(), W, None, stride=s, padding=p))) <= 1e-5
+
+
+@pytest.mark.parametrize("N,Cin,Cout,L", [(2, 128, 128, 16), (3, 64, 32, 25), (2, 128, 64, 64)])
+def test_conv_transpose1d_fwd_bwd(N, Cin, Cout, L):
+    torch.manual_seed(Cin + L)
+    x = torch.randn(N, Cin, L, requires_grad=True)
+    W = torch.randn(Cin, Cout, 4) * 0.2
+    b = torch.randn(Cout) * 0.1
+    Wt, bt = W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = F.conv_transpose1d(x, Wt, bt, stride=2, padding=1)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    op = mk(W, b, "convT", (4,), 2, 1, [Cin])
+    xs = cl1(x.detach()).to(DEV)
+    out, _, Lo = op.forward([xs], N, 1, L, n_bias=N)
+    assert Lo == 2 * L
+    assert rel_l2(out.view(N, Lo, Cout).cpu(), cl1(y.detach())) <= 1e-5
+    (dx,) = op.backward(cl1(gy).to(DEV), [xs], N, 1, L, n_bias=N)
+    assert rel_l2(dx.view(N, L, Cin).cpu(), cl1(x.grad)) <= 1e-5
+    op.unpack_grads()
+    assert rel_l2(op.weight.grad.cpu(), Wt.grad) <= 1e-5
+    assert rel_l2(op.bias.grad.cpu(), bt.grad) <= 1e-5
+
+
+def test_conv1d_concat_and_embedding_channels():
+    """[up, skip, emb] concat (NNUnet1D.py:175): two real sources + 128 broadcast channels folded into a bias."""
+    torch.manual_seed(7)
+    N, Ca, Cb, E, Cout, L = 3, 32, 32, 128, 32, 50
+    a, bsrc = torch.randn(N, Ca, L, requires_grad=True), torch.randn(N, Cb, L, requires_grad=True)
+    emb = torch.randn(N, E, requires_grad=True)
+    W = torch.randn(Cout, Ca + Cb + E, 3) * 0.1
+    bias = torch.randn(Cout) * 0.1
+    Wt, bt = W.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    y = F.conv1d(torch.cat([a, bsrc, emb[:, :, None].expand(-1, -1, L)], 1), Wt, bt, padding=1)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    op = mk(W, bias, "conv", (3,), 1, 1, [Ca, Cb], embC=E)
+    sa, sb_, e = cl1(a.detach()).to(DEV), cl1(bsrc.detach()).to(DEV), emb.detach().to(DEV).contiguous()
+    out, _, _ = op.forward([sa, sb_], N, 1, L, n_bias=N, emb=e)
+    assert rel_l2(out.view(N, L, Cout).cpu(), cl1(y.detach())) <= 1e-5
+    demb = torch.zeros(N * E, device=DEV)
+    da, db = op.backward(cl1(gy).to(DEV), [sa, sb_], N, 1, L, n_bias=N, emb=e, demb=demb)
+    assert rel_l2(da.view(N, L, Ca).cpu(), cl1(a.grad)) <= 1e-5
+    assert rel_l2(db.view(N, L, Cb).cpu(), cl1(bsrc.grad)) <= 1e-5
+    assert rel_l2(demb.view(N, E).cpu(), emb.grad) <= 1e-5
+    op.unpack_grads()
+    assert rel_l2(op.weight.grad.cpu(), Wt.grad) <= 1e-5
+    assert rel_l2(op.bias.grad.cpu(), bt.grad) <= 1e-5
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W_,k,s,p", [(2, 3, 32, 16, 16, 3, 1, 1), (2, 32, 32, 16, 12, 3, 2, 1), (1, 96, 64, 8, 8, 3, 1, 1),
+                                                    (2, 64, 128, 8, 8, 1, 1, 0), (2, 192, 64, 4, 4, 3, 1, 1), (1, 32, 3, 10, 10, 3, 1, 1)])
+def test_conv2d_fwd_bwd(N, Cin, Cout, H, W_, k, s, p):
+    torch.manual_seed(Cin + H)
+    x = torch.randn(N, Cin, H, W_, requires_grad=True)
+    W = torch.randn(Cout, Cin, k, k) * 0.1
+    b = torch.randn(Cout) * 0.1
+    Wt, bt = W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = F.conv2d(x, Wt, bt, stride=s, padding=p)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    op = mk(W, b, "conv", (k, k), s, p, [Cin])
+    xs = cl2(x.detach()).to(DEV)
+    out, Ho, Wo = op.forward([xs], N, H, W_, n_bias=N)
+    assert (Ho, Wo) == tuple(y.shape[-2:])
+    assert rel_l2(out.view(N, Ho, Wo, Cout).cpu(), cl2(y.detach())) <= 1e-5
+    (dx,) = op.backward(cl2(gy).to(DEV), [xs], N, H, W_, n_bias=N)
+    assert rel_l2(dx.view(N, H, W_, Cin).cpu(), cl2(x.grad)) <= 1e-5
+    op.unpack_grads()
+    assert rel_l2(op.weight.grad.cpu(), Wt.grad) <= 1e-5
+    assert rel_l2(op.bias.grad.cpu(), bt.grad) <= 1e-5
+
+
+def test_conv2d_upsample_folded_and_two_sources():
+    torch.manual_seed(3)
+    N, C, H = 2, 64, 8
+    x = torch.randn(N, C, H, H)
+    W, b = torch.randn(C, C, 3, 3) * 0.1, torch.randn(C) * 0.1
+    y = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), W, b, padding=1)      # model/unet.py:67-69
+    op = mk(W, b, "conv", (3, 3), 1, 1, [C], ups=True)
+    out, Ho, Wo = op.forward([cl2(x).to(DEV)], N, H, H, n_bias=N)
+    assert (Ho, Wo) == (16, 16) and rel_l2(out.view(N, 16, 16, C).cpu(), cl2(y)) <= 1e-5
+    a, c = torch.randn(N, 128, H, H), torch.randn(N, 64, H, H)
+    W2, b2 = torch.randn(128, 192, 3, 3) * 0.05, torch.randn(128) * 0.1
+    y2 = F.conv2d(torch.cat([a, c], 1), W2, b2, padding=1)                               # model/unet.py:514
+    op2 = mk(W2, b2, "conv", (3, 3), 1, 1, [128, 64])
+    out2, _, _ = op2.forward([cl2(a).to(DEV), cl2(c).to(DEV)], N, H, H, n_bias=N)
+    assert rel_l2(out2.view(N, H, H, 128).cpu(), cl2(y2)) <= 1e-5
+
+
+def test_linear_as_1x1():
+    torch.manual_seed(4)
+    x = torch.randn(37, 1, requires_grad=True)
+    W, b = torch.randn(128, 1), torch.randn(128)
+    Wt = W.clone().requires_grad_(True)
+    y = F.linear(x, Wt, b)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    op = mk(W, b, "linear", (1,), 1, 0, [1])
+    out, _, _ = op.forward([x.detach().to(DEV).contiguous()], 37, 1, 1, n_bias=37)
+    assert rel_l2(out.view(37, 128).cpu(), y.detach()) <= 1e-5
+    (dx,) = op.backward(gy.to(DEV).contiguous(), [x.detach().to(DEV).contiguous()], 37, 1, 1, n_bias=37)
+    op.unpack_grads()
+    assert rel_l2(dx.view(37, 1).cpu(), x.grad) <= 1e-5 and rel_l2(op.weight.grad.cpu(), Wt.grad) <= 1e-5
+
+
+@pytest.mark.parametrize("act,fn", [(0, lambda z: F.gelu(z)), (1, lambda z: torch.sigmoid(z) * z)])
+def test_act_dual_forward_backward(act, fn):
+    from sdeflow_light_amd import ops
+    torch.manual_seed(5)
+    n = 4096
+    zp, zt = torch.randn(n) * 2, torch.randn(n)
+    hp, ht = torch.func.jvp(fn, (zp,), (zt,))
+    z = torch.cat([zp, zt]).to(DEV)
+    h = ops.act_dual_forward(act, z, torch.empty_like(z), dual=True)
+    assert rel_l2(h[:n].cpu(), hp) <= 1e-6 and rel_l2(h[n:].cpu(), ht) <= 1e-5
+    h1 = ops.act_dual_forward(act, z[:n].contiguous(), torch.empty(n, device=DEV), dual=False)
+    assert rel_l2(h1.cpu(), hp) <= 1e-6
+    gp, gt = torch.randn(n), torch.randn(n)
+    zp_, zt_ = zp.clone().requires_grad_(True), zt.clone().requires_grad_(True)
+    hp2, ht2 = torch.func.jvp(fn, (zp_,), (zt_,))
+    (hp2 * gp).sum().add((ht2 * gt).sum()).backward()
+    g = torch.cat([gp, gt]).to(DEV)
+    ops.act_dual_backward(act, z, g)
+    assert rel_l2(g[:n].cpu(), zp_.grad) <= 1e-5 and rel_l2(g[n:].cpu(), zt_.grad) <= 1e-5
+
+
+def test_colsum_rows():
+    from sdeflow_light_amd import ops
+    torch.manual_seed(6)
+    for (N, P, C) in ((3, 100, 32), (2, 7, 300), (5, 1, 16), (1, 1000, 1)):
+        x = torch.randn(N, P, C)
+        assert rel_l2(ops.colsum(x.to(DEV), N, P, C).cpu(), x.sum(1)) <= 1e-5
+        assert torch.equal(ops.gather_row(x.to(DEV), N, P, C, P - 1).cpu(), x[:, P - 1])
+        xd = x.to(DEV).clone()
+        E = torch.randn(N, C)
+        ops.add_row(xd, E.to(DEV), N, P, C, 0, -1.0)
+        ref = x.clone(); ref[:, 0] -= E
+        assert rel_l2(xd.cpu(), ref) <= 1e-6
