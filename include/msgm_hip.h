@@ -130,6 +130,14 @@ int msgm_sde_stage(float* out, const float* base, float c_out,
                    const float* delta_rows, float t_frac,
                    msgm_stream_t stream);
 
+/* K12: SSM loss reduction for a score net evaluated on a (primal | tangent)
+ * stacked batch, SGM case.  `out` is [2B][n] (a = out[:B], adot = J_a v = out[B:]):
+ *   per[b] = sum_i v_i (sqrt(beta_b) adot_i + 1/2 beta_b v_i) + 1/2 a_i^2   (SDEs.py:631-646)
+ * and the cotangents of mean_b(per) * (1/inv_batch scaling) w.r.t. (a, adot):
+ *   g[:B] = a * inv_batch, g[B:] = sqrt(beta) v * inv_batch. */
+int msgm_ssm_loss_diag(const float* out, const float* v, const float* t, float* per, float* g,
+                       int64_t B, int64_t n, const msgm_sde_t* sde, float inv_batch, msgm_stream_t stream);
+
 /* out = c0*a + c1*b + c2*c (b, c may be NULL): stage points of Heun / RK4
  * (x + K/2, sde_scheme.py:148,234,240,246). */
 int msgm_lincomb(float* out, const float* a, float c0, const float* b, float c1,

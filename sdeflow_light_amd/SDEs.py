@@ -380,8 +380,11 @@ class PluginReverseSDE(nn.Module):
         inject the three draws of SDEs.py:688,141,515 (parity tests)."""
         from .NN import MLP
         base = self.base_sde
-        if not (isinstance(self.a, MLP) and base.kind == L.SDE_SGM):
-            raise MsgmError("fused SSM is built for MLP + SGMsde in this round; U-Net paths are next (DESIGN.md)")
+        net = self.a
+        if base.kind != L.SDE_SGM:
+            raise MsgmError("fused SSM training is built for SGMsde in this round (MSGM training is next, DESIGN.md)")
+        if not (isinstance(net, MLP) or hasattr(net, "ssm_grad")):
+            raise MsgmError(f"no HIP SSM path for score net {type(net).__name__}")
         if self.vtype != 'rademacher' and u_v is None:
             raise MsgmError("fused SSM draws Rademacher probes")
         x = x.contiguous().float()
@@ -392,13 +395,20 @@ class PluginReverseSDE(nn.Module):
         v = ops.rademacher((B, d), dev, u=u_v, rng=None if u_v is not None else rng)
         if u is None or eps is None or u_v is None:
             rng.advance(1)
-        net = self.a
         flat, gflat = net.flat_parameters()
-        if self._ws is None or self._ws.device != dev:
-            self._ws = ops.mlp_ssm_workspace(d, net.pre is not None, dev)
-        per = torch.empty(B, dtype=torch.float32, device=dev)
-        gtmp = torch.empty_like(gflat)
-        ops.mlp_ssm_grad(net.kernel_params(), y, t.reshape(-1), v, base.struct(), 1.0 / B, gtmp, self._ws, loss_per=per)
+        if isinstance(net, MLP):
+            if self._ws is None or self._ws.device != dev:
+                self._ws = ops.mlp_ssm_workspace(d, net.pre is not None, dev)
+            per = torch.empty(B, dtype=torch.float32, device=dev)
+            gtmp = torch.empty_like(gflat)
+            ops.mlp_ssm_grad(net.kernel_params(), y, t.reshape(-1), v, base.struct(), 1.0 / B, gtmp, self._ws, loss_per=per)
+        else:
+            # U-Nets: dual-number forward + hand-written backward; the net writes its flat .grad bucket
+            keep = gflat.clone()
+            per = net.ssm_grad(y, t.reshape(-1), v, base.struct(), 1.0 / B)
+            flat, gflat = net.flat_parameters()
+            gtmp = gflat.clone()
+            gflat.copy_(keep)
         return _SSMGradBridge.apply(per, gtmp, gflat, net, B, next(net.parameters()))
 
     def ssm_loss(self, t_, x, y, v=None):

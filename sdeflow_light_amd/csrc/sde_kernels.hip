@@ -307,6 +307,37 @@ __global__ void k_rk4_combine(float* __restrict__ out, const float* __restrict__
   }
 }
 
+// K12: per-sample SSM loss and the cotangents of (a, adot) for the SGM (diagonal) case.
+// out is the score net's (primal | tangent) output [2B][n]: a = out[:B], adot = J_a v = out[B:].
+//   loss_b = sum_i v_i (sqrt(beta) adot_i + 1/2 beta v_i) + 1/2 a_i^2        SDEs.py:631-646
+//   g[:B] = a * w, g[B:] = sqrt(beta) v * w   (w = 1/global batch: gradient of the mean)
+template <int GS>
+__global__ void k_ssm_loss_diag(const float* __restrict__ out, const float* __restrict__ v, const float* __restrict__ t,
+                                float* __restrict__ per, float* __restrict__ g, int64_t B, int64_t n, float b0, float b1,
+                                float w) {
+  const int lane = threadIdx.x & (GS - 1);
+  const int64_t gpb = blockDim.x / GS;
+  const int64_t gid = blockIdx.x * gpb + threadIdx.x / GS;
+  const int64_t gstride = (int64_t)gridDim.x * gpb;
+  const int64_t rows_pad = ((B + gstride - 1) / gstride) * gstride;
+  for (int64_t b = gid; b < rows_pad; b += gstride) {
+    float acc = 0.f;
+    if (b < B) {
+      const float beta = sde_beta(b0, b1, t[b]);
+      const float sb = sqrtf(beta);
+      for (int64_t i = lane; i < n; i += GS) {
+        const float a = out[b * n + i], ad = out[(B + b) * n + i], vi = v[b * n + i];
+        acc += vi * (sb * ad + 0.5f * beta * vi) + 0.5f * a * a;
+        g[b * n + i] = a * w;
+        g[(B + b) * n + i] = sb * vi * w;
+      }
+    }
+#pragma unroll
+    for (int o = GS >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, GS);
+    if (b < B && lane == 0) per[b] = acc;
+  }
+}
+
 // out = c0*a + c1*b + c2*c (b, c optional) — glue for Heun / RK4 stage points
 __global__ void k_lincomb(float* __restrict__ out, const float* __restrict__ a, float c0, const float* __restrict__ b,
                           float c1, const float* __restrict__ c, float c2, int64_t n) {
@@ -517,6 +548,22 @@ int msgm_rk4_combine(float* out, const float* x, const float* k1, const float* k
       case 16: hipLaunchKernelGGL(k_rk4_combine<16>, dim3(grid), dim3(block), 0, S(stream), out, x, k1, k2, k3, k4, B, n, norm0); break;
       case 32: hipLaunchKernelGGL(k_rk4_combine<32>, dim3(grid), dim3(block), 0, S(stream), out, x, k1, k2, k3, k4, B, n, norm0); break;
       default: hipLaunchKernelGGL(k_rk4_combine<64>, dim3(grid), dim3(block), 0, S(stream), out, x, k1, k2, k3, k4, B, n, norm0); break;
+    }
+  });
+}
+
+int msgm_ssm_loss_diag(const float* out, const float* v, const float* t, float* per, float* g, int64_t B, int64_t n,
+                       const msgm_sde_t* sde, float inv_batch, msgm_stream_t stream) {
+  if (!out || !v || !t || !per || !g || !sde || B <= 0 || n <= 0) return MSGM_E_BADARG;
+  if (sde->kind != MSGM_SDE_SGM) return MSGM_E_UNSUPPORTED;
+  return launch_rows(B, n, [&](int gs, int grid, int block) {
+    switch (gs) {
+      case 2: hipLaunchKernelGGL(k_ssm_loss_diag<2>, dim3(grid), dim3(block), 0, S(stream), out, v, t, per, g, B, n, sde->beta_min, sde->beta_max, inv_batch); break;
+      case 4: hipLaunchKernelGGL(k_ssm_loss_diag<4>, dim3(grid), dim3(block), 0, S(stream), out, v, t, per, g, B, n, sde->beta_min, sde->beta_max, inv_batch); break;
+      case 8: hipLaunchKernelGGL(k_ssm_loss_diag<8>, dim3(grid), dim3(block), 0, S(stream), out, v, t, per, g, B, n, sde->beta_min, sde->beta_max, inv_batch); break;
+      case 16: hipLaunchKernelGGL(k_ssm_loss_diag<16>, dim3(grid), dim3(block), 0, S(stream), out, v, t, per, g, B, n, sde->beta_min, sde->beta_max, inv_batch); break;
+      case 32: hipLaunchKernelGGL(k_ssm_loss_diag<32>, dim3(grid), dim3(block), 0, S(stream), out, v, t, per, g, B, n, sde->beta_min, sde->beta_max, inv_batch); break;
+      default: hipLaunchKernelGGL(k_ssm_loss_diag<64>, dim3(grid), dim3(block), 0, S(stream), out, v, t, per, g, B, n, sde->beta_min, sde->beta_max, inv_batch); break;
     }
   });
 }

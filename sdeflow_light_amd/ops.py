@@ -89,6 +89,18 @@ def sde_stage(out: torch.Tensor, base: Optional[torch.Tensor], c_out: float, x: 
     return out
 
 
+def ssm_loss_diag(out: torch.Tensor, v: torch.Tensor, t: torch.Tensor, sde: L.SdeT, inv_batch: float):
+    """(per[B], g[2B][n]) from the stacked (primal | tangent) net output — K12."""
+    B, n = v.shape
+    if out.numel() != 2 * B * n or t.numel() != B:
+        raise MsgmError("ssm_loss_diag: out must be [2B][n], t [B]")
+    per = torch.empty(B, dtype=torch.float32, device=v.device)
+    g = torch.empty(2 * B * n, dtype=torch.float32, device=v.device)
+    check(lib().msgm_ssm_loss_diag(ptr(f32(out)), ptr(f32(v)), ptr(f32(t)), ptr(per), ptr(g), B, n, sde, float(inv_batch),
+                                   stream()), "msgm_ssm_loss_diag")
+    return per, g
+
+
 def lincomb(out: torch.Tensor, a: torch.Tensor, c0: float, b: Optional[torch.Tensor] = None, c1: float = 0.0,
             c: Optional[torch.Tensor] = None, c2: float = 0.0) -> torch.Tensor:
     n = a.numel()

@@ -248,3 +248,58 @@ def test_trainer_fused_launches_match_separate_kernels():
         assert rel_l2(tr.gflat.cpu(), g.cpu()) <= 1e-6
         assert rel_l2(tr.flat.cpu(), p.cpu()) <= 1e-7
     assert int(tr.step_dev) == 2
+
+
+# ------------------------------------------------------------------ 1-D U-Net (C3 path)
+def _unet1d(L, dev=DEV):
+    from sdeflow_light_amd.NNUnet1D import UNet1D
+    from oracle.det_params import load_det_
+    net = UNet1D(input_dim=L, base_channels=32, channel_mults=(1, 2, 4), num_res_blocks=2, premodule=None, emb_dim=128)
+    load_det_(net)
+    return net.to(dev)
+
+
+def test_unet1d_state_dict_keys_match_reference_layout():
+    from test_oracle_golden import unet1d_shapes
+    net = _unet1d(64, "cpu")
+    want = unet1d_shapes(64, None)
+    got = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert got == {k: tuple(v) for k, v in want.items()}
+    assert sum(v.numel() for v in net.state_dict().values()) == 819265
+
+
+@pytest.mark.parametrize("tag,L", [("u1d", 1024), ("u1d_odd", 1001), ("u1d_small", 64)])
+def test_unet1d_forward_golden(tag, L):
+    g = load_golden("g09_unet1d")
+    net = _unet1d(L)
+    out = net(g[tag + "_x"].to(DEV), g[tag + "_t"].to(DEV))
+    assert out.shape == g[tag + "_out"].shape
+    assert rel_l2(out.cpu(), g[tag + "_out"]) <= 1e-4, rel_l2(out.cpu(), g[tag + "_out"])
+
+
+def test_unet1d_ssm_golden():
+    """Per-sample SSM loss and every parameter gradient (digest) vs the reference's double-backward (g10)."""
+    from test_oracle_golden import _check_digest
+    g = load_golden("g10_ssm_unets")
+    net = _unet1d(256)
+    gen = make_gen("sgm", net)
+    gen.zero_grad()
+    per = gen.ssm(g["u1d_x"].to(DEV), u=g["u1d_u_t"].reshape(-1).to(DEV), eps=g["u1d_eps"].to(DEV), u_v=g["u1d_u_v"].to(DEV))
+    assert rel_l2(per.detach().cpu(), g["u1d_per"]) <= 1e-4, rel_l2(per.detach().cpu(), g["u1d_per"])
+    per.mean().backward()
+    grads = {k: p.grad.cpu() for k, p in gen.a.named_parameters()}
+    _check_digest(g, "u1d", grads, "a.", 5e-4)
+
+
+def test_unet1d_sampler_runs_and_matches_oracle():
+    from sdeflow_light_amd import sde_scheme as SS
+    from oracle import sde_ref as S, nets_ref as N
+    torch.manual_seed(0)
+    L = 64
+    net = _unet1d(L)
+    gen = make_gen("sgm", net)
+    x0, z = torch.randn(5, L), torch.randn(6, 5, L)
+    xs = SS.euler_maruyama_sampler(gen, x0.to(DEV), num_steps=6, keep_all_samples=False, noise=z)
+    p = {k: v.cpu() for k, v in net.state_dict().items()}
+    ref = S.euler_maruyama(S.ReverseProcess(S.SdeSpec(), lambda y, s: N.unet1d_forward(p, y, s)), x0, 6, z)
+    assert rel_l2(xs, ref) <= 1e-4, rel_l2(xs, ref)
