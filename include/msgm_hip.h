@@ -277,6 +277,51 @@ int msgm_colsum(const float* x, float* S, int32_t N, int32_t P, int32_t C, msgm_
 int msgm_gather_row(const float* x, float* out, int32_t N, int32_t P, int32_t C, int32_t pos, msgm_stream_t stream);
 int msgm_add_row(float* x, const float* E, int32_t N, int32_t P, int32_t C, int32_t pos, float sgn, msgm_stream_t stream);
 
+/* ---- K7/K8/K9/K10: the 2-D U-Net's non-convolution ops ---------------------- */
+/* GroupNorm(G groups, affine) [+ SiLU] on a (primal | tangent) stacked tensor
+ * x [N][P][C] channels-last, N = 2*Bp when dual (model/nn_utils.py:39-46,107-114;
+ * used at model/unet.py:140-143,152-155,214,443-444).  Tangent:
+ *   ydot = gamma (xdot - mean(xdot) - xhat mean(xhat xdot)) / sigma.
+ * stats [Bp][G][4] = {mean, 1/sigma, mean(xdot), mean(xhat xdot)} is written by
+ * forward (may be NULL when no backward follows) and read by backward, which
+ * recomputes xhat / SiLU from x, adds to dgamma / dbeta (float atomics) and
+ * writes the input cotangents (primal | tangent) to gx (may alias gout). */
+int msgm_groupnorm_dual_forward(const float* x, const float* gamma, const float* beta, float* out, float* stats,
+                                int32_t Bp, int32_t P, int32_t C, int32_t G, int32_t dual, int32_t silu, float eps,
+                                msgm_stream_t stream);
+int msgm_groupnorm_dual_backward(const float* x, const float* gamma, const float* beta, const float* stats,
+                                 const float* gout, float* gx, float* dgamma, float* dbeta, int32_t Bp, int32_t P,
+                                 int32_t C, int32_t G, int32_t silu, float eps, msgm_stream_t stream);
+
+/* Batched fp32-MFMA GEMM with element strides:
+ *   C[b](i,j) (+)= alpha sum_k A[b](i,k) B[b](k,j)
+ * (QK^T, PV and their adjoints in QKVAttention, model/unet.py:236-250). */
+int msgm_bmm(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, int32_t batch,
+             int64_t sAb, int64_t sAi, int64_t sAk, int64_t sBb, int64_t sBk, int64_t sBj,
+             int64_t sCb, int64_t sCi, int64_t sCj, float alpha, int32_t accumulate, msgm_stream_t stream);
+
+/* Row softmax on dual numbers (model/unet.py:249): S (primal logits) is
+ * overwritten by P = softmax(S); with dual, Wd holds the tangent logits (kept
+ * for backward) and Pd receives Pdot = P (Wd - sum_j P Wd).  Backward, in place:
+ * (Pb, Pdb) = cotangents of (P, Pdot) -> cotangents of (S, Wd). */
+int msgm_softmax_dual_forward(float* S, const float* Wd, float* Pd, int64_t rows, int32_t T, int32_t dual,
+                              msgm_stream_t stream);
+int msgm_softmax_dual_backward(const float* P, const float* Wd, float* Pb, float* Pdb, int64_t rows, int32_t T,
+                               msgm_stream_t stream);
+
+/* [cos(t f_j), sin(t f_j)], f_j = exp(-ln(max_period) j/half) (model/nn_utils.py:130-148). */
+int msgm_timestep_embedding(const float* t, float* emb, int32_t B, int32_t dim, float max_period, msgm_stream_t stream);
+
+/* flat (B, C*H*W) [channel-major; per channel 'C' (h*W+w) or 'F' (w*H+h) order]
+ * <-> channels-last image [B][H][W][C], times `scale` (the /5, x5 of NNUnet.py:19-77). */
+int msgm_flat_to_image(const float* flat, float* img, int32_t B, int32_t C, int32_t H, int32_t W, int32_t forder,
+                       float scale, msgm_stream_t stream);
+int msgm_image_to_flat(const float* img, float* flat, int32_t B, int32_t C, int32_t H, int32_t W, int32_t forder,
+                       float scale, msgm_stream_t stream);
+/* out[n][h][w][c] = sum of the 2x2 block in[n][2h..2h+1][2w..2w+1][c]: adjoint of the
+ * nearest-2x upsample (model/unet.py:67). */
+int msgm_sum2x2(const float* in, float* out, int32_t N, int32_t H, int32_t W, int32_t C, msgm_stream_t stream);
+
 /* Slab reduction fused with the Adam update of msgm_adam_step (single-GPU step:
  * nothing sits between them) and, when rng_advance != NULL, rng_advance[1] += 1.
  * grads may be NULL. */

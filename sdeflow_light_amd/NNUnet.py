@@ -1,0 +1,482 @@
+"""2-D U-Net score network on HIP kernels — host mirror of the reference's
+``NNUnet.py`` + ``model/unet.py`` (``VorticityUNet`` / ``UNetModelWithLogNorm``):
+same constructor signature and ``state_dict`` keys (``core.time_embed.*``,
+``core.input_blocks.N.0.{in_layers,emb_layers,out_layers,skip_connection}.*``,
+``…N.1.{norm,qkv,proj_out}.*``, ``…N.0.op.*``, ``core.middle_block.*``,
+``core.output_blocks.N.K.*`` (``.conv`` for Upsample), ``core.out.{0,2}.*``;
+model/unet.py:338-446).
+
+The ``nn`` children only hold parameters (PyTorch layouts); the computation is a
+hand-scheduled pipeline of the implicit-GEMM conv kernels, the dual GroupNorm+SiLU
+kernels and the attention pieces (batched MFMA GEMM + dual softmax), channels-last,
+with the forward-mode tangent as the second half of the batch and a hand-written
+backward (no autograd tape, no double backward).
+
+Extension over the reference wrapper: ``channels`` (default
+1) lets the flat state be ``(B, channels*H*W)`` — needed for the 64x64x3 config;
+the core UNet upstream already supports any ``in_channels``.
+"""
+from __future__ import annotations
+
+import math
+from typing import Literal, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import MsgmError
+from .NN import FlatParamMixin
+from .convnet import ConvOp
+
+SILU = ops.ACT_SILU
+scale_image = 5          # NNUnet.py:19
+
+
+def zero_module(m):
+    for p in m.parameters():
+        p.detach().zero_()
+    return m
+
+
+def _norm(c):            # normalization(): GroupNorm32(min(c,32), c)      model/nn_utils.py:107-114
+    return nn.GroupNorm(min(c, 32), c)
+
+
+class ResBlock(nn.Module):
+    """Parameter holder with the reference's child names (model/unet.py:139-168)."""
+
+    def __init__(self, channels, emb_channels, out_channels):
+        super().__init__()
+        self.channels, self.out_channels = channels, out_channels
+        self.in_layers = nn.Sequential(_norm(channels), nn.Identity(), nn.Conv2d(channels, out_channels, 3, padding=1))
+        self.emb_layers = nn.Sequential(nn.Identity(), nn.Linear(emb_channels, out_channels))
+        self.out_layers = nn.Sequential(_norm(out_channels), nn.Identity(), nn.Identity(),
+                                        zero_module(nn.Conv2d(out_channels, out_channels, 3, padding=1)))
+        self.skip_connection = nn.Identity() if out_channels == channels else nn.Conv2d(channels, out_channels, 1)
+
+
+class AttentionBlock(nn.Module):
+    def __init__(self, channels):
+        super().__init__()
+        self.channels = channels
+        self.norm = _norm(channels)
+        self.qkv = nn.Conv1d(channels, channels * 3, 1)
+        self.proj_out = zero_module(nn.Conv1d(channels, channels, 1))
+
+
+class Downsample(nn.Module):
+    def __init__(self, channels):
+        super().__init__()
+        self.op = nn.Conv2d(channels, channels, 3, stride=2, padding=1)
+
+
+class Upsample(nn.Module):
+    def __init__(self, channels):
+        super().__init__()
+        self.conv = nn.Conv2d(channels, channels, 3, padding=1)
+
+
+class UNetModelWithLogNorm(nn.Module):
+    """Topology of UNetModel.__init__ (model/unet.py:300-446) at the options the
+    driver uses (dims=2, conv_resample, 1 head, no scale-shift norm, no classes)."""
+
+    def __init__(self, in_channels, model_channels, out_channels, in_space, num_res_blocks, attention_resolutions,
+                 dropout=0, channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2, num_classes=None, use_checkpoint=False,
+                 num_heads=1, num_heads_upsample=-1, use_scale_shift_norm=False, learn_potential=False, use_log_norm=False):
+        super().__init__()
+        if dims != 2 or not conv_resample or num_classes is not None or num_heads != 1 or use_scale_shift_norm or \
+                learn_potential or dropout != 0:
+            raise MsgmError("HIP U-Net is built for the driver's options (dims=2, conv_resample, 1 head, dropout 0)")
+        if use_log_norm:
+            raise MsgmError("use_log_norm / NormalizeLogRadius conditioning is not built yet for the HIP U-Net")
+        self.in_channels, self.model_channels, self.out_channels = in_channels, model_channels, out_channels
+        self.channel_mult, self.num_res_blocks = tuple(channel_mult), num_res_blocks
+        self.attention_resolutions = tuple(attention_resolutions)
+        ted = model_channels * 4
+        self.time_embed = nn.Sequential(nn.Linear(model_channels, ted), nn.Identity(), nn.Linear(ted, ted))
+        ch = model_channels * channel_mult[0]
+        self.input_blocks = nn.ModuleList([nn.Sequential(nn.Conv2d(in_channels, ch, 3, padding=1))])
+        chans, ds = [ch], 1
+        for level, mult in enumerate(channel_mult):
+            for _ in range(num_res_blocks):
+                layers = [ResBlock(ch, ted, mult * model_channels)]
+                ch = mult * model_channels
+                if ds in attention_resolutions:
+                    layers.append(AttentionBlock(ch))
+                self.input_blocks.append(nn.Sequential(*layers))
+                chans.append(ch)
+            if level != len(channel_mult) - 1:
+                self.input_blocks.append(nn.Sequential(Downsample(ch)))
+                chans.append(ch)
+                ds *= 2
+        self.middle_block = nn.Sequential(ResBlock(ch, ted, ch), AttentionBlock(ch), ResBlock(ch, ted, ch))
+        self.output_blocks = nn.ModuleList([])
+        for level, mult in list(enumerate(channel_mult))[::-1]:
+            for i in range(num_res_blocks + 1):
+                layers = [ResBlock(ch + chans.pop(), ted, model_channels * mult)]
+                ch = model_channels * mult
+                if ds in attention_resolutions:
+                    layers.append(AttentionBlock(ch))
+                if level and i == num_res_blocks:
+                    layers.append(Upsample(ch))
+                    ds //= 2
+                self.output_blocks.append(nn.Sequential(*layers))
+        self.out = nn.Sequential(_norm(ch), nn.Identity(), zero_module(nn.Conv2d(model_channels * channel_mult[0], out_channels, 3, padding=1)))
+
+
+# ----------------------------------------------------------------------------- executable ops
+class _Res:
+    def __init__(self, m: ResBlock):
+        self.m = m
+        ci, co = m.channels, m.out_channels
+        self.ci, self.co = ci, co
+        self.conv1 = ConvOp(m.in_layers[2].weight, m.in_layers[2].bias, "conv", (3, 3), 1, 1, [ci])
+        self.lin = ConvOp(m.emb_layers[1].weight, m.emb_layers[1].bias, "linear", (1,), 1, 0, [m.emb_layers[1].in_features])
+        self.conv2 = ConvOp(m.out_layers[3].weight, m.out_layers[3].bias, "conv", (3, 3), 1, 1, [co])
+        self.skip = None if isinstance(m.skip_connection, nn.Identity) else \
+            ConvOp(m.skip_connection.weight, m.skip_connection.bias, "conv", (1, 1), 1, 0, [ci])
+        self.ops = [self.conv1, self.lin, self.conv2] + ([self.skip] if self.skip else [])
+
+
+class _Attn:
+    def __init__(self, m: AttentionBlock):
+        self.m, self.c = m, m.channels
+        self.qkv = ConvOp(m.qkv.weight, m.qkv.bias, "conv", (1,), 1, 0, [m.channels])
+        self.proj = ConvOp(m.proj_out.weight, m.proj_out.bias, "conv", (1,), 1, 0, [m.channels])
+        self.ops = [self.qkv, self.proj]
+
+
+class VorticityUNet(nn.Module, FlatParamMixin):
+    def __init__(self, base_channels: int = 32, channel_mults=(1, 2, 4), num_res_blocks: int = 2, emb_dim_ignored: int = 128,
+                 dropout: float = 0.0, premodule: Optional[str] = None, in_space: int = 16, attention_resolutions=(2, 4),
+                 conv_resample: bool = True, num_heads: int = 1, use_checkpoint: bool = False, learn_potential: bool = False,
+                 flatten_order: Literal["C", "F"] = "C", channels: int = 1):
+        super().__init__()
+        assert premodule in (None, "NormalizeLogRadius")
+        if premodule is not None:
+            raise MsgmError("VorticityUNet on HIP: premodule='NormalizeLogRadius' is not built yet (SGM configs use None)")
+        self.pre = None
+        self.in_space = int(in_space)
+        assert flatten_order in ("C", "F")
+        self.flatten_order = flatten_order
+        self.channels = channels
+        self.core = UNetModelWithLogNorm(in_channels=channels, model_channels=base_channels, out_channels=channels,
+                                         in_space=in_space, num_res_blocks=num_res_blocks,
+                                         attention_resolutions=attention_resolutions, dropout=dropout,
+                                         channel_mult=tuple(channel_mults), conv_resample=conv_resample, dims=2,
+                                         num_classes=None, use_checkpoint=use_checkpoint, num_heads=num_heads,
+                                         use_scale_shift_norm=False, learn_potential=learn_potential, use_log_norm=False)
+        self._x = None
+        self._flat = None
+
+    # ------------------------------------------------------------------ build
+    def _build(self):
+        self.flat_parameters()
+        core = self.core
+        first = core.time_embed[0].weight
+        if self._x is not None and self._x["t0"].weight is first and self._x["t0"].Wp.device == first.device:
+            return self._x
+        mc = core.model_channels
+        x = {"t0": ConvOp(core.time_embed[0].weight, core.time_embed[0].bias, "linear", (1,), 1, 0, [mc]),
+             "t2": ConvOp(core.time_embed[2].weight, core.time_embed[2].bias, "linear", (1,), 1, 0, [4 * mc])}
+
+        def wrap(seq):
+            out = []
+            for layer in seq:
+                if isinstance(layer, ResBlock):
+                    out.append(("res", _Res(layer)))
+                elif isinstance(layer, AttentionBlock):
+                    out.append(("attn", _Attn(layer)))
+                elif isinstance(layer, Downsample):
+                    c = layer.op.in_channels
+                    out.append(("down", ConvOp(layer.op.weight, layer.op.bias, "conv", (3, 3), 2, 1, [c])))
+                elif isinstance(layer, Upsample):
+                    c = layer.conv.in_channels
+                    out.append(("up", ConvOp(layer.conv.weight, layer.conv.bias, "conv", (3, 3), 1, 1, [c], ups=True)))
+                elif isinstance(layer, nn.Conv2d):
+                    out.append(("conv", ConvOp(layer.weight, layer.bias, "conv", (3, 3), 1, 1, [layer.in_channels])))
+                else:
+                    raise MsgmError(f"unexpected layer {type(layer)}")
+            return out
+        x["in"] = [wrap(b) for b in core.input_blocks]
+        x["mid"] = wrap(core.middle_block)
+        x["outb"] = [wrap(b) for b in core.output_blocks]
+        x["fin"] = ConvOp(core.out[2].weight, core.out[2].bias, "conv", (3, 3), 1, 1, [core.out[2].in_channels])
+        allops = [x["t0"], x["t2"], x["fin"]]
+        for blk in x["in"] + [x["mid"]] + x["outb"]:
+            for kind, o in blk:
+                allops += o.ops if kind in ("res", "attn") else [o]
+        x["all"] = allops
+        self._x = x
+        return x
+
+    # ------------------------------------------------------------------ forward pieces
+    def _gn(self, gnm: nn.GroupNorm, h, Bp, P, C, dual, silu, tape):
+        G = gnm.num_groups
+        stats = torch.empty(Bp * G * 4, device=h.device) if tape is not None else None
+        out = ops.groupnorm_dual_forward(h, gnm.weight.detach(), gnm.bias.detach(), Bp, P, C, G, dual, silu, stats=stats)
+        return out, stats
+
+    def _res_fwd(self, r: _Res, x, N, Bp, H, W, semb, dual, tape):
+        P = H * W
+        h1, st1 = self._gn(r.m.in_layers[0], x, Bp, P, r.ci, dual, True, tape)
+        eo, _, _ = r.lin.forward([semb], Bp, 1, 1, Bp)
+        h2, _, _ = r.conv1.forward([h1], N, H, W, Bp, samp_bias=eo)
+        h3, st2 = self._gn(r.m.out_layers[0], h2, Bp, P, r.co, dual, True, tape)
+        if r.skip is not None:
+            out, _, _ = r.skip.forward([x], N, H, W, Bp)
+            r.conv2.forward([h3], N, H, W, Bp, out=out, accumulate=True)
+        else:
+            out, _, _ = r.conv2.forward([h3], N, H, W, Bp)
+            ops.lincomb(out, out, 1.0, x, 1.0)
+        if tape is not None:
+            tape.append(("res", r, x, H, W, h1, st1, h2, st2, h3))
+        return out
+
+    def _attn_fwd(self, a: _Attn, x, N, Bp, H, W, dual, tape):
+        T, C = H * W, a.c
+        dev = x.device
+        hn, st = self._gn(a.m.norm, x, Bp, T, C, dual, False, tape)
+        qkv, _, _ = a.qkv.forward([hn], N, 1, T, Bp)                     # [N][T][3C]: q | k | v channel slices
+        s2 = 1.0 / math.sqrt(C)                                          # (ch^-1/4)^2           model/unet.py:245-248
+        ld = 3 * C
+        half = Bp * T * ld                                               # offset of the tangent rows
+        S = torch.empty(Bp * T * T, device=dev)
+        sq, sk, sS = (T * ld, ld, 1), (T * ld, 1, ld), (T * T, T, 1)
+        ops.bmm(qkv, 0, qkv, C, S, 0, T, T, C, Bp, sq, sk, sS, alpha=s2)
+        Wd = Pd = None
+        if dual:
+            Wd, Pd = torch.empty_like(S), torch.empty_like(S)
+            ops.bmm(qkv, half, qkv, C, Wd, 0, T, T, C, Bp, sq, sk, sS, alpha=s2)                     # qdot k^T
+            ops.bmm(qkv, 0, qkv, half + C, Wd, 0, T, T, C, Bp, sq, sk, sS, alpha=s2, accumulate=True)  # q kdot^T
+        ops.softmax_dual_forward(S, T, Wd, Pd)                           # S <- P
+        att = torch.empty(N * T * C, device=dev)
+        sP, sv, sa = (T * T, T, 1), (T * ld, ld, 1), (T * C, C, 1)
+        ops.bmm(S, 0, qkv, 2 * C, att, 0, T, C, T, Bp, sP, sv, sa)                                   # a = P v
+        if dual:
+            offa = Bp * T * C
+            ops.bmm(Pd, 0, qkv, 2 * C, att, offa, T, C, T, Bp, sP, sv, sa)                           # Pdot v
+            ops.bmm(S, 0, qkv, half + 2 * C, att, offa, T, C, T, Bp, sP, sv, sa, accumulate=True)     # + P vdot
+        out, _, _ = a.proj.forward([att], N, 1, T, Bp)
+        ops.lincomb(out, out, 1.0, x, 1.0)
+        if tape is not None:
+            tape.append(("attn", a, x, H, W, hn, st, qkv, S, Wd, Pd, att))
+        return out
+
+    def _run(self, img, t, N, Bp, dual, tape):
+        """img: channels-last [N][H][W][Cin].  Returns channels-last [N][H][W][Cout]."""
+        x = self._build()
+        for op in x["all"]:
+            op.pack()
+        core = self.core
+        mc = core.model_channels
+        H = W = self.in_space
+        e0 = ops.timestep_embedding(t, mc)
+        z1, _, _ = x["t0"].forward([e0.view(-1)], Bp, 1, 1, Bp)
+        a1 = ops.act_dual_forward(SILU, z1, torch.empty_like(z1), False)
+        emb, _, _ = x["t2"].forward([a1], Bp, 1, 1, Bp)
+        semb = ops.act_dual_forward(SILU, emb, torch.empty_like(emb), False)     # emb_layers[0] = SiLU, shared
+        if tape is not None:
+            tape.append(("emb", e0, z1, a1, emb, semb))
+
+        def run_block(blk, h, C, H, W):
+            for kind, o in blk:
+                if kind == "conv":
+                    if tape is not None:
+                        tape.append(("conv", o, h, H, W))
+                    h, H, W = o.forward([h], N, H, W, Bp)
+                    C = o.Cout
+                elif kind == "res":
+                    h = self._res_fwd(o, h, N, Bp, H, W, semb, dual, tape)
+                    C = o.co
+                elif kind == "attn":
+                    h = self._attn_fwd(o, h, N, Bp, H, W, dual, tape)
+                elif kind in ("down", "up"):
+                    if tape is not None:
+                        tape.append((kind, o, h, H, W))
+                    h, H, W = o.forward([h], N, H, W, Bp)
+            return h, C, H, W
+
+        h, C = img, core.in_channels
+        hs = []
+        for blk in x["in"]:
+            h, C, H, W = run_block(blk, h, C, H, W)
+            hs.append((h, C))
+            if tape is not None:
+                tape.append(("save_skip",))
+        h, C, H, W = run_block(x["mid"], h, C, H, W)
+        for blk in x["outb"]:
+            s, Cs = hs.pop()
+            cat = torch.cat([h.view(N, H * W, C), s.view(N, H * W, Cs)], dim=2).reshape(-1)    # model/unet.py:514
+            if tape is not None:
+                tape.append(("cat", C, Cs, H, W))
+            h, C, H, W = run_block(blk, cat, C + Cs, H, W)
+        hf, stf = self._gn(core.out[0], h, Bp, H * W, C, dual, True, tape)
+        if tape is not None:
+            tape.append(("fin", h, stf, hf, H, W, C))
+        out, _, _ = x["fin"].forward([hf], N, H, W, Bp)
+        return out
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+        """x: (B, channels*H*W) flat or (B,channels,H,W); t: (B,) or (B,1) (NNUnet.py:195-245)."""
+        t = t.reshape(-1).float().contiguous()
+        S_, Cc = self.in_space, self.channels
+        need_flat = x.dim() == 2
+        if need_flat:
+            B, d = x.shape
+            assert d == Cc * S_ * S_, f"Flat dim {d} != {Cc}*{S_}*{S_}"
+            flat, forder, sc_in, sc_out = x.contiguous().float(), self.flatten_order == "F", 1.0 / scale_image, float(scale_image)
+        elif x.dim() == 4:
+            B = x.shape[0]
+            assert x.size(1) == Cc
+            flat, forder, sc_in, sc_out = x.contiguous().float().reshape(B, -1), False, 1.0, 1.0
+        else:
+            raise ValueError(f"Unexpected input shape {tuple(x.shape)}")
+        if t.numel() == 1 and B != 1:
+            t = t.expand(B).contiguous()
+        img = ops.flat_to_image(flat, B, Cc, S_, S_, forder, sc_in)
+        out = self._run(img, t, B, B, False, None)
+        y = ops.image_to_flat(out, B, Cc, S_, S_, forder, sc_out)
+        return y if need_flat else y.view(B, Cc, S_, S_)
+
+    # ------------------------------------------------------------------ training
+    @torch.no_grad()
+    def ssm_grad(self, y, t, v, sde_struct, inv_batch):
+        """Per-sample SSM loss (B,), SGM base SDE; gradients of sum_b loss_b*inv_batch into .grad."""
+        B, d = y.shape
+        N = 2 * B
+        S_, Cc = self.in_space, self.channels
+        self.flat_parameters()
+        for p in self.parameters():
+            if p.grad is None:
+                self._flatten_parameters()
+                break
+        x = self._build()
+        for op in x["all"]:
+            op.zero_grad_images()
+        flat, gflat = self.flat_parameters()
+        for gn in self._groupnorms():
+            gn.weight.grad.zero_(); gn.bias.grad.zero_()
+        forder = self.flatten_order == "F"
+        stacked = torch.cat([y.contiguous().float(), v.contiguous().float()], 0)
+        img = ops.flat_to_image(stacked, N, Cc, S_, S_, forder, 1.0 / scale_image)
+        tape = []
+        tt = t.reshape(-1).contiguous().float()
+        out = self._run(img, tt, N, B, True, tape)
+        a_flat = ops.image_to_flat(out, N, Cc, S_, S_, forder, float(scale_image))      # [2B][d]: a | adot
+        per, g = ops.ssm_loss_diag(a_flat.view(-1), v.contiguous().float(), tt, sde_struct, inv_batch)
+        gimg = ops.flat_to_image(g.view(N, d), N, Cc, S_, S_, forder, float(scale_image))   # adjoint of (x5, unflatten)
+        self._backward(tape, gimg, N, B)
+        for op in x["all"]:
+            op.unpack_grads()
+        return per
+
+    def _groupnorms(self):
+        return [m for m in self.modules() if isinstance(m, nn.GroupNorm)]
+
+    def _gn_bwd(self, gnm, xin, stats, g, Bp, P, C, silu):
+        return ops.groupnorm_dual_backward(xin, gnm.weight.detach(), gnm.bias.detach(), stats, g, gnm.weight.grad, gnm.bias.grad,
+                                           Bp, P, C, gnm.num_groups, silu)
+
+    def _backward(self, tape, g, N, Bp):
+        x = self._x
+        dev = g.device
+        emb_rec = tape[0]
+        _, e0, z1, a1, emb, semb = emb_rec
+        dsemb = torch.zeros_like(semb)
+        dh = g
+        pend = []                       # gradients w.r.t. the skip (hs) tensors, in pop order
+        i = len(tape) - 1
+        while i >= 1:
+            r = tape[i]
+            kind = r[0]
+            if kind == "fin":
+                _, h, stf, hf, H, W, C = r
+                (dhf,) = x["fin"].backward(dh, [hf], N, H, W, Bp)
+                dh = self._gn_bwd(self.core.out[0], h, stf, dhf, Bp, H * W, C, True)
+            elif kind == "res":
+                _, rb, xin, H, W, h1, st1, h2, st2, h3 = r
+                P = H * W
+                (dh3,) = rb.conv2.backward(dh, [h3], N, H, W, Bp)
+                dh2 = self._gn_bwd(rb.m.out_layers[0], h2, st2, dh3, Bp, P, rb.co, True)
+                deo = torch.empty(Bp * rb.co, device=dev)
+                (dh1,) = rb.conv1.backward(dh2, [h1], N, H, W, Bp, dsamp_bias=deo)
+                rb.lin.backward(deo, [semb], Bp, 1, 1, Bp, dsrc=[dsemb], dacc=[True])
+                dx = self._gn_bwd(rb.m.in_layers[0], xin, st1, dh1, Bp, P, rb.ci, True)
+                if rb.skip is not None:
+                    rb.skip.backward(dh, [xin], N, H, W, Bp, dsrc=[dx], dacc=[True])
+                else:
+                    ops.lincomb(dx, dx, 1.0, dh, 1.0)
+                dh = dx
+            elif kind == "attn":
+                dh = self._attn_bwd(r, dh, N, Bp)
+            elif kind == "conv":
+                _, o, hin, H, W = r
+                o.backward(dh, [hin], N, H, W, Bp, need=[False])
+                dh = None
+            elif kind == "down":
+                _, o, hin, H, W = r
+                (dh,) = o.backward(dh, [hin], N, H, W, Bp)
+            elif kind == "up":
+                _, o, hin, H, W = r
+                dh = o.backward_ups(dh, hin, N, H, W, Bp)
+            elif kind == "cat":
+                _, C, Cs, H, W = r
+                gg = dh.view(N, H * W, C + Cs)
+                pend.append(gg[:, :, C:].contiguous().view(-1))
+                dh = gg[:, :, :C].contiguous().view(-1)
+            elif kind == "save_skip":
+                # this tensor also fed an output block through the skip stack (model/unet.py:514)
+                sk = pend.pop()
+                if dh is None:
+                    dh = sk
+                else:
+                    ops.lincomb(dh, dh, 1.0, sk, 1.0)
+            i -= 1
+        # time-embedding MLP (primal rows): Linear -> SiLU -> Linear -> SiLU (shared emb_layers[0])
+        z = torch.zeros_like(emb)
+        ge = torch.cat([dsemb, z])
+        ops.act_dual_backward(SILU, torch.cat([emb, z]), ge)
+        (da1,) = x["t2"].backward(ge[: emb.numel()].contiguous(), [a1], Bp, 1, 1, Bp)
+        z1z = torch.zeros_like(z1)
+        g1 = torch.cat([da1, z1z])
+        ops.act_dual_backward(SILU, torch.cat([z1, z1z]), g1)
+        x["t0"].backward(g1[: z1.numel()].contiguous(), [e0.view(-1)], Bp, 1, 1, Bp, need=[False])
+        return dh
+
+    def _attn_bwd(self, r, dout, N, Bp):
+        _, a, xin, H, W, hn, st, qkv, Pm, Wd, Pd, att = r
+        T, C = H * W, a.c
+        dev = dout.device
+        s2 = 1.0 / math.sqrt(C)
+        ld = 3 * C
+        half, offa = Bp * T * ld, Bp * T * C
+        (datt,) = a.proj.backward(dout, [att], N, 1, T, Bp)             # [N][T][C]: abar | adotbar
+        dqkv = torch.zeros(N * T * ld, device=dev)
+        sP, sPt = (T * T, T, 1), (T * T, 1, T)                          # P(t,s) / P^T(s,t)
+        sa, sq = (T * C, C, 1), (T * ld, ld, 1)
+        # vbar = P^T abar + Pdot^T adotbar ; vdotbar = P^T adotbar
+        ops.bmm(Pm, 0, datt, 0, dqkv, 2 * C, T, C, T, Bp, sPt, sa, sq)
+        ops.bmm(Pd, 0, datt, offa, dqkv, 2 * C, T, C, T, Bp, sPt, sa, sq, accumulate=True)
+        ops.bmm(Pm, 0, datt, offa, dqkv, half + 2 * C, T, C, T, Bp, sPt, sa, sq)
+        # Pbar = abar v^T + adotbar vdot^T ; Pdotbar = adotbar v^T
+        Pb, Pdb = torch.empty_like(Pm), torch.empty_like(Pm)
+        svT = (T * ld, 1, ld)                                            # B(k=c, j=s) = v[s][c]
+        ops.bmm(datt, 0, qkv, 2 * C, Pb, 0, T, T, C, Bp, sa, svT, sP)
+        ops.bmm(datt, offa, qkv, half + 2 * C, Pb, 0, T, T, C, Bp, sa, svT, sP, accumulate=True)
+        ops.bmm(datt, offa, qkv, 2 * C, Pdb, 0, T, T, C, Bp, sa, svT, sP)
+        ops.softmax_dual_backward(Pm, Wd, Pb, Pdb, T)                   # Pb <- Wbar, Pdb <- Wdotbar
+        # qbar = s2 (Wbar k + Wdotbar kdot) ; qdotbar = s2 Wdotbar k
+        ops.bmm(Pb, 0, qkv, C, dqkv, 0, T, C, T, Bp, sP, sq, sq, alpha=s2)
+        ops.bmm(Pdb, 0, qkv, half + C, dqkv, 0, T, C, T, Bp, sP, sq, sq, alpha=s2, accumulate=True)
+        ops.bmm(Pdb, 0, qkv, C, dqkv, half, T, C, T, Bp, sP, sq, sq, alpha=s2)
+        # kbar = s2 (Wbar^T q + Wdotbar^T qdot) ; kdotbar = s2 Wdotbar^T q
+        ops.bmm(Pb, 0, qkv, 0, dqkv, C, T, C, T, Bp, sPt, sq, sq, alpha=s2)
+        ops.bmm(Pdb, 0, qkv, half, dqkv, C, T, C, T, Bp, sPt, sq, sq, alpha=s2, accumulate=True)
+        ops.bmm(Pdb, 0, qkv, 0, dqkv, half + C, T, C, T, Bp, sPt, sq, sq, alpha=s2)
+        (dhn,) = a.qkv.backward(dqkv, [hn], N, 1, T, Bp)
+        dx = self._gn_bwd(a.m.norm, xin, st, dhn, Bp, T, C, False)
+        ops.lincomb(dx, dx, 1.0, dout, 1.0)
+        return dx

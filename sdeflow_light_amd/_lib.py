@@ -72,6 +72,15 @@ SIGNATURES = {
     "msgm_colsum": (C.c_int, [_P, _P, _I32, _I32, _I32, _P]),
     "msgm_gather_row": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P]),
     "msgm_add_row": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _F, _P]),
+    "msgm_groupnorm_dual_forward": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _F, _P]),
+    "msgm_groupnorm_dual_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _F, _P]),
+    "msgm_bmm": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, _I32, _P]),
+    "msgm_softmax_dual_forward": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P]),
+    "msgm_softmax_dual_backward": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P]),
+    "msgm_timestep_embedding": (C.c_int, [_P, _P, _I32, _I32, _F, _P]),
+    "msgm_flat_to_image": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _F, _P]),
+    "msgm_image_to_flat": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _F, _P]),
+    "msgm_sum2x2": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P]),
     "msgm_mlp_forward": (C.c_int, [C.POINTER(MlpParamsT), _P, _P, _P, _I64, _P]),
     "msgm_mlp_em_step": (C.c_int, [C.POINTER(MlpParamsT), _P, _I64, C.POINTER(SdeT), _F, _F, _F, _P, _P, _U64, _P]),
     "msgm_mlp_ssm_workspace": (_SZ, [_I32, _I32]),

@@ -192,3 +192,20 @@ class ConvOp:
                              CoutP=pad16(C))
             outs.append(d)
         return outs
+
+    def backward_ups(self, gy: torch.Tensor, src: torch.Tensor, N: int, Hi: int, Wi: int, n_bias: int) -> torch.Tensor:
+        """Backward of a conv whose input is nearest-upsampled 2x on the fly (Upsample, model/unet.py:60-73):
+        wgrad through the folded gather, dgrad on the 2x grid, then the 2x2 block sum (adjoint of the upsample)."""
+        if not self.ups or len(self.srcC) != 1:
+            raise MsgmError("backward_ups is for a single-source folded-upsample conv")
+        geom, Ho, Wo = self._geom(N, Hi, Wi)
+        dev, C = gy.device, self.srcC[0]
+        ops.conv_wgrad(geom, gy, src, C, 0, self.dWp, self.Cout, self.CoutP, self.Ktot)
+        if self.bias is not None:
+            S = torch.empty(n_bias * self.Cout, device=dev)
+            ops.colsum(gy, n_bias, Ho * Wo, self.Cout, out=S)
+            ops.colsum(S, 1, n_bias, self.Cout, out=self.bias.grad.view(1, -1))
+        gd = ops.conv_geom(N, Ho, Wo, 2 * Hi, 2 * Wi, self.KH, self.KW, self.stride, self.pad, 1 - self.mode, 0)
+        gup = torch.empty(N * 4 * Hi * Wi * C, device=dev)
+        ops.conv_forward(gd, gy, self.Cout, self.Wd[0], C, gup, CoutP=pad16(C))
+        return ops.sum2x2(gup, N, Hi, Wi, C)

@@ -1,0 +1,445 @@
+// unet2d_kernels.hip — the 2-D U-Net's non-convolution ops on gfx950:
+//   K7  GroupNorm(min(C,32) groups) [+ SiLU] on dual numbers, forward and backward
+//       (model/nn_utils.py:39-46,107-114; model/unet.py:140-143,152-155,214,443-444)
+//   K8  single-head attention pieces: batched fp32-MFMA GEMM + dual softmax rows
+//       (model/unet.py:236-250)
+//   K10 sinusoidal timestep embedding (model/nn_utils.py:130-148)
+//   K9  layout glue: flat <-> channels-last image (NNUnet.py:19-77), 2x2 block sum
+//       (adjoint of the nearest-2x upsample folded into the conv gather)
+// Activations are channels-last [N][P][C]; the forward-mode tangent is the second
+// half of the batch (rows n >= Bp).
+#include "common.h"
+
+__device__ __forceinline__ f32x4 mfma16u(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ void silu012u(float z, float& s0, float& s1, float& s2) {
+  const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-z));
+  const float om = 1.0f - sg;
+  s0 = z * sg;
+  s1 = sg * (1.0f + z * om);
+  s2 = sg * om * (2.0f + z * (1.0f - 2.0f * sg));
+}
+
+// ------------------------------------------------------------------ GroupNorm dual
+// One workgroup per primal sample b (it also owns tangent row b + Bp).  Threads run
+// along channels (coalesced) with 256/C pixel lanes; group statistics are combined
+// through LDS.  stats[b][g] = {mean, inv_std, mean(xdot), a = mean(xhat xdot)}.
+struct GnArgs {
+  const float* x; const float* gamma; const float* beta;
+  float* out; float* stats;
+  int P, C, G, Bp, dual, silu;
+  float eps;
+  // backward
+  const float* gout; float* gx; float* dgamma; float* dbeta;
+};
+
+__device__ __forceinline__ float gn_group_sum(float* red, float* bc, float v, int tid, int cl, int pl, int G, int cpg,
+                                              int c) {
+  red[tid] = v;
+  __syncthreads();
+  if (tid < G) {
+    float s = 0.f;
+    for (int p = 0; p < pl; ++p)
+      for (int cc = 0; cc < cpg; ++cc) s += red[p * cl + tid * cpg + cc];
+    bc[tid] = s;
+  }
+  __syncthreads();
+  const float r = bc[c / cpg];
+  __syncthreads();
+  return r;
+}
+__device__ __forceinline__ float gn_chan_sum(float* red, float v, int tid, int cl, int pl, int c) {
+  red[tid] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int p = 0; p < pl; ++p) s += red[p * cl + c];
+  __syncthreads();
+  return s;
+}
+
+__global__ void __launch_bounds__(256) k_gn_dual_fwd(GnArgs A) {
+  __shared__ float red[256];
+  __shared__ float bc[64];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int C = A.C, P = A.P, G = A.G, cpg = C / G;
+  const int cl = C, pl = 256 / C > 0 ? 256 / C : 1;
+  const bool live = tid < cl * pl;
+  const int c = live ? tid % cl : 0, pr = live ? tid / cl : 0;
+  const float* xp = A.x + (size_t)b * P * C;
+  const float* xt = A.x + (size_t)(b + A.Bp) * P * C;
+  const float cnt = (float)P * (float)cpg;
+  float s0 = 0.f, s1 = 0.f;
+  if (live)
+    for (int p = pr; p < P; p += pl) {
+      s0 += xp[(size_t)p * C + c];
+      if (A.dual) s1 += xt[(size_t)p * C + c];
+    }
+  const float mu = gn_group_sum(red, bc, live ? s0 : 0.f, tid, cl, pl, G, cpg, c) / cnt;
+  const float md = A.dual ? gn_group_sum(red, bc, live ? s1 : 0.f, tid, cl, pl, G, cpg, c) / cnt : 0.f;
+  s0 = 0.f; s1 = 0.f;
+  if (live)
+    for (int p = pr; p < P; p += pl) {
+      const float d = xp[(size_t)p * C + c] - mu;
+      s0 += d * d;
+      if (A.dual) s1 += d * (xt[(size_t)p * C + c] - md);
+    }
+  const float var = gn_group_sum(red, bc, live ? s0 : 0.f, tid, cl, pl, G, cpg, c) / cnt;
+  const float inv = rsqrtf(var + A.eps);
+  const float a = A.dual ? inv * gn_group_sum(red, bc, live ? s1 : 0.f, tid, cl, pl, G, cpg, c) / cnt : 0.f;
+  if (live && pr == 0 && (c % cpg) == 0 && A.stats) {
+    float* st = A.stats + ((size_t)b * G + c / cpg) * 4;
+    st[0] = mu; st[1] = inv; st[2] = md; st[3] = a;
+  }
+  if (!live) return;
+  const float ga = A.gamma[c], be = A.beta[c];
+  float* op = A.out + (size_t)b * P * C;
+  float* ot = A.out + (size_t)(b + A.Bp) * P * C;
+  for (int p = pr; p < P; p += pl) {
+    const size_t e = (size_t)p * C + c;
+    const float xh = (xp[e] - mu) * inv;
+    const float y = ga * xh + be;
+    float yd = 0.f;
+    if (A.dual) yd = ga * (inv * ((xt[e] - md) - xh * a));
+    if (A.silu) {
+      float z0, z1, z2;
+      silu012u(y, z0, z1, z2);
+      op[e] = z0;
+      if (A.dual) ot[e] = z1 * yd;
+    } else {
+      op[e] = y;
+      if (A.dual) ot[e] = yd;
+    }
+  }
+}
+
+// Backward over the dual pair.  With X = gamma*zbar, W = gamma*zdotbar (cotangents of xhat and of
+// its tangent what = inv (xdot_c - xhat a)):
+//   xdotbar = inv (W - mean W - xhat p),                      p = mean(xhat W)
+//   xbar    = inv (X - mean X - xhat mean(xhat X)) - inv (c xhat + a xdotbar + p what),  c = mean(W what)
+// (derived and checked against autograd in DESIGN.md §3 / tests).
+__global__ void __launch_bounds__(256) k_gn_dual_bwd(GnArgs A) {
+  __shared__ float red[256];
+  __shared__ float bc[64];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int C = A.C, P = A.P, G = A.G, cpg = C / G;
+  const int cl = C, pl = 256 / C > 0 ? 256 / C : 1;
+  const bool live = tid < cl * pl;
+  const int c = live ? tid % cl : 0, pr = live ? tid / cl : 0;
+  const size_t offp = (size_t)b * P * C, offt = (size_t)(b + A.Bp) * P * C;
+  const float* st = A.stats + ((size_t)b * G + c / cpg) * 4;
+  const float mu = st[0], inv = st[1], md = st[2], a = st[3];
+  const float ga = A.gamma[c], be = A.beta[c];
+  const float cnt = (float)P * (float)cpg;
+  float sX = 0.f, sXx = 0.f, sW = 0.f, sWx = 0.f, sWw = 0.f, dga = 0.f, dbe = 0.f;
+  if (live)
+    for (int p = pr; p < P; p += pl) {
+      const size_t e = (size_t)p * C + c;
+      const float xh = (A.x[offp + e] - mu) * inv;
+      const float wh = inv * ((A.x[offt + e] - md) - xh * a);
+      float zb = A.gout[offp + e], zdb = A.gout[offt + e];
+      if (A.silu) {
+        float z0, z1, z2;
+        silu012u(ga * xh + be, z0, z1, z2);
+        const float yd = ga * wh;
+        const float nzb = zb * z1 + zdb * (z2 * yd);
+        zdb = zdb * z1;
+        zb = nzb;
+      }
+      const float X = ga * zb, W = ga * zdb;
+      sX += X; sXx += X * xh; sW += W; sWx += W * xh; sWw += W * wh;
+      dga += zb * xh + zdb * wh; dbe += zb;
+    }
+  const float mX = gn_group_sum(red, bc, live ? sX : 0.f, tid, cl, pl, G, cpg, c) / cnt;
+  const float mXx = gn_group_sum(red, bc, live ? sXx : 0.f, tid, cl, pl, G, cpg, c) / cnt;
+  const float mW = gn_group_sum(red, bc, live ? sW : 0.f, tid, cl, pl, G, cpg, c) / cnt;
+  const float pp = gn_group_sum(red, bc, live ? sWx : 0.f, tid, cl, pl, G, cpg, c) / cnt;
+  const float cc = gn_group_sum(red, bc, live ? sWw : 0.f, tid, cl, pl, G, cpg, c) / cnt;
+  const float tg = gn_chan_sum(red, live ? dga : 0.f, tid, cl, pl, c);
+  const float tb = gn_chan_sum(red, live ? dbe : 0.f, tid, cl, pl, c);
+  if (live && pr == 0) { atomicAdd(A.dgamma + c, tg); atomicAdd(A.dbeta + c, tb); }
+  if (!live) return;
+  for (int p = pr; p < P; p += pl) {
+    const size_t e = (size_t)p * C + c;
+    const float xh = (A.x[offp + e] - mu) * inv;
+    const float wh = inv * ((A.x[offt + e] - md) - xh * a);
+    float zb = A.gout[offp + e], zdb = A.gout[offt + e];
+    if (A.silu) {
+      float z0, z1, z2;
+      silu012u(ga * xh + be, z0, z1, z2);
+      const float yd = ga * wh;
+      const float nzb = zb * z1 + zdb * (z2 * yd);
+      zdb = zdb * z1;
+      zb = nzb;
+    }
+    const float X = ga * zb, W = ga * zdb;
+    const float xdb = inv * (W - mW - xh * pp);
+    const float xb = inv * (X - mX - xh * mXx) - inv * (cc * xh + a * xdb + pp * wh);
+    A.gx[offp + e] = xb;
+    A.gx[offt + e] = xdb;
+  }
+}
+
+// ------------------------------------------------------------------ batched GEMM
+// C[b](i,j) (+)= alpha * sum_k A[b](i,k) B[b](k,j) with arbitrary element strides; one wave
+// computes a (16 MT) x (16 NT) tile, 4 waves a 2x2 arrangement of them.
+struct BmmArgs {
+  const float* A; const float* B; float* C;
+  int M, N, K, batch;
+  long sAb, sAi, sAk, sBb, sBk, sBj, sCb, sCi, sCj;
+  float alpha; int accumulate;
+};
+template <int MT, int NT, bool KVEC>   // KVEC: sAk == 1 && sBk == 1 (both operands contiguous along K, K % 16 == 0)
+__global__ void __launch_bounds__(256) k_bmm(BmmArgs P) {
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, il = lane & 15, q = lane >> 4;
+  const int tiles_n = (P.N + 32 * NT - 1) / (32 * NT);
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+  const int i0 = tm * 32 * MT + (w >> 1) * 16 * MT, j0 = tn * 32 * NT + (w & 1) * 16 * NT;
+  if (i0 >= P.M || j0 >= P.N) return;
+  const float* Ab = P.A + (size_t)blockIdx.y * P.sAb;
+  const float* Bb = P.B + (size_t)blockIdx.y * P.sBb;
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0, 0, 0, 0};
+  bool vi[MT], vj[NT];
+  const float* ap[MT];
+  const float* bp[NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) { const int i = i0 + 16 * m + il; vi[m] = i < P.M; ap[m] = Ab + (size_t)(vi[m] ? i : 0) * P.sAi; }
+#pragma unroll
+  for (int n = 0; n < NT; ++n) { const int j = j0 + 16 * n + il; vj[n] = j < P.N; bp[n] = Bb + (size_t)(vj[n] ? j : 0) * P.sBj; }
+  if (KVEC) {
+    for (int k0 = 0; k0 < P.K; k0 += 16) {
+      f32x4 a[MT], bb[NT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) a[m] = vi[m] ? *reinterpret_cast<const f32x4*>(ap[m] + k0 + 4 * q) : f32x4{0, 0, 0, 0};
+#pragma unroll
+      for (int n = 0; n < NT; ++n) bb[n] = vj[n] ? *reinterpret_cast<const f32x4*>(bp[n] + k0 + 4 * q) : f32x4{0, 0, 0, 0};
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[m][n] = mfma16u(a[m][r], bb[n][r], acc[m][n]);
+    }
+  } else {
+    for (int k0 = 0; k0 < P.K; k0 += 4) {
+      const int k = k0 + q;
+      const bool vk = k < P.K;
+      float a[MT], bb[NT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) a[m] = (vi[m] && vk) ? ap[m][(size_t)k * P.sAk] : 0.f;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) bb[n] = (vj[n] && vk) ? bp[n][(size_t)k * P.sBk] : 0.f;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = mfma16u(a[m], bb[n], acc[m][n]);
+    }
+  }
+  float* Cb = P.C + (size_t)blockIdx.y * P.sCb;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int j = j0 + 16 * n + il;
+      if (j >= P.N) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + 16 * m + 4 * q + r;
+        if (i >= P.M) continue;
+        float* cp = Cb + (size_t)i * P.sCi + (size_t)j * P.sCj;
+        const float v = P.alpha * acc[m][n][r];
+        *cp = P.accumulate ? *cp + v : v;
+      }
+    }
+}
+
+// ------------------------------------------------------------------ dual softmax rows
+// forward: S (primal logits, in place -> P); Wd (tangent logits, kept); Pd <- P (Wd - sum P Wd)
+__global__ void __launch_bounds__(256) k_softmax_dual_fwd(float* __restrict__ S, const float* __restrict__ Wd,
+                                                          float* __restrict__ Pd, long rows, int T, int dual) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float* s = S + row * T;
+  float mx = -3.0e38f;
+  for (int j = lane; j < T; j += 64) mx = fmaxf(mx, s[j]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float sum = 0.f;
+  for (int j = lane; j < T; j += 64) { const float e = __expf(s[j] - mx); s[j] = e; sum += e; }
+  sum = wave_sum(sum);
+  const float rs = 1.0f / sum;
+  float r = 0.f;
+  for (int j = lane; j < T; j += 64) {
+    const float p = s[j] * rs;
+    s[j] = p;
+    if (dual) r += p * Wd[row * T + j];
+  }
+  if (dual) {
+    r = wave_sum(r);
+    for (int j = lane; j < T; j += 64) Pd[row * T + j] = s[j] * (Wd[row * T + j] - r);
+  }
+}
+// backward (in place): Pb <- Wbar, Pdb <- Wdbar given P, Wd
+__global__ void __launch_bounds__(256) k_softmax_dual_bwd(const float* __restrict__ Pm, const float* __restrict__ Wd,
+                                                          float* __restrict__ Pb, float* __restrict__ Pdb, long rows, int T) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* p = Pm + row * T;
+  const float* wd = Wd + row * T;
+  float* pb = Pb + row * T;
+  float* pdb = Pdb + row * T;
+  float r = 0.f, m = 0.f;
+  for (int j = lane; j < T; j += 64) { r += p[j] * wd[j]; m += p[j] * pdb[j]; }
+  r = wave_sum(r); m = wave_sum(m);
+  float s2 = 0.f;
+  for (int j = lane; j < T; j += 64) {
+    const float pt = pb[j] + pdb[j] * (wd[j] - r) - wd[j] * m;
+    pb[j] = pt;
+    s2 += p[j] * pt;
+  }
+  s2 = wave_sum(s2);
+  for (int j = lane; j < T; j += 64) {
+    pb[j] = p[j] * (pb[j] - s2);
+    pdb[j] = p[j] * (pdb[j] - m);
+  }
+}
+
+// ------------------------------------------------------------------ embedding / layout glue
+// emb[b][j] = cos(t_b f_j), emb[b][half + j] = sin(t_b f_j), f_j = exp(-ln(max_period) j / half)
+__global__ void k_timestep_embedding(const float* __restrict__ t, float* __restrict__ emb, int B, int dim, float max_period) {
+  const int half = dim / 2;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < B * dim; e += gridDim.x * blockDim.x) {
+    const int b = e / dim, j = e - b * dim;
+    float v = 0.f;
+    if (j < 2 * half) {
+      const int jj = j < half ? j : j - half;
+      const float f = expf(-logf(max_period) * (float)jj / (float)half);
+      const float arg = t[b] * f;
+      v = j < half ? cosf(arg) : sinf(arg);
+    }
+    emb[e] = v;
+  }
+}
+// flat (B, C*H*W) channel-major, per-channel 'C' (h*W+w) or 'F' (w*H+h) order  <->  [B][H][W][C], with scale
+__global__ void k_flat_to_cl(const float* __restrict__ flat, float* __restrict__ img, int B, int C, int H, int W, int forder,
+                             float scale) {
+  const long tot = (long)B * H * W * C;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    const int w = (int)((e / C) % W);
+    const int h = (int)((e / ((long)C * W)) % H);
+    const long b = e / ((long)C * W * H);
+    const long idx = forder ? (long)w * H + h : (long)h * W + w;
+    img[e] = flat[(b * C + c) * (long)H * W + idx] * scale;
+  }
+}
+__global__ void k_cl_to_flat(const float* __restrict__ img, float* __restrict__ flat, int B, int C, int H, int W, int forder,
+                             float scale) {
+  const long tot = (long)B * H * W * C;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    const int w = (int)((e / C) % W);
+    const int h = (int)((e / ((long)C * W)) % H);
+    const long b = e / ((long)C * W * H);
+    const long idx = forder ? (long)w * H + h : (long)h * W + w;
+    flat[(b * C + c) * (long)H * W + idx] = img[e] * scale;
+  }
+}
+// out[n][h][w][c] = sum of the 2x2 block of in[n][2h+dh][2w+dw][c]
+__global__ void k_sum2x2(const float* __restrict__ in, float* __restrict__ out, int N, int H, int W, int C) {
+  const long tot = (long)N * H * W * C;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    const int w = (int)((e / C) % W);
+    const int h = (int)((e / ((long)C * W)) % H);
+    const long n = e / ((long)C * W * H);
+    const float* p = in + ((n * 2 * H + 2 * h) * (long)(2 * W) + 2 * w) * C + c;
+    out[e] = (p[0] + p[C]) + (p[(long)2 * W * C] + p[(long)2 * W * C + C]);
+  }
+}
+
+// ============================================================ C ABI
+static inline hipStream_t S(msgm_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+extern "C" {
+
+int msgm_groupnorm_dual_forward(const float* x, const float* gamma, const float* beta, float* out, float* stats, int32_t Bp,
+                                int32_t P, int32_t C, int32_t G, int32_t dual, int32_t silu, float eps, msgm_stream_t stream) {
+  if (!x || !gamma || !beta || !out || Bp <= 0 || P <= 0 || C <= 0 || G <= 0) return MSGM_E_BADARG;
+  if (C % G || C > 256 || G > 64) return MSGM_E_UNSUPPORTED;
+  GnArgs A{x, gamma, beta, out, stats, P, C, G, Bp, dual, silu, eps, nullptr, nullptr, nullptr, nullptr};
+  hipLaunchKernelGGL(k_gn_dual_fwd, dim3(Bp), dim3(256), 0, S(stream), A);
+  return msgm_check_launch();
+}
+
+int msgm_groupnorm_dual_backward(const float* x, const float* gamma, const float* beta, const float* stats, const float* gout,
+                                 float* gx, float* dgamma, float* dbeta, int32_t Bp, int32_t P, int32_t C, int32_t G,
+                                 int32_t silu, float eps, msgm_stream_t stream) {
+  if (!x || !gamma || !beta || !stats || !gout || !gx || !dgamma || !dbeta || Bp <= 0 || P <= 0 || C <= 0 || G <= 0)
+    return MSGM_E_BADARG;
+  if (C % G || C > 256 || G > 64) return MSGM_E_UNSUPPORTED;
+  GnArgs A{x, gamma, beta, nullptr, const_cast<float*>(stats), P, C, G, Bp, 1, silu, eps, gout, gx, dgamma, dbeta};
+  hipLaunchKernelGGL(k_gn_dual_bwd, dim3(Bp), dim3(256), 0, S(stream), A);
+  return msgm_check_launch();
+}
+
+int msgm_bmm(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, int32_t batch, int64_t sAb, int64_t sAi,
+             int64_t sAk, int64_t sBb, int64_t sBk, int64_t sBj, int64_t sCb, int64_t sCi, int64_t sCj, float alpha,
+             int32_t accumulate, msgm_stream_t stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0) return MSGM_E_BADARG;
+  BmmArgs P{A, B, C, M, N, K, batch, sAb, sAi, sAk, sBb, sBk, sBj, sCb, sCi, sCj, alpha, accumulate};
+  const bool kvec = sAk == 1 && sBk == 1 && (K % 16 == 0) && (sAi % 4 == 0) && (sBj % 4 == 0) && (sAb % 4 == 0) &&
+                    (sBb % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0;
+  const int tiles = ((M + 63) / 64) * ((N + 63) / 64);
+  dim3 grid((unsigned)tiles, (unsigned)batch);
+  if (kvec) hipLaunchKernelGGL((k_bmm<2, 2, true>), grid, dim3(256), 0, S(stream), P);
+  else hipLaunchKernelGGL((k_bmm<2, 2, false>), grid, dim3(256), 0, S(stream), P);
+  return msgm_check_launch();
+}
+
+int msgm_softmax_dual_forward(float* Sm, const float* Wd, float* Pd, int64_t rows, int32_t T, int32_t dual, msgm_stream_t stream) {
+  if (!Sm || rows <= 0 || T <= 0 || (dual && (!Wd || !Pd))) return MSGM_E_BADARG;
+  hipLaunchKernelGGL(k_softmax_dual_fwd, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, S(stream), Sm, Wd, Pd, (long)rows, T, dual);
+  return msgm_check_launch();
+}
+
+int msgm_softmax_dual_backward(const float* Pm, const float* Wd, float* Pb, float* Pdb, int64_t rows, int32_t T,
+                               msgm_stream_t stream) {
+  if (!Pm || !Wd || !Pb || !Pdb || rows <= 0 || T <= 0) return MSGM_E_BADARG;
+  hipLaunchKernelGGL(k_softmax_dual_bwd, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, S(stream), Pm, Wd, Pb, Pdb, (long)rows, T);
+  return msgm_check_launch();
+}
+
+int msgm_timestep_embedding(const float* t, float* emb, int32_t B, int32_t dim, float max_period, msgm_stream_t stream) {
+  if (!t || !emb || B <= 0 || dim <= 0) return MSGM_E_BADARG;
+  hipLaunchKernelGGL(k_timestep_embedding, dim3(grid_for((int64_t)B * dim, 256)), dim3(256), 0, S(stream), t, emb, B, dim, max_period);
+  return msgm_check_launch();
+}
+
+int msgm_flat_to_image(const float* flat, float* img, int32_t B, int32_t C, int32_t H, int32_t W, int32_t forder, float scale,
+                       msgm_stream_t stream) {
+  if (!flat || !img || B <= 0 || C <= 0 || H <= 0 || W <= 0) return MSGM_E_BADARG;
+  hipLaunchKernelGGL(k_flat_to_cl, dim3(grid_for((int64_t)B * C * H * W, 256)), dim3(256), 0, S(stream), flat, img, B, C, H, W, forder, scale);
+  return msgm_check_launch();
+}
+
+int msgm_image_to_flat(const float* img, float* flat, int32_t B, int32_t C, int32_t H, int32_t W, int32_t forder, float scale,
+                       msgm_stream_t stream) {
+  if (!flat || !img || B <= 0 || C <= 0 || H <= 0 || W <= 0) return MSGM_E_BADARG;
+  hipLaunchKernelGGL(k_cl_to_flat, dim3(grid_for((int64_t)B * C * H * W, 256)), dim3(256), 0, S(stream), img, flat, B, C, H, W, forder, scale);
+  return msgm_check_launch();
+}
+
+int msgm_sum2x2(const float* in, float* out, int32_t N, int32_t H, int32_t W, int32_t C, msgm_stream_t stream) {
+  if (!in || !out || N <= 0 || H <= 0 || W <= 0 || C <= 0) return MSGM_E_BADARG;
+  hipLaunchKernelGGL(k_sum2x2, dim3(grid_for((int64_t)N * H * W * C, 256)), dim3(256), 0, S(stream), in, out, N, H, W, C);
+  return msgm_check_launch();
+}
+
+}  // extern "C"

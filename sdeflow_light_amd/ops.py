@@ -318,3 +318,88 @@ def add_row(x: torch.Tensor, E: torch.Tensor, N: int, P: int, C: int, pos: int, 
     if x.numel() < N * P * C or E.numel() != N * C:
         raise MsgmError("add_row: size mismatch")
     check(lib().msgm_add_row(ptr(f32(x)), ptr(f32(E)), N, P, C, pos, float(sgn), stream()), "msgm_add_row")
+
+
+# ---------------------------------------------------------------- 2-D U-Net ops
+def groupnorm_dual_forward(x, gamma, beta, Bp, P, C, G, dual, silu, stats=None, out=None, eps=1e-5):
+    N = 2 * Bp if dual else Bp
+    if x.numel() != N * P * C or gamma.numel() != C or beta.numel() != C:
+        raise MsgmError("groupnorm: size mismatch")
+    if stats is not None and stats.numel() != Bp * G * 4:
+        raise MsgmError("groupnorm: stats must be [Bp][G][4]")
+    out = torch.empty_like(x) if out is None else out
+    check(lib().msgm_groupnorm_dual_forward(ptr(f32(x)), ptr(f32(gamma)), ptr(f32(beta)), ptr(out), ptr(stats), Bp, P, C, G,
+                                            int(bool(dual)), int(bool(silu)), float(eps), stream()), "msgm_groupnorm_dual_forward")
+    return out
+
+
+def groupnorm_dual_backward(x, gamma, beta, stats, gout, dgamma, dbeta, Bp, P, C, G, silu, gx=None, eps=1e-5):
+    if x.numel() != 2 * Bp * P * C or gout.numel() != x.numel() or stats.numel() != Bp * G * 4:
+        raise MsgmError("groupnorm backward: size mismatch")
+    if dgamma.numel() != C or dbeta.numel() != C:
+        raise MsgmError("groupnorm backward: dgamma/dbeta size")
+    gx = gout if gx is None else gx
+    check(lib().msgm_groupnorm_dual_backward(ptr(f32(x)), ptr(f32(gamma)), ptr(f32(beta)), ptr(f32(stats)), ptr(f32(gout)),
+                                             ptr(gx), ptr(dgamma), ptr(dbeta), Bp, P, C, G, int(bool(silu)), float(eps), stream()),
+          "msgm_groupnorm_dual_backward")
+    return gx
+
+
+def bmm(A, a_off, B, b_off, Cm, c_off, M, N, K, batch, sA, sB, sC, alpha=1.0, accumulate=False):
+    """C[b](i,j) (+)= alpha sum_k A[b](i,k) B[b](k,j); sA = (batch, i, k), sB = (batch, k, j), sC = (batch, i, j)
+    element strides; *_off are element offsets into the given tensors (channel slices of a fused qkv tensor)."""
+    def span(off, s, dims):
+        return off + sum((d - 1) * st for d, st in zip(dims, s)) + 1
+    if span(a_off, sA, (batch, M, K)) > A.numel() or span(b_off, sB, (batch, K, N)) > B.numel() or \
+            span(c_off, sC, (batch, M, N)) > Cm.numel():
+        raise MsgmError("bmm: strides run past the end of a tensor")
+    check(lib().msgm_bmm(ptr(f32(A)) + 4 * a_off, ptr(f32(B)) + 4 * b_off, ptr(f32(Cm)) + 4 * c_off, M, N, K, batch,
+                         sA[0], sA[1], sA[2], sB[0], sB[1], sB[2], sC[0], sC[1], sC[2], float(alpha), int(bool(accumulate)),
+                         stream()), "msgm_bmm")
+
+
+def softmax_dual_forward(S, T, Wd=None, Pd=None):
+    rows = S.numel() // T
+    dual = Wd is not None
+    if dual and (Wd.numel() != S.numel() or Pd.numel() != S.numel()):
+        raise MsgmError("softmax: size mismatch")
+    check(lib().msgm_softmax_dual_forward(ptr(f32(S)), ptr(Wd), ptr(Pd), rows, T, int(dual), stream()), "msgm_softmax_dual_forward")
+
+
+def softmax_dual_backward(Pm, Wd, Pb, Pdb, T):
+    rows = Pm.numel() // T
+    if not (Wd.numel() == Pb.numel() == Pdb.numel() == Pm.numel()):
+        raise MsgmError("softmax backward: size mismatch")
+    check(lib().msgm_softmax_dual_backward(ptr(f32(Pm)), ptr(f32(Wd)), ptr(f32(Pb)), ptr(f32(Pdb)), rows, T, stream()),
+          "msgm_softmax_dual_backward")
+
+
+def timestep_embedding(t, dim, max_period=10000.0):
+    t = t.reshape(-1).contiguous()
+    emb = torch.empty(t.numel(), dim, dtype=torch.float32, device=t.device)
+    check(lib().msgm_timestep_embedding(ptr(f32(t)), ptr(emb), t.numel(), dim, float(max_period), stream()), "msgm_timestep_embedding")
+    return emb
+
+
+def flat_to_image(flat, B, C, H, W, forder, scale):
+    if flat.numel() != B * C * H * W:
+        raise MsgmError("flat_to_image: size mismatch")
+    img = torch.empty(B * H * W * C, dtype=torch.float32, device=flat.device)
+    check(lib().msgm_flat_to_image(ptr(f32(flat)), ptr(img), B, C, H, W, int(bool(forder)), float(scale), stream()), "msgm_flat_to_image")
+    return img
+
+
+def image_to_flat(img, B, C, H, W, forder, scale):
+    if img.numel() != B * C * H * W:
+        raise MsgmError("image_to_flat: size mismatch")
+    flat = torch.empty(B, C * H * W, dtype=torch.float32, device=img.device)
+    check(lib().msgm_image_to_flat(ptr(f32(img)), ptr(flat), B, C, H, W, int(bool(forder)), float(scale), stream()), "msgm_image_to_flat")
+    return flat
+
+
+def sum2x2(x, N, H, W, C):
+    if x.numel() != N * 4 * H * W * C:
+        raise MsgmError("sum2x2: size mismatch")
+    out = torch.empty(N * H * W * C, dtype=torch.float32, device=x.device)
+    check(lib().msgm_sum2x2(ptr(f32(x)), ptr(out), N, H, W, C, stream()), "msgm_sum2x2")
+    return out

@@ -97,3 +97,44 @@ class MLPScoreTrainer:
         else:
             self._body()
         return self.loss
+
+
+class UNetScoreTrainer:
+    """SGM + a U-Net score net exposing ``ssm_grad`` (configs C3/C4): prep kernel
+    (K1 + probe) -> dual-number forward / hand-written backward -> [RCCL all-reduce
+    of the flat gradient bucket] -> fused Adam on the flat parameter bucket."""
+
+    def __init__(self, gen_sde, batch_local: int, dim: int, lr: float = 1e-4, world: int = 1, seed: int = 0):
+        net, base = gen_sde.a, gen_sde.base_sde
+        if not hasattr(net, "ssm_grad") or base.kind != L.SDE_SGM:
+            raise MsgmError("UNetScoreTrainer needs a HIP U-Net score net and an SGMsde")
+        self.gen_sde, self.net, self.base = gen_sde, net, base
+        self.dev = next(net.parameters()).device
+        self.B, self.d, self.world, self.lr = batch_local, dim, world, lr
+        self.flat, self.gflat = net.flat_parameters()
+        self.m, self.v = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
+        self.step_dev = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        self.rng = L.PhiloxState(seed * 1000003 + 29, self.dev)
+        self.x = torch.zeros(batch_local, dim, dtype=torch.float32, device=self.dev)
+        self.y, self.vp = torch.empty_like(self.x), torch.empty_like(self.x)
+        self.t = torch.empty(batch_local, dtype=torch.float32, device=self.dev)
+        self.st = base.struct()
+        self.inv_batch = 1.0 / (batch_local * world)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=self.dev)
+
+    def set_data(self, x):
+        self.x.copy_(x)
+
+    def step(self):
+        lib, s = ops.lib(), ops.stream()
+        ops.check(lib.msgm_ssm_prep(self.x.data_ptr(), self.y.data_ptr(), self.t.data_ptr(), self.vp.data_ptr(), self.B,
+                                    self.d, self.st, self.rng.ptr(), self.step_dev.data_ptr(), s), "msgm_ssm_prep")
+        per = self.net.ssm_grad(self.y, self.t, self.vp, self.st, self.inv_batch)
+        self.flat, self.gflat = self.net.flat_parameters()
+        self.loss = per.sum() * self.inv_batch
+        if self.world > 1:
+            parallel.allreduce_sum_(self.gflat)
+            parallel.allreduce_sum_(self.loss)
+        ops.adam_step(self.flat, self.gflat, self.m, self.v, step=0, lr=self.lr, step_dev=self.step_dev)
+        self.rng.advance(1)
+        return self.loss

@@ -1,0 +1,185 @@
+"""GPU parity of the 2-D U-Net pieces (K7 GroupNorm+SiLU dual, K8 attention
+pieces, K9/K10 glue) against plain PyTorch fp32 CPU, and of the assembled
+VorticityUNet against the golden vectors recorded from the reference."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def cl(x):    # (N,C,H,W) -> [N][H*W][C] flat
+    return x.permute(0, 2, 3, 1).contiguous().reshape(-1)
+
+
+@pytest.mark.parametrize("C,H,silu", [(32, 8, True), (64, 4, True), (96, 8, True), (192, 4, True), (256, 4, False), (128, 16, False)])
+def test_groupnorm_dual_forward_backward(C, H, silu):
+    from sdeflow_light_amd import ops
+    torch.manual_seed(C)
+    B, G = 3, min(C, 32)
+    x, xd = torch.randn(B, C, H, H) * 1.5 + 0.3, torch.randn(B, C, H, H)
+    gam, bet = 1 + 0.2 * torch.randn(C), 0.2 * torch.randn(C)
+
+    def f(xx, g_, b_):
+        y = F.group_norm(xx, G, g_, b_, eps=1e-5)
+        return torch.sigmoid(y) * y if silu else y
+    xg, xdg = x.clone().requires_grad_(True), xd.clone().requires_grad_(True)
+    gg, bg = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    yp, yt = torch.func.jvp(lambda a: f(a, gg, bg), (xg,), (xdg,))
+    P = H * H
+    xs = torch.cat([cl(x), cl(xd)]).to(DEV)
+    stats = torch.empty(B * G * 4, device=DEV)
+    out = ops.groupnorm_dual_forward(xs, gam.to(DEV), bet.to(DEV), B, P, C, G, True, silu, stats=stats)
+    half = B * P * C
+    assert rel_l2(out[:half].cpu(), cl(yp.detach())) <= 1e-5
+    assert rel_l2(out[half:].cpu(), cl(yt.detach())) <= 1e-5
+    out1 = ops.groupnorm_dual_forward(cl(x).to(DEV), gam.to(DEV), bet.to(DEV), B, P, C, G, False, silu)
+    assert rel_l2(out1.cpu(), cl(yp.detach())) <= 1e-5
+    gp, gt = torch.randn_like(yp), torch.randn_like(yt)
+    ((yp * gp).sum() + (yt * gt).sum()).backward()
+    gout = torch.cat([cl(gp), cl(gt)]).to(DEV)
+    dga, dbe = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    gx = ops.groupnorm_dual_backward(xs, gam.to(DEV), bet.to(DEV), stats, gout, dga, dbe, B, P, C, G, silu)
+    assert rel_l2(gx[:half].cpu(), cl(xg.grad)) <= 2e-5, rel_l2(gx[:half].cpu(), cl(xg.grad))
+    assert rel_l2(gx[half:].cpu(), cl(xdg.grad)) <= 2e-5
+    assert rel_l2(dga.cpu(), gg.grad) <= 2e-5 and rel_l2(dbe.cpu(), bg.grad) <= 2e-5
+
+
+def test_bmm_strided_and_softmax_dual():
+    from sdeflow_light_amd import ops
+    torch.manual_seed(1)
+    Bn, T, C = 3, 80, 32
+    qkv = torch.randn(Bn, T, 3 * C)
+    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    ld = 3 * C
+    qd = qkv.to(DEV).contiguous()
+    S = torch.empty(Bn * T * T, device=DEV)
+    ops.bmm(qd, 0, qd, C, S, 0, T, T, C, Bn, (T * ld, ld, 1), (T * ld, 1, ld), (T * T, T, 1), alpha=0.5)
+    ref = 0.5 * torch.einsum("btc,bsc->bts", q, k)
+    assert rel_l2(S.view(Bn, T, T).cpu(), ref) <= 1e-5
+    W = torch.softmax(ref, -1)
+    att = torch.zeros(Bn * T * C, device=DEV)
+    ops.bmm(W.to(DEV).contiguous(), 0, qd, 2 * C, att, 0, T, C, T, Bn, (T * T, T, 1), (T * ld, ld, 1), (T * C, C, 1))
+    assert rel_l2(att.view(Bn, T, C).cpu(), torch.einsum("bts,bsc->btc", W, v)) <= 1e-5
+    tr = torch.zeros(Bn * T * C, device=DEV)                   # transposed A, accumulate twice
+    for _ in range(2):
+        ops.bmm(W.to(DEV).contiguous(), 0, qd, 0, tr, 0, T, C, T, Bn, (T * T, 1, T), (T * ld, ld, 1), (T * C, C, 1), accumulate=True)
+    assert rel_l2(tr.view(Bn, T, C).cpu(), 2 * torch.einsum("bts,btc->bsc", W, q)) <= 1e-5
+    # dual softmax rows
+    Wl, Wdl = torch.randn(Bn * T, T) * 2, torch.randn(Bn * T, T)
+    Wg, Wdg = Wl.clone().requires_grad_(True), Wdl.clone().requires_grad_(True)
+    Pp, Pt = torch.func.jvp(lambda a: torch.softmax(a, -1), (Wg,), (Wdg,))
+    Sd, Wd_, Pd = Wl.to(DEV).clone(), Wdl.to(DEV).clone(), torch.empty(Bn * T, T, device=DEV)
+    ops.softmax_dual_forward(Sd, T, Wd_, Pd)
+    assert rel_l2(Sd.cpu(), Pp.detach()) <= 1e-6 and rel_l2(Pd.cpu(), Pt.detach()) <= 1e-5
+    Pb, Pdb = torch.randn_like(Pp), torch.randn_like(Pt)
+    ((Pp * Pb).sum() + (Pt * Pdb).sum()).backward()
+    pb, pdb = Pb.to(DEV).clone(), Pdb.to(DEV).clone()
+    ops.softmax_dual_backward(Sd, Wd_, pb, pdb, T)
+    assert rel_l2(pb.cpu(), Wg.grad) <= 2e-5 and rel_l2(pdb.cpu(), Wdg.grad) <= 2e-5
+
+
+def test_glue_kernels():
+    from sdeflow_light_amd import ops
+    from oracle import nets_ref as N
+    g = load_golden("g12_embedding")
+    emb = ops.timestep_embedding(g["t"].to(DEV), 32)
+    assert rel_l2(emb.cpu(), g["emb32"]) <= 1e-6
+    torch.manual_seed(2)
+    B, C, H = 3, 2, 6
+    x = torch.randn(B, C * H * H)
+    for order in ("C", "F"):
+        img = ops.flat_to_image(x.to(DEV), B, C, H, H, order == "F", 0.2)
+        ref = torch.stack([N.flat_to_image(x[:, c * H * H:(c + 1) * H * H], H, H, order)[:, 0] for c in range(C)], -1)   # [B][H][W][C]
+        assert rel_l2(img.view(B, H, H, C).cpu(), ref) <= 1e-6
+        back = ops.image_to_flat(img, B, C, H, H, order == "F", 5.0)
+        assert rel_l2(back.cpu(), x) <= 1e-6
+    up = torch.randn(B, 2 * H, 2 * H, C)
+    s = ops.sum2x2(up.to(DEV).reshape(-1), B, H, H, C)
+    ref = up.view(B, H, 2, H, 2, C).sum((2, 4))
+    assert rel_l2(s.view(B, H, H, C).cpu(), ref) <= 1e-6
+
+
+def _vunet(S_, order, channels=1):
+    from sdeflow_light_amd.NNUnet import VorticityUNet
+    from oracle.det_params import load_det_
+    net = VorticityUNet(base_channels=32, channel_mults=(1, 2, 4), num_res_blocks=2, premodule=None, in_space=S_,
+                        attention_resolutions=(2, 4), flatten_order=order, channels=channels)
+    if channels == 1:
+        load_det_(net)
+    else:
+        load_det_(net.core)
+    return net.to(DEV)
+
+
+def test_unet2d_state_dict_matches_reference_layout():
+    from test_oracle_golden import unet2d_shapes
+    from oracle import nets_ref as N
+    net = _vunet(16, "C")
+    want = unet2d_shapes(N.UNet2DConfig(in_space=16), "core.")
+    got = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert got == {k: tuple(v) for k, v in want.items()}
+    assert sum(v.numel() for v in net.state_dict().values()) == 4023233
+
+
+@pytest.mark.parametrize("tag,S_,order", [("u2d16C", 16, "C"), ("u2d16F", 16, "F"), ("u2d32F", 32, "F")])
+def test_unet2d_forward_golden(tag, S_, order):
+    g = load_golden("g09_unet2d")
+    net = _vunet(S_, order)
+    out = net(g[tag + "_x"].to(DEV), g[tag + "_t"].to(DEV))
+    assert out.shape == g[tag + "_out"].shape
+    assert rel_l2(out.cpu(), g[tag + "_out"]) <= 1e-4, rel_l2(out.cpu(), g[tag + "_out"])
+
+
+def test_unet2d_core64_three_channels_golden():
+    """64x64x3 (config C4 shape): 4-D image input through the 3-channel core."""
+    g = load_golden("g09_unet2d")
+    net = _vunet(64, "C", channels=3)
+    out = net(g["core64_x"].to(DEV), g["core64_t"].to(DEV))
+    assert rel_l2(out.cpu(), g["core64_out"]) <= 1e-4, rel_l2(out.cpu(), g["core64_out"])
+
+
+def test_unet2d_ssm_golden():
+    """SSM loss + all parameter gradients (digest) vs the reference's double backward (g10)."""
+    from test_oracle_golden import _check_digest
+    from test_host_gpu import make_gen
+    g = load_golden("g10_ssm_unets")
+    net = _vunet(16, "F")
+    gen = make_gen("sgm", net)
+    gen.zero_grad()
+    per = gen.ssm(g["u2d_x"].to(DEV), u=g["u2d_u_t"].reshape(-1).to(DEV), eps=g["u2d_eps"].to(DEV), u_v=g["u2d_u_v"].to(DEV))
+    assert rel_l2(per.detach().cpu(), g["u2d_per"]) <= 1e-4, rel_l2(per.detach().cpu(), g["u2d_per"])
+    per.mean().backward()
+    grads = {k: p.grad.cpu() for k, p in gen.a.named_parameters()}
+    _check_digest(g, "u2d", grads, "a.", 1e-3)
+
+
+def test_unet2d_ssm_vs_oracle_32():
+    """Second size (32x32, both attention resolutions with T=256 / 64) against the CPU oracle's JVP form."""
+    from test_oracle_golden import unet2d_shapes
+    from test_host_gpu import make_gen
+    from oracle import sde_ref as S, nets_ref as N, ssm_ref as LR
+    from oracle.det_params import det_state_dict
+    torch.manual_seed(0)
+    net = _vunet(32, "F")
+    gen = make_gen("sgm", net)
+    B, d = 2, 1024
+    x, u, eps, uv = torch.randn(B, d) * 3, torch.rand(B), torch.randn(B, d), torch.rand(B, d)
+    gen.zero_grad()
+    per = gen.ssm(x.to(DEV), u=u.to(DEV), eps=eps.to(DEV), u_v=uv.to(DEV))
+    per.mean().backward()
+    sp = S.SdeSpec()
+    cfg = N.UNet2DConfig(in_space=32)
+    p = det_state_dict(unet2d_shapes(cfg, "core."))
+    t = S.clamp_time(sp, u.reshape(B, 1)); y = S.vp_perturb(sp, t, x, eps); v = S.rademacher_from_uniform(uv)
+    score = lambda prm, yy, tt: N.vorticity_unet_forward(prm, yy, tt, cfg, None, "F")
+    loss, per_ref, gref = LR.ssm_mean_and_grads(sp, score, p, t, y, v)
+    assert rel_l2(per.detach().cpu(), per_ref) <= 1e-4
+    flat = torch.cat([pp.grad.reshape(-1).cpu() for _, pp in gen.a.named_parameters()])
+    ref = torch.cat([gref[k].reshape(-1) for k, _ in gen.a.named_parameters()])
+    assert rel_l2(flat, ref) <= 1e-3, rel_l2(flat, ref)
