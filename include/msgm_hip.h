@@ -282,16 +282,21 @@ int msgm_add_row(float* x, const float* E, int32_t N, int32_t P, int32_t C, int3
  * x [N][P][C] channels-last, N = 2*Bp when dual (model/nn_utils.py:39-46,107-114;
  * used at model/unet.py:140-143,152-155,214,443-444).  Tangent:
  *   ydot = gamma (xdot - mean(xdot) - xhat mean(xhat xdot)) / sigma.
+ * Each direction is two fully parallel launches (moment reduction over
+ * (sample, pixel-chunk) workgroups with double atomics into `workspace`, then an
+ * elementwise apply pass), so 32 samples/GPU still fill the chip.
  * stats [Bp][G][4] = {mean, 1/sigma, mean(xdot), mean(xhat xdot)} is written by
  * forward (may be NULL when no backward follows) and read by backward, which
  * recomputes xhat / SiLU from x, adds to dgamma / dbeta (float atomics) and
  * writes the input cotangents (primal | tangent) to gx (may alias gout). */
+size_t msgm_groupnorm_workspace(int32_t Bp, int32_t G);   /* bytes: per-(sample, group) double moment accumulators */
 int msgm_groupnorm_dual_forward(const float* x, const float* gamma, const float* beta, float* out, float* stats,
                                 int32_t Bp, int32_t P, int32_t C, int32_t G, int32_t dual, int32_t silu, float eps,
-                                msgm_stream_t stream);
+                                void* workspace, size_t workspace_bytes, msgm_stream_t stream);
 int msgm_groupnorm_dual_backward(const float* x, const float* gamma, const float* beta, const float* stats,
                                  const float* gout, float* gx, float* dgamma, float* dbeta, int32_t Bp, int32_t P,
-                                 int32_t C, int32_t G, int32_t silu, float eps, msgm_stream_t stream);
+                                 int32_t C, int32_t G, int32_t silu, float eps, void* workspace, size_t workspace_bytes,
+                                 msgm_stream_t stream);
 
 /* Batched fp32-MFMA GEMM with element strides:
  *   C[b](i,j) (+)= alpha sum_k A[b](i,k) B[b](k,j)

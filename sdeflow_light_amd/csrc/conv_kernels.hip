@@ -374,24 +374,28 @@ __global__ void k_act_dual_bwd(const float* __restrict__ z, float* __restrict__ 
   }
 }
 
-// S[n][c] = sum over positions of x[n][pos][c]  (bias / embedding gradients).  One block per n.
-__global__ void __launch_bounds__(256) k_colsum(const float* __restrict__ x, float* __restrict__ S, int P, int C) {
+// S[n][c] (+)= sum over positions of x[n][pos][c]  (bias / embedding gradients).  Grid (n, position
+// chunk): threads along channels, LDS across pixel lanes, one float atomic per (n, c) per block into a
+// zeroed S (a per-sample workgroup would leave the chip idle at small batch).
+__global__ void __launch_bounds__(256) k_colsum(const float* __restrict__ x, float* __restrict__ S, int P, int C, int chunk) {
   __shared__ float red[256];
   const int n = blockIdx.x;
   const float* xn = x + (size_t)n * P * C;
+  const int p0 = blockIdx.y * chunk, p1 = min(p0 + chunk, P);
   for (int cb = 0; cb < C; cb += 256) {
     const int lanes_c = min(C - cb, 256);
     const int rows = 256 / lanes_c;                  // position lanes per channel
     const int c = threadIdx.x % lanes_c, pr = threadIdx.x / lanes_c;
     float s = 0.f;
     if (pr < rows)
-      for (int p = pr; p < P; p += rows) s += xn[(size_t)p * C + cb + c];
+      for (int p = p0 + pr; p < p1; p += rows) s += xn[(size_t)p * C + cb + c];
     red[threadIdx.x] = (pr < rows) ? s : 0.f;
     __syncthreads();
     if (pr == 0) {
       float t = 0.f;
       for (int r = 0; r < rows; ++r) t += red[r * lanes_c + c];
-      S[(size_t)n * C + cb + c] = t;
+      if (gridDim.y == 1) S[(size_t)n * C + cb + c] = t;
+      else atomicAdd(S + (size_t)n * C + cb + c, t);
     }
     __syncthreads();
   }
@@ -518,7 +522,13 @@ int msgm_act_dual_backward(int32_t act, const float* z, float* g, int64_t half, 
 
 int msgm_colsum(const float* x, float* Sout, int32_t N, int32_t P, int32_t C, msgm_stream_t stream) {
   if (!x || !Sout || N <= 0 || P <= 0 || C <= 0) return MSGM_E_BADARG;
-  hipLaunchKernelGGL(k_colsum, dim3(N), dim3(256), 0, S(stream), x, Sout, P, C);
+  int nch = (1024 + N - 1) / N;
+  int chunk = (P + nch - 1) / nch;
+  if (chunk < 64) chunk = 64;
+  if (chunk > P) chunk = P;
+  nch = (P + chunk - 1) / chunk;
+  if (nch > 1 && hipMemsetAsync(Sout, 0, (size_t)N * C * sizeof(float), S(stream)) != hipSuccess) return MSGM_E_LAUNCH;
+  hipLaunchKernelGGL(k_colsum, dim3(N, nch), dim3(256), 0, S(stream), x, Sout, P, C, chunk);
   return msgm_check_launch();
 }
 

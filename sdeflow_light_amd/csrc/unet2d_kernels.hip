@@ -22,45 +22,39 @@ __device__ __forceinline__ void silu012u(float z, float& s0, float& s1, float& s
 }
 
 // ------------------------------------------------------------------ GroupNorm dual
-// One workgroup per primal sample b (it also owns tangent row b + Bp).  Threads run
-// along channels (coalesced) with 256/C pixel lanes; group statistics are combined
-// through LDS.  stats[b][g] = {mean, inv_std, mean(xdot), a = mean(xhat xdot)}.
+// Two fully parallel launches per direction (a per-sample workgroup would leave the
+// chip idle at 32 samples/GPU):
+//   1. k_gn_*_reduce: grid (sample, pixel chunk); threads run along channels (coalesced,
+//      256/C pixel lanes), fp32 partials -> LDS -> one double atomicAdd per (sample, group,
+//      moment).  Moments are raw (sum x, sum x^2, sum xdot, sum x xdot) but combined in
+//      double, so the variance does not suffer from E[x^2]-mu^2 cancellation.
+//   2. k_gn_*_apply: grid-stride elementwise pass that rebuilds {mean, inv_std,
+//      mean(xdot), a = mean(xhat xdot)} from the moments.
+// acc[b][g][8] doubles: forward uses 0..3, backward 0..4 (+ dgamma/dbeta atomics).
 struct GnArgs {
   const float* x; const float* gamma; const float* beta;
-  float* out; float* stats;
-  int P, C, G, Bp, dual, silu;
+  float* out; double* acc; float* stats;
+  int P, C, G, Bp, dual, silu, chunk;
   float eps;
   // backward
   const float* gout; float* gx; float* dgamma; float* dbeta;
 };
 
-__device__ __forceinline__ float gn_group_sum(float* red, float* bc, float v, int tid, int cl, int pl, int G, int cpg,
-                                              int c) {
+__device__ __forceinline__ void gn_group_atomic(float* red, float v, int tid, int cl, int pl, int G, int cpg, double* dst,
+                                                int stride) {
   red[tid] = v;
   __syncthreads();
   if (tid < G) {
     float s = 0.f;
     for (int p = 0; p < pl; ++p)
       for (int cc = 0; cc < cpg; ++cc) s += red[p * cl + tid * cpg + cc];
-    bc[tid] = s;
+    atomicAdd(dst + (size_t)tid * stride, (double)s);
   }
   __syncthreads();
-  const float r = bc[c / cpg];
-  __syncthreads();
-  return r;
-}
-__device__ __forceinline__ float gn_chan_sum(float* red, float v, int tid, int cl, int pl, int c) {
-  red[tid] = v;
-  __syncthreads();
-  float s = 0.f;
-  for (int p = 0; p < pl; ++p) s += red[p * cl + c];
-  __syncthreads();
-  return s;
 }
 
-__global__ void __launch_bounds__(256) k_gn_dual_fwd(GnArgs A) {
+__global__ void __launch_bounds__(256) k_gn_fwd_reduce(GnArgs A) {
   __shared__ float red[256];
-  __shared__ float bc[64];
   const int tid = threadIdx.x, b = blockIdx.x;
   const int C = A.C, P = A.P, G = A.G, cpg = C / G;
   const int cl = C, pl = 256 / C > 0 ? 256 / C : 1;
@@ -68,47 +62,60 @@ __global__ void __launch_bounds__(256) k_gn_dual_fwd(GnArgs A) {
   const int c = live ? tid % cl : 0, pr = live ? tid / cl : 0;
   const float* xp = A.x + (size_t)b * P * C;
   const float* xt = A.x + (size_t)(b + A.Bp) * P * C;
-  const float cnt = (float)P * (float)cpg;
-  float s0 = 0.f, s1 = 0.f;
+  const int p0 = blockIdx.y * A.chunk, p1 = min(p0 + A.chunk, P);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (live)
-    for (int p = pr; p < P; p += pl) {
-      s0 += xp[(size_t)p * C + c];
-      if (A.dual) s1 += xt[(size_t)p * C + c];
+    for (int p = p0 + pr; p < p1; p += pl) {
+      const float xv = xp[(size_t)p * C + c];
+      s0 += xv; s1 += xv * xv;
+      if (A.dual) { const float dv = xt[(size_t)p * C + c]; s2 += dv; s3 += xv * dv; }
     }
-  const float mu = gn_group_sum(red, bc, live ? s0 : 0.f, tid, cl, pl, G, cpg, c) / cnt;
-  const float md = A.dual ? gn_group_sum(red, bc, live ? s1 : 0.f, tid, cl, pl, G, cpg, c) / cnt : 0.f;
-  s0 = 0.f; s1 = 0.f;
-  if (live)
-    for (int p = pr; p < P; p += pl) {
-      const float d = xp[(size_t)p * C + c] - mu;
-      s0 += d * d;
-      if (A.dual) s1 += d * (xt[(size_t)p * C + c] - md);
-    }
-  const float var = gn_group_sum(red, bc, live ? s0 : 0.f, tid, cl, pl, G, cpg, c) / cnt;
-  const float inv = rsqrtf(var + A.eps);
-  const float a = A.dual ? inv * gn_group_sum(red, bc, live ? s1 : 0.f, tid, cl, pl, G, cpg, c) / cnt : 0.f;
-  if (live && pr == 0 && (c % cpg) == 0 && A.stats) {
-    float* st = A.stats + ((size_t)b * G + c / cpg) * 4;
-    st[0] = mu; st[1] = inv; st[2] = md; st[3] = a;
+  double* dst = A.acc + (size_t)b * G * 8;
+  gn_group_atomic(red, live ? s0 : 0.f, tid, cl, pl, G, cpg, dst + 0, 8);
+  gn_group_atomic(red, live ? s1 : 0.f, tid, cl, pl, G, cpg, dst + 1, 8);
+  if (A.dual) {
+    gn_group_atomic(red, live ? s2 : 0.f, tid, cl, pl, G, cpg, dst + 2, 8);
+    gn_group_atomic(red, live ? s3 : 0.f, tid, cl, pl, G, cpg, dst + 3, 8);
   }
-  if (!live) return;
-  const float ga = A.gamma[c], be = A.beta[c];
-  float* op = A.out + (size_t)b * P * C;
-  float* ot = A.out + (size_t)(b + A.Bp) * P * C;
-  for (int p = pr; p < P; p += pl) {
-    const size_t e = (size_t)p * C + c;
-    const float xh = (xp[e] - mu) * inv;
+}
+
+__device__ __forceinline__ void gn_stats(const double* a8, double cnt, float eps, float& mu, float& inv, float& md, float& a) {
+  const double m = a8[0] / cnt;
+  double var = a8[1] / cnt - m * m;
+  if (var < 0) var = 0;
+  const double iv = 1.0 / sqrt(var + (double)eps);
+  const double d = a8[2] / cnt;
+  mu = (float)m; inv = (float)iv; md = (float)d;
+  a = (float)(iv * (a8[3] / cnt - m * d));
+}
+
+__global__ void __launch_bounds__(256) k_gn_fwd_apply(GnArgs A) {
+  const int C = A.C, P = A.P, G = A.G, cpg = C / G;
+  const long per = (long)P * C, tot = (long)A.Bp * per;
+  const double cnt = (double)P * cpg;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(e / per);
+    const int c = (int)(e % C);
+    const int g = c / cpg;
+    float mu, inv, md, a;
+    gn_stats(A.acc + ((size_t)b * G + g) * 8, cnt, A.eps, mu, inv, md, a);
+    if (A.stats && (e - (long)b * per) == (long)g * cpg) {
+      float* st = A.stats + ((size_t)b * G + g) * 4;
+      st[0] = mu; st[1] = inv; st[2] = md; st[3] = a;
+    }
+    const float ga = A.gamma[c], be = A.beta[c];
+    const float xh = (A.x[e] - mu) * inv;
     const float y = ga * xh + be;
     float yd = 0.f;
-    if (A.dual) yd = ga * (inv * ((xt[e] - md) - xh * a));
+    if (A.dual) yd = ga * (inv * ((A.x[e + tot] - md) - xh * a));
     if (A.silu) {
       float z0, z1, z2;
       silu012u(y, z0, z1, z2);
-      op[e] = z0;
-      if (A.dual) ot[e] = z1 * yd;
+      A.out[e] = z0;
+      if (A.dual) A.out[e + tot] = z1 * yd;
     } else {
-      op[e] = y;
-      if (A.dual) ot[e] = yd;
+      A.out[e] = y;
+      if (A.dual) A.out[e + tot] = yd;
     }
   }
 }
@@ -117,66 +124,81 @@ __global__ void __launch_bounds__(256) k_gn_dual_fwd(GnArgs A) {
 // its tangent what = inv (xdot_c - xhat a)):
 //   xdotbar = inv (W - mean W - xhat p),                      p = mean(xhat W)
 //   xbar    = inv (X - mean X - xhat mean(xhat X)) - inv (c xhat + a xdotbar + p what),  c = mean(W what)
-// (derived and checked against autograd in DESIGN.md §3 / tests).
-__global__ void __launch_bounds__(256) k_gn_dual_bwd(GnArgs A) {
+// (derived by hand, checked against autograd in tests/test_unet2d_gpu.py).
+__device__ __forceinline__ void gn_bwd_elem(const GnArgs& A, long e, long tot, float mu, float inv, float md, float a,
+                                            float ga, float be, float& xh, float& wh, float& zb, float& zdb) {
+  xh = (A.x[e] - mu) * inv;
+  wh = inv * ((A.x[e + tot] - md) - xh * a);
+  zb = A.gout[e]; zdb = A.gout[e + tot];
+  if (A.silu) {
+    float z0, z1, z2;
+    silu012u(ga * xh + be, z0, z1, z2);
+    const float yd = ga * wh;
+    const float nzb = zb * z1 + zdb * (z2 * yd);
+    zdb = zdb * z1;
+    zb = nzb;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_gn_bwd_reduce(GnArgs A) {
   __shared__ float red[256];
-  __shared__ float bc[64];
   const int tid = threadIdx.x, b = blockIdx.x;
   const int C = A.C, P = A.P, G = A.G, cpg = C / G;
   const int cl = C, pl = 256 / C > 0 ? 256 / C : 1;
   const bool live = tid < cl * pl;
   const int c = live ? tid % cl : 0, pr = live ? tid / cl : 0;
-  const size_t offp = (size_t)b * P * C, offt = (size_t)(b + A.Bp) * P * C;
+  const long tot = (long)A.Bp * P * C;
   const float* st = A.stats + ((size_t)b * G + c / cpg) * 4;
   const float mu = st[0], inv = st[1], md = st[2], a = st[3];
   const float ga = A.gamma[c], be = A.beta[c];
-  const float cnt = (float)P * (float)cpg;
+  const int p0 = blockIdx.y * A.chunk, p1 = min(p0 + A.chunk, P);
   float sX = 0.f, sXx = 0.f, sW = 0.f, sWx = 0.f, sWw = 0.f, dga = 0.f, dbe = 0.f;
   if (live)
-    for (int p = pr; p < P; p += pl) {
-      const size_t e = (size_t)p * C + c;
-      const float xh = (A.x[offp + e] - mu) * inv;
-      const float wh = inv * ((A.x[offt + e] - md) - xh * a);
-      float zb = A.gout[offp + e], zdb = A.gout[offt + e];
-      if (A.silu) {
-        float z0, z1, z2;
-        silu012u(ga * xh + be, z0, z1, z2);
-        const float yd = ga * wh;
-        const float nzb = zb * z1 + zdb * (z2 * yd);
-        zdb = zdb * z1;
-        zb = nzb;
-      }
+    for (int p = p0 + pr; p < p1; p += pl) {
+      const long e = ((long)b * P + p) * C + c;
+      float xh, wh, zb, zdb;
+      gn_bwd_elem(A, e, tot, mu, inv, md, a, ga, be, xh, wh, zb, zdb);
       const float X = ga * zb, W = ga * zdb;
       sX += X; sXx += X * xh; sW += W; sWx += W * xh; sWw += W * wh;
       dga += zb * xh + zdb * wh; dbe += zb;
     }
-  const float mX = gn_group_sum(red, bc, live ? sX : 0.f, tid, cl, pl, G, cpg, c) / cnt;
-  const float mXx = gn_group_sum(red, bc, live ? sXx : 0.f, tid, cl, pl, G, cpg, c) / cnt;
-  const float mW = gn_group_sum(red, bc, live ? sW : 0.f, tid, cl, pl, G, cpg, c) / cnt;
-  const float pp = gn_group_sum(red, bc, live ? sWx : 0.f, tid, cl, pl, G, cpg, c) / cnt;
-  const float cc = gn_group_sum(red, bc, live ? sWw : 0.f, tid, cl, pl, G, cpg, c) / cnt;
-  const float tg = gn_chan_sum(red, live ? dga : 0.f, tid, cl, pl, c);
-  const float tb = gn_chan_sum(red, live ? dbe : 0.f, tid, cl, pl, c);
-  if (live && pr == 0) { atomicAdd(A.dgamma + c, tg); atomicAdd(A.dbeta + c, tb); }
-  if (!live) return;
-  for (int p = pr; p < P; p += pl) {
-    const size_t e = (size_t)p * C + c;
-    const float xh = (A.x[offp + e] - mu) * inv;
-    const float wh = inv * ((A.x[offt + e] - md) - xh * a);
-    float zb = A.gout[offp + e], zdb = A.gout[offt + e];
-    if (A.silu) {
-      float z0, z1, z2;
-      silu012u(ga * xh + be, z0, z1, z2);
-      const float yd = ga * wh;
-      const float nzb = zb * z1 + zdb * (z2 * yd);
-      zdb = zdb * z1;
-      zb = nzb;
-    }
+  double* dst = A.acc + (size_t)b * G * 8;
+  gn_group_atomic(red, live ? sX : 0.f, tid, cl, pl, G, cpg, dst + 0, 8);
+  gn_group_atomic(red, live ? sXx : 0.f, tid, cl, pl, G, cpg, dst + 1, 8);
+  gn_group_atomic(red, live ? sW : 0.f, tid, cl, pl, G, cpg, dst + 2, 8);
+  gn_group_atomic(red, live ? sWx : 0.f, tid, cl, pl, G, cpg, dst + 3, 8);
+  gn_group_atomic(red, live ? sWw : 0.f, tid, cl, pl, G, cpg, dst + 4, 8);
+  // per-channel parameter gradients: sum the pixel lanes, one atomic per channel per block
+  red[tid] = live ? dga : 0.f;
+  __syncthreads();
+  if (tid < cl) { float s = 0.f; for (int p = 0; p < pl; ++p) s += red[p * cl + tid]; atomicAdd(A.dgamma + tid, s); }
+  __syncthreads();
+  red[tid] = live ? dbe : 0.f;
+  __syncthreads();
+  if (tid < cl) { float s = 0.f; for (int p = 0; p < pl; ++p) s += red[p * cl + tid]; atomicAdd(A.dbeta + tid, s); }
+}
+
+__global__ void __launch_bounds__(256) k_gn_bwd_apply(GnArgs A) {
+  const int C = A.C, P = A.P, G = A.G, cpg = C / G;
+  const long per = (long)P * C, tot = (long)A.Bp * per;
+  const float rc = 1.0f / ((float)P * (float)cpg);
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(e / per);
+    const int c = (int)(e % C);
+    const int g = c / cpg;
+    const float* st = A.stats + ((size_t)b * G + g) * 4;
+    const float mu = st[0], inv = st[1], md = st[2], a = st[3];
+    const double* a8 = A.acc + ((size_t)b * G + g) * 8;
+    const float mX = (float)a8[0] * rc, mXx = (float)a8[1] * rc, mW = (float)a8[2] * rc, pp = (float)a8[3] * rc,
+                cc = (float)a8[4] * rc;
+    const float ga = A.gamma[c], be = A.beta[c];
+    float xh, wh, zb, zdb;
+    gn_bwd_elem(A, e, tot, mu, inv, md, a, ga, be, xh, wh, zb, zdb);
     const float X = ga * zb, W = ga * zdb;
     const float xdb = inv * (W - mW - xh * pp);
     const float xb = inv * (X - mX - xh * mXx) - inv * (cc * xh + a * xdb + pp * wh);
-    A.gx[offp + e] = xb;
-    A.gx[offt + e] = xdb;
+    A.gx[e] = xb;
+    A.gx[e + tot] = xdb;
   }
 }
 
@@ -369,23 +391,47 @@ static inline hipStream_t S(msgm_stream_t s) { return reinterpret_cast<hipStream
 
 extern "C" {
 
+static int gn_chunks(int Bp, int P, int* chunk) {
+  // enough (sample, chunk) workgroups to fill 256 CUs a few times over, >= 64 pixels per chunk
+  int n = (1024 + Bp - 1) / Bp;
+  if (n < 1) n = 1;
+  int c = (P + n - 1) / n;
+  if (c < 64) c = 64;
+  if (c > P) c = P;
+  *chunk = c;
+  return (P + c - 1) / c;
+}
+
+size_t msgm_groupnorm_workspace(int32_t Bp, int32_t G) { return (size_t)Bp * (size_t)G * 8 * sizeof(double); }
+
 int msgm_groupnorm_dual_forward(const float* x, const float* gamma, const float* beta, float* out, float* stats, int32_t Bp,
-                                int32_t P, int32_t C, int32_t G, int32_t dual, int32_t silu, float eps, msgm_stream_t stream) {
-  if (!x || !gamma || !beta || !out || Bp <= 0 || P <= 0 || C <= 0 || G <= 0) return MSGM_E_BADARG;
+                                int32_t P, int32_t C, int32_t G, int32_t dual, int32_t silu, float eps, void* workspace,
+                                size_t workspace_bytes, msgm_stream_t stream) {
+  if (!x || !gamma || !beta || !out || !workspace || Bp <= 0 || P <= 0 || C <= 0 || G <= 0) return MSGM_E_BADARG;
   if (C % G || C > 256 || G > 64) return MSGM_E_UNSUPPORTED;
-  GnArgs A{x, gamma, beta, out, stats, P, C, G, Bp, dual, silu, eps, nullptr, nullptr, nullptr, nullptr};
-  hipLaunchKernelGGL(k_gn_dual_fwd, dim3(Bp), dim3(256), 0, S(stream), A);
+  if (workspace_bytes < msgm_groupnorm_workspace(Bp, G)) return MSGM_E_WORKSPACE;
+  GnArgs A{x, gamma, beta, out, reinterpret_cast<double*>(workspace), stats, P, C, G, Bp, dual, silu, 0, eps,
+           nullptr, nullptr, nullptr, nullptr};
+  if (hipMemsetAsync(workspace, 0, msgm_groupnorm_workspace(Bp, G), S(stream)) != hipSuccess) return MSGM_E_LAUNCH;
+  const int nch = gn_chunks(Bp, P, &A.chunk);
+  hipLaunchKernelGGL(k_gn_fwd_reduce, dim3(Bp, nch), dim3(256), 0, S(stream), A);
+  hipLaunchKernelGGL(k_gn_fwd_apply, dim3(grid_for((int64_t)Bp * P * C, 256)), dim3(256), 0, S(stream), A);
   return msgm_check_launch();
 }
 
 int msgm_groupnorm_dual_backward(const float* x, const float* gamma, const float* beta, const float* stats, const float* gout,
                                  float* gx, float* dgamma, float* dbeta, int32_t Bp, int32_t P, int32_t C, int32_t G,
-                                 int32_t silu, float eps, msgm_stream_t stream) {
-  if (!x || !gamma || !beta || !stats || !gout || !gx || !dgamma || !dbeta || Bp <= 0 || P <= 0 || C <= 0 || G <= 0)
+                                 int32_t silu, float eps, void* workspace, size_t workspace_bytes, msgm_stream_t stream) {
+  if (!x || !gamma || !beta || !stats || !gout || !gx || !dgamma || !dbeta || !workspace || Bp <= 0 || P <= 0 || C <= 0 || G <= 0)
     return MSGM_E_BADARG;
   if (C % G || C > 256 || G > 64) return MSGM_E_UNSUPPORTED;
-  GnArgs A{x, gamma, beta, nullptr, const_cast<float*>(stats), P, C, G, Bp, 1, silu, eps, gout, gx, dgamma, dbeta};
-  hipLaunchKernelGGL(k_gn_dual_bwd, dim3(Bp), dim3(256), 0, S(stream), A);
+  if (workspace_bytes < msgm_groupnorm_workspace(Bp, G)) return MSGM_E_WORKSPACE;
+  GnArgs A{x, gamma, beta, nullptr, reinterpret_cast<double*>(workspace), const_cast<float*>(stats), P, C, G, Bp, 1, silu, 0,
+           eps, gout, gx, dgamma, dbeta};
+  if (hipMemsetAsync(workspace, 0, msgm_groupnorm_workspace(Bp, G), S(stream)) != hipSuccess) return MSGM_E_LAUNCH;
+  const int nch = gn_chunks(Bp, P, &A.chunk);
+  hipLaunchKernelGGL(k_gn_bwd_reduce, dim3(Bp, nch), dim3(256), 0, S(stream), A);
+  hipLaunchKernelGGL(k_gn_bwd_apply, dim3(grid_for((int64_t)Bp * P * C, 256)), dim3(256), 0, S(stream), A);
   return msgm_check_launch();
 }
 

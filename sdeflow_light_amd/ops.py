@@ -321,6 +321,18 @@ def add_row(x: torch.Tensor, E: torch.Tensor, N: int, P: int, C: int, pos: int, 
 
 
 # ---------------------------------------------------------------- 2-D U-Net ops
+_GN_WS = {}
+
+
+def _gn_ws(Bp: int, G: int, device) -> torch.Tensor:
+    """Per-device scratch for the GroupNorm moment accumulators (consumed in stream order)."""
+    n = int(lib().msgm_groupnorm_workspace(Bp, G)) // 8
+    key = (torch.device(device), n)
+    if key not in _GN_WS:
+        _GN_WS[key] = torch.empty(n, dtype=torch.float64, device=device)
+    return _GN_WS[key]
+
+
 def groupnorm_dual_forward(x, gamma, beta, Bp, P, C, G, dual, silu, stats=None, out=None, eps=1e-5):
     N = 2 * Bp if dual else Bp
     if x.numel() != N * P * C or gamma.numel() != C or beta.numel() != C:
@@ -328,8 +340,10 @@ def groupnorm_dual_forward(x, gamma, beta, Bp, P, C, G, dual, silu, stats=None, 
     if stats is not None and stats.numel() != Bp * G * 4:
         raise MsgmError("groupnorm: stats must be [Bp][G][4]")
     out = torch.empty_like(x) if out is None else out
+    ws = _gn_ws(Bp, G, x.device)
     check(lib().msgm_groupnorm_dual_forward(ptr(f32(x)), ptr(f32(gamma)), ptr(f32(beta)), ptr(out), ptr(stats), Bp, P, C, G,
-                                            int(bool(dual)), int(bool(silu)), float(eps), stream()), "msgm_groupnorm_dual_forward")
+                                            int(bool(dual)), int(bool(silu)), float(eps), ptr(ws), ws.numel() * 8, stream()),
+          "msgm_groupnorm_dual_forward")
     return out
 
 
@@ -339,9 +353,10 @@ def groupnorm_dual_backward(x, gamma, beta, stats, gout, dgamma, dbeta, Bp, P, C
     if dgamma.numel() != C or dbeta.numel() != C:
         raise MsgmError("groupnorm backward: dgamma/dbeta size")
     gx = gout if gx is None else gx
+    ws = _gn_ws(Bp, G, x.device)
     check(lib().msgm_groupnorm_dual_backward(ptr(f32(x)), ptr(f32(gamma)), ptr(f32(beta)), ptr(f32(stats)), ptr(f32(gout)),
-                                             ptr(gx), ptr(dgamma), ptr(dbeta), Bp, P, C, G, int(bool(silu)), float(eps), stream()),
-          "msgm_groupnorm_dual_backward")
+                                             ptr(gx), ptr(dgamma), ptr(dbeta), Bp, P, C, G, int(bool(silu)), float(eps),
+                                             ptr(ws), ws.numel() * 8, stream()), "msgm_groupnorm_dual_backward")
     return gx
 
 
