@@ -97,14 +97,153 @@ def cpu_baseline(budget_s=12.0):
             "sample": f"{n} full C2 train steps (B=65536, MLP d=2, double-backward SSM + Adam) on the CPU oracle in {dt:.1f} s"}
 
 
+UNET_FWD_FLOP = {"c3": 0.4554e9, "c4": 5.974e9 + 9.4e6, "c5": 5.974e9 + 9.4e6}    # per sample, SURVEY.md App. A
+
+
+def build_unet(workload, dev):
+    from sdeflow_light_amd.SDEs import SGMsde, PluginReverseSDE
+    torch.manual_seed(0)
+    if workload == "c3":
+        from sdeflow_light_amd.NNUnet1D import UNet1D
+        net, d = UNet1D(input_dim=1024, base_channels=32, channel_mults=(1, 2, 4), num_res_blocks=2, emb_dim=128).to(dev), 1024
+    else:
+        from sdeflow_light_amd.NNUnet import VorticityUNet
+        net = VorticityUNet(base_channels=32, channel_mults=(1, 2, 4), num_res_blocks=2, in_space=64,
+                            attention_resolutions=(2, 4), flatten_order="F", channels=3).to(dev)
+        d = 3 * 64 * 64
+        # upstream zero-initialises every ResBlock's 2nd conv, attention proj_out and the final conv
+        # (model/nn_utils.py:151-157); random-init them so no kernel multiplies by zeros
+        with torch.no_grad():
+            for p in net.parameters():
+                if p.dim() > 1 and float(p.abs().sum()) == 0.0:
+                    p.normal_(0, 0.02)
+    T = torch.nn.Parameter(torch.FloatTensor([1.0]), requires_grad=False)
+    sde = SGMsde(beta_min=0.1, beta_max=20.0, t_epsilon=1e-3, T=T, num_steps_forward=16, device=dev)
+    return PluginReverseSDE(sde, net, T, vtype="rademacher", deviceReverseSDE=dev).to(dev), d
+
+
+def cpu_baseline_unet(workload, budget_s=15.0):
+    """CPU oracle at a reduced batch, scaled linearly to the config batch."""
+    from oracle import sde_ref as S, nets_ref as N, ssm_ref as LR
+    from oracle.det_params import det_state_dict
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_oracle_golden import unet1d_shapes, unet2d_shapes
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except Exception:
+        avail = os.cpu_count() or 1
+    torch.set_num_threads(min(avail, 16))
+    sp = S.SdeSpec()
+    if workload == "c3":
+        b, d, full = 8, 1024, 4096
+        p = det_state_dict(unet1d_shapes(1024, None))
+        score = lambda prm, yy, tt: N.unet1d_forward(prm, yy, tt, None)
+    else:
+        b, d, full = 1, 3 * 64 * 64, 256
+        cfg = N.UNet2DConfig(in_channels=3, out_channels=3, in_space=64)
+        p = det_state_dict(unet2d_shapes(cfg))
+        score = lambda prm, yy, tt: N.image_to_flat(N.unet2d_core_forward(prm, N.flat_to_image(yy, 64, 64, "F", 3), tt.reshape(-1), cfg), "F")
+    x = torch.randn(b, d)
+
+    def one():
+        t = S.clamp_time(sp, torch.rand(b, 1)); y = S.vp_perturb(sp, t, x, torch.randn(b, d))
+        v = S.rademacher_from_uniform(torch.rand(b, d))
+        LR.ssm_mean_and_grads(sp, score, p, t, y, v, form="double_backward")
+    one()
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        one(); n += 1
+    dt = (time.perf_counter() - t0) / n
+    return {"value": 1.0 / (dt * full / b), "unit": f"train_steps/s (B={full})", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} oracle train steps at batch {b} ({dt:.2f} s each, double-backward SSM, no Adam), scaled linearly to batch {full}"}
+
+
+def bench_unet(a, workload):
+    """Secondary workloads (not the driver's default line): c3 = UNet1D L=1024 B=4096/GPU (weak);
+    c4 = UNet2D 64x64x3, global batch 256 split over the ranks (strong); c5 = EM sampling with the c4 net,
+    8192 rows split over the ranks (strong), --sample-steps steps."""
+    from sdeflow_light_amd import parallel, ops, _lib as L
+    from sdeflow_light_amd.train import UNetScoreTrainer
+    from sdeflow_light_amd.data import signals_1d, random_images
+    rank, local, world = parallel.init_distributed()
+    dev = parallel.local_device(local)
+    torch.cuda.set_device(dev)
+    gen, d = build_unet(workload, dev)
+    flat, _ = gen.a.flat_parameters()
+    parallel.broadcast_(flat, 0)
+    out = {"n_gpus": world, "dtype": "f32", "data": "synthetic", "higher_is_better": True, "vs_baseline": None}
+    if workload in ("c3", "c4"):
+        B = 4096 if workload == "c3" else 256 // world
+        tr = UNetScoreTrainer(gen, B, d, lr=1e-4, world=world, seed=1 + rank)
+        tr.set_data(signals_1d(B, seed=1234 + rank, device=dev) if workload == "c3" else random_images(B, seed=1234 + rank, device=dev))
+        for _ in range(a.warmup):
+            tr.step()
+        parallel.barrier(); torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            tr.step()
+        torch.cuda.synchronize(dev); parallel.barrier()
+        dt = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+        gb = B * world
+        units = (world if workload == "c3" else 1) * a.steps          # c3 weak: B/GPU fixed; c4 strong: global 256
+        flops = 6 * UNET_FWD_FLOP[workload] * gb * a.steps
+        out.update(metric="score-matching train steps/sec", value=units / dt, steps=a.steps, warmup=a.warmup,
+                   unit=f"train_steps/s (B={4096 if workload == 'c3' else 256} per step)", ms_per_step=dt / a.steps * 1e3,
+                   scaling="weak" if workload == "c3" else "strong",
+                   config={"workload": {"c3": "C3: UNet1D L=1024, batch 4096/GPU, SGM, SSM + Adam",
+                                        "c4": "C4: UNet2D 64x64x3, global batch 256, SGM, SSM + Adam"}[workload],
+                           "global_batch": gb, "parallelism": f"dp{world}"},
+                   final_loss=float(tr.loss), algorithmic_tflops=flops / dt / 1e12,
+                   roofline={"bound": "mfma", "achieved": flops / dt / 1e12 / world, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                             "frac": flops / dt / 1e12 / world / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                             "note": "whole step, all kernels (as-written FLOPs 6 x forward)"},
+                   cpu_baseline=cpu_baseline_unet(workload) if (rank == 0 and world == 1 and not a.no_cpu_baseline) else None)
+    else:
+        rows = 8192 // world
+        chunk = min(rows, 1024)
+        st, rng = gen.base_sde.struct(), gen.base_sde.philox(dev)
+        x = gen.latent_sample(rows, d)
+        N = a.sample_steps
+        ts = torch.linspace(0, 1, N + 1)
+
+        def step(i):
+            for c0 in range(0, rows, chunk):
+                xc = x[c0:c0 + chunk]
+                s = torch.full((xc.shape[0],), 1.0 - float(ts[i]), device=dev)
+                sc = gen.a(xc, s)
+                ops.sde_stage(xc, xc, 1.0, xc, sc, st, L.PROC_REVERSE, False, float(ts[i]), 1.0 / N, 0.0, rng=rng, rng_step=i)
+        step(0)
+        parallel.barrier(); torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(N):
+            step(i)
+        torch.cuda.synchronize(dev); parallel.barrier()
+        dt = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+        flops = UNET_FWD_FLOP["c5"] * 8192 * N
+        out.update(metric="reverse-SDE sample steps/sec", value=N / dt, steps=N, warmup=1, unit="EM steps/s (8192 samples per step)",
+                   ms_per_step=dt / N * 1e3, scaling="strong",
+                   config={"workload": "C5: EM sampling, UNet2D 64x64x3, 8192 samples", "parallelism": f"dp{world}", "rows_per_gpu": rows},
+                   algorithmic_tflops=flops / dt / 1e12, sampler_finite=bool(torch.isfinite(x).all()),
+                   roofline={"bound": "mfma", "achieved": flops / dt / 1e12 / world, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                             "frac": flops / dt / 1e12 / world / PEAK_F32_MFMA_TFLOPS, "traffic": None}, cpu_baseline=None)
+    if rank == 0:
+        print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", choices=["c2", "c3", "c4", "c5"], default="c2",
+                    help="c2 (default, the driver's line): MLP d=2 B=65536; c3/c4/c5: U-Net configs of BASELINE.json")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--sample-steps", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
+    if a.workload != "c2":
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+        return bench_unet(a, a.workload)
 
     from sdeflow_light_amd import parallel, ops
     from sdeflow_light_amd.train import MLPScoreTrainer
@@ -116,8 +255,8 @@ def main():
     rank, local, world = parallel.init_distributed()
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    dev = parallel.local_device(local)
+    torch.cuda.set_device(dev)
     ops.lib()
 
     gen = build_model(dev, B_C2)

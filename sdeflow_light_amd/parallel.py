@@ -22,15 +22,21 @@ def env_world() -> Tuple[int, int, int]:
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
 
+def local_device(local: int) -> torch.device:
+    """cuda:<local rank>, wrapped onto the visible devices (several ranks may share a GPU in rehearsals)."""
+    return torch.device("cuda", local % max(torch.cuda.device_count(), 1))
+
+
 def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
     rank, local, world = env_world()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local)
+            # MSGM_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal of the N>1 path on a 1-GPU box)
+            backend = os.environ.get("MSGM_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
 
