@@ -199,30 +199,24 @@ def bench_unet(a, workload):
                              "note": "whole step, all kernels (as-written FLOPs 6 x forward)"},
                    cpu_baseline=cpu_baseline_unet(workload) if (rank == 0 and world == 1 and not a.no_cpu_baseline) else None)
     else:
+        from sdeflow_light_amd.sde_scheme import GraphedStepSampler
         rows = 8192 // world
-        chunk = min(rows, 1024)
-        st, rng = gen.base_sde.struct(), gen.base_sde.philox(dev)
-        x = gen.latent_sample(rows, d)
+        chunk = min(rows, 1024)                       # rows are independent: integrate them in chunks of 1024
         N = a.sample_steps
-        ts = torch.linspace(0, 1, N + 1)
-
-        def step(i):
-            for c0 in range(0, rows, chunk):
-                xc = x[c0:c0 + chunk]
-                s = torch.full((xc.shape[0],), 1.0 - float(ts[i]), device=dev)
-                sc = gen.a(xc, s)
-                ops.sde_stage(xc, xc, 1.0, xc, sc, st, L.PROC_REVERSE, False, float(ts[i]), 1.0 / N, 0.0, rng=rng, rng_step=i)
-        step(0)
+        gs = GraphedStepSampler(gen, chunk, d, N)     # ONE EM step captured as a hipGraph, device-side clock
+        x = gen.latent_sample(rows, d)
+        gs.run(x[:chunk])                             # warm-up replay
         parallel.barrier(); torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        for i in range(N):
-            step(i)
+        for c0 in range(0, rows, chunk):
+            x[c0:c0 + chunk].copy_(gs.run(x[c0:c0 + chunk]))
         torch.cuda.synchronize(dev); parallel.barrier()
         dt = parallel.max_over_ranks(time.perf_counter() - t0, dev)
         flops = UNET_FWD_FLOP["c5"] * 8192 * N
         out.update(metric="reverse-SDE sample steps/sec", value=N / dt, steps=N, warmup=1, unit="EM steps/s (8192 samples per step)",
                    ms_per_step=dt / N * 1e3, scaling="strong",
-                   config={"workload": "C5: EM sampling, UNet2D 64x64x3, 8192 samples", "parallelism": f"dp{world}", "rows_per_gpu": rows},
+                   config={"workload": "C5: EM sampling, UNet2D 64x64x3, 8192 samples, hipGraph-captured step", "parallelism": f"dp{world}",
+                           "rows_per_gpu": rows, "chunk": chunk},
                    algorithmic_tflops=flops / dt / 1e12, sampler_finite=bool(torch.isfinite(x).all()),
                    roofline={"bound": "mfma", "achieved": flops / dt / 1e12 / world, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                              "frac": flops / dt / 1e12 / world / PEAK_F32_MFMA_TFLOPS, "traffic": None}, cpu_baseline=None)

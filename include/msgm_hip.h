@@ -116,6 +116,7 @@ int msgm_rademacher(float* v, int64_t n, const float* u, const uint64_t* rng, ms
  *           norm (norm_correction, sde_scheme.py:85-86).
  *   dW_out / inc_out  optional (B,n): the Wiener increment actually used (RK4
  *           shares one dW across its stages, sde_scheme.py:227) / the bare inc.
+ *   t_dev / step_dev  optional device scalars overriding `t` / `rng_step` (graph replay).
  *   delta_rows  optional (B): per-row step length; then t_b = t + t_frac*delta_b
  *           and dW_b = sqrt(delta_b) z_b (the one-step RK4 of SDEs.py:112-117
  *           for rows whose stop index is 0).
@@ -128,7 +129,15 @@ int msgm_sde_stage(float* out, const float* base, float c_out,
                    int64_t B, int64_t n, const msgm_sde_t* sde, int32_t proc, int32_t strato,
                    float t, float delta, float lmbd, const float* norm0,
                    const float* delta_rows, float t_frac,
+                   const float* t_dev, const int64_t* step_dev,
                    msgm_stream_t stream);
+
+/* Device-side clock for a hipGraph-replayed sampler step: t_dev[0] = ts[*step],
+ * s_out[b] = T - t (score-net time argument).  With t_dev / step_dev passed to
+ * msgm_sde_stage (overriding `t` / `rng_step`) one captured step can be
+ * replayed for every i; msgm_counter_inc(step) closes the step. */
+int msgm_time_tick(const float* ts, const int64_t* step, int64_t n_ts, float T, float* t_dev, float* s_out,
+                   int64_t B, msgm_stream_t stream);
 
 /* K12: SSM loss reduction for a score net evaluated on a (primal | tangent)
  * stacked batch, SGM case.  `out` is [2B][n] (a = out[:B], adot = J_a v = out[B:]):

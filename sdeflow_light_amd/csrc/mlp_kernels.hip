@@ -108,48 +108,92 @@ __device__ __forceinline__ f32x4 load_afrag(const float* __restrict__ W, int w, 
 // (a k-group = 16 MFMAs = 512 cycles of matrix pipe per wave), so only
 // (PF+1) x 8 registers hold weights at any time; `pre` carries groups
 // 0..PF-1 of the NEXT gemm across the phase boundary.
+#ifndef PF
 #define PF 2
-struct WPre { f32x4 a[PF][2]; };
+#endif
+#ifndef MLP_HINTS
+#define MLP_HINTS 0
+#endif
+#ifndef MLP_SB
+#define MLP_SB 1
+#endif
+#ifndef MLP_OVL_FWD
+#define MLP_OVL_FWD 1
+#endif
+#ifndef MLP_OVL_BWD
+#define MLP_OVL_BWD 1
+#endif
+struct WPre { f32x4 a[PF]; };     // fragments j = 0..PF-1 of the next gemm (j = it*8 + g: row tile 0 first)
 
 template <bool TR>
 __device__ __forceinline__ void prefetch_w(const float* __restrict__ W, int w, int il, int q, WPre& pre) {
 #pragma unroll
-  for (int g = 0; g < PF; ++g) { pre.a[g][0] = load_afrag<TR>(W, w, il, q, 0, g); pre.a[g][1] = load_afrag<TR>(W, w, il, q, 1, g); }
+  for (int j = 0; j < PF; ++j) pre.a[j] = load_afrag<TR>(W, w, il, q, j >> 3, j & 7);
 }
 
-// acc[it][ck] += sum_k A[it][k] * buf[ck*16+il][k]   (K = 128, B operand from LDS)
-// Software-pipelined by hand: the LDS reads of group g+1 and the global loads of
-// group g+PF are issued ahead of the 16 MFMAs of group g; the sched_barrier keeps
-// hipcc from hoisting every load to the top (which spills) or sinking them.
-template <bool TR>
+// acc[it][ck] += sum_k A[it][k] * buf[ck*16+il][k]   (K = 128, B operand from LDS), row tile 0 first, then
+// row tile 1.  Software-pipelined by hand: the LDS reads of step j+1 and the global loads of step j+PF are
+// issued ahead of the 8 MFMAs of step j; sched_barrier keeps hipcc from hoisting every load (which spills).
+// HOOK: while the matrix pipe works on row tile 1, the VALU applies bias + Swish to the finished row tile 0
+// (an MFMA occupies the vector issue port for only 8 of its 32 cycles):
+//   HOOK 1 (train): h[0][0] = s(z), h[0][1] = s'(z) zdot;   HOOK 2 (inference): both column halves are primal.
+template <bool TR, int HOOK>
 __device__ __forceinline__ void gemm128(const float* __restrict__ W, const WPre& pre, const float* buf, int w, int il,
-                                        int q, f32x4 (&acc)[2][2]) {
-  f32x4 ring[PF + 1][2];
+                                        int q, f32x4 (&acc)[2][2], const float* bias_lds, f32x4 (&h)[2][2]) {
+  f32x4 ring[PF + 1];
 #pragma unroll
-  for (int g = 0; g < PF; ++g) { ring[g][0] = pre.a[g][0]; ring[g][1] = pre.a[g][1]; }
+  for (int j = 0; j < PF; ++j) ring[j] = pre.a[j];
   const float* bp0 = buf + il * ACT_P + 4 * q;
   const float* bp1 = buf + (16 + il) * ACT_P + 4 * q;
   f32x4 bn0 = *reinterpret_cast<const f32x4*>(bp0), bn1 = *reinterpret_cast<const f32x4*>(bp1);
 #pragma unroll
-  for (int g = 0; g < 8; ++g) {
+  for (int j = 0; j < 16; ++j) {
+    const int it = j >> 3;
     const f32x4 b0 = bn0, b1 = bn1;
-    if (g + PF < 8) {
-      ring[(g + PF) % (PF + 1)][0] = load_afrag<TR>(W, w, il, q, 0, g + PF);
-      ring[(g + PF) % (PF + 1)][1] = load_afrag<TR>(W, w, il, q, 1, g + PF);
+    if (j + PF < 16) ring[(j + PF) % (PF + 1)] = load_afrag<TR>(W, w, il, q, (j + PF) >> 3, (j + PF) & 7);
+    if (j + 1 < 16) {
+      bn0 = *reinterpret_cast<const f32x4*>(bp0 + 16 * ((j + 1) & 7));
+      bn1 = *reinterpret_cast<const f32x4*>(bp1 + 16 * ((j + 1) & 7));
     }
-    if (g + 1 < 8) {
-      bn0 = *reinterpret_cast<const f32x4*>(bp0 + 16 * (g + 1));
-      bn1 = *reinterpret_cast<const f32x4*>(bp1 + 16 * (g + 1));
+    if (MLP_OVL_FWD && HOOK && j == 8) {        // row tile 0 is complete: bias
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(bias_lds + 32 * w + 4 * q);
+      acc[0][0] += bb;
+      if (HOOK == 2) acc[0][1] += bb;
     }
-    const f32x4 a0 = ring[g % (PF + 1)][0], a1 = ring[g % (PF + 1)][1];
+    if (MLP_OVL_FWD && HOOK && j >= 8 && j < 12) {   // one register per step
+      const int r = j - 8;
+      if (HOOK == 1) {
+        float s0, s1, s2;
+        swish012(acc[0][0][r], s0, s1, s2);
+        h[0][0][r] = s0; h[0][1][r] = s1 * acc[0][1][r];
+      } else {
+        h[0][0][r] = swish0(acc[0][0][r]); h[0][1][r] = swish0(acc[0][1][r]);
+      }
+    }
+    const f32x4 a = ring[j % (PF + 1)];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      acc[0][0] = mfma16(a0[r], b0[r], acc[0][0]);
-      acc[0][1] = mfma16(a0[r], b1[r], acc[0][1]);
-      acc[1][0] = mfma16(a1[r], b0[r], acc[1][0]);
-      acc[1][1] = mfma16(a1[r], b1[r], acc[1][1]);
+      if (it == 0) { acc[0][0] = mfma16(a[r], b0[r], acc[0][0]); acc[0][1] = mfma16(a[r], b1[r], acc[0][1]); }
+      else { acc[1][0] = mfma16(a[r], b0[r], acc[1][0]); acc[1][1] = mfma16(a[r], b1[r], acc[1][1]); }
     }
-    __builtin_amdgcn_sched_barrier(0);
+    if (MLP_HINTS && HOOK && j >= 8 && j < 12) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x002, 6, 0); }
+    }
+    if (MLP_SB) __builtin_amdgcn_sched_barrier(0);
+  }
+  if (!MLP_OVL_FWD && HOOK) {
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(bias_lds + 32 * w + 4 * q);
+    acc[0][0] += bb;
+    if (HOOK == 2) acc[0][1] += bb;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (HOOK == 1) {
+        float s0, s1, s2;
+        swish012(acc[0][0][r], s0, s1, s2);
+        h[0][0][r] = s0; h[0][1][r] = s1 * acc[0][1][r];
+      } else { h[0][0][r] = swish0(acc[0][0][r]); h[0][1][r] = swish0(acc[0][1][r]); }
+    }
   }
 }
 
@@ -192,7 +236,63 @@ __device__ __forceinline__ void wgrad(const float* zb, const float* hb, int hb_p
       dW[0][kt] = mfma16(a0, b[kt], dW[0][kt]);
       dW[1][kt] = mfma16(a1, b[kt], dW[1][kt]);
     }
-    __builtin_amdgcn_sched_barrier(0);
+    if (MLP_SB) __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// wgrad of a 128x128 layer with the dual Swish backward of the NEXT pointwise stage hidden under its
+// MFMAs: step st of 8 also turns (gP,gT) -> (zbarP, zbarT), in place, for register (it = st>>2, r = st&3).
+template <int KT>
+__device__ __forceinline__ void wgrad_swish(const float* zbuf, const float* hb, int hb_pitch, int w, int il, int q,
+                                            f32x4 (&dW)[2][KT], const f32x4 (&z)[2][2], f32x4 (&g)[2][2]) {
+  float na0, na1, nb[KT];
+  {
+    const int n = q;
+    na0 = zbuf[n * ACT_P + 32 * w + il]; na1 = zbuf[n * ACT_P + 32 * w + 16 + il];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) nb[kt] = hb[n * hb_pitch + 16 * kt + il];
+  }
+#pragma unroll
+  for (int st = 0; st < 8; ++st) {
+    const float a0 = na0, a1 = na1;
+    float b[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) b[kt] = nb[kt];
+    if (st + 1 < 8) {
+      const int n = ((st + 1) >> 2) * 16 + 4 * ((st + 1) & 3) + q;
+      na0 = zbuf[n * ACT_P + 32 * w + il]; na1 = zbuf[n * ACT_P + 32 * w + 16 + il];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) nb[kt] = hb[n * hb_pitch + 16 * kt + il];
+    }
+    if (MLP_OVL_BWD) {
+      const int it = st >> 2, r = st & 3;
+      float s0, s1, s2;
+      swish012(z[it][0][r], s0, s1, s2);
+      const float gt = g[it][1][r];
+      g[it][0][r] = g[it][0][r] * s1 + gt * (s2 * z[it][1][r]);     // in place: g becomes (zbarP, zbarT)
+      g[it][1][r] = gt * s1;
+    }
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      dW[0][kt] = mfma16(a0, b[kt], dW[0][kt]);
+      dW[1][kt] = mfma16(a1, b[kt], dW[1][kt]);
+    }
+    if (MLP_HINTS) {
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); }
+    }
+    if (MLP_SB) __builtin_amdgcn_sched_barrier(0);
+  }
+  if (!MLP_OVL_BWD) {
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      const int it = st >> 2, r = st & 3;
+      float s0, s1, s2;
+      swish012(z[it][0][r], s0, s1, s2);
+      const float gt = g[it][1][r];
+      g[it][0][r] = g[it][0][r] * s1 + gt * (s2 * z[it][1][r]);
+      g[it][1][r] = gt * s1;
+    }
   }
 }
 
@@ -341,19 +441,18 @@ __global__ void __launch_bounds__(256, 1) k_mlp(MlpArgs A) {
     // ---- phase 2: layer 2 --------------------------------------------------
 #pragma unroll
     for (int it = 0; it < 2; ++it) { z2[it][0] = f32x4{0, 0, 0, 0}; z2[it][1] = f32x4{0, 0, 0, 0}; }
-    gemm128<false>(A.P.W2, pre, X, w, il, q, z2);
+    gemm128<false, (MODE == MODE_TRAIN ? 1 : 2)>(A.P.W2, pre, X, w, il, q, z2, B2s, h);
     prefetch_w<false>(A.P.W3, w, il, q, pre);          // head of the next gemm's weights
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const f32x4 bb = *reinterpret_cast<const f32x4*>(B2s + 32 * w + 16 * it + 4 * q);
-      z2[it][0] += bb;
-      if (MODE != MODE_TRAIN) z2[it][1] += bb;
+    {
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(B2s + 32 * w + 16 + 4 * q);
+      z2[1][0] += bb;
+      if (MODE != MODE_TRAIN) z2[1][1] += bb;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (MODE == MODE_TRAIN) {
-          float s0, s1, s2; swish012(z2[it][0][r], s0, s1, s2);
-          h[it][0][r] = s0; h[it][1][r] = s1 * z2[it][1][r];
-        } else { h[it][0][r] = swish0(z2[it][0][r]); h[it][1][r] = swish0(z2[it][1][r]); }
+          float s0, s1, s2; swish012(z2[1][0][r], s0, s1, s2);
+          h[1][0][r] = s0; h[1][1][r] = s1 * z2[1][1][r];
+        } else { h[1][0][r] = swish0(z2[1][0][r]); h[1][1][r] = swish0(z2[1][1][r]); }
       }
     }
     store_act(Y, w, il, q, h);
@@ -363,20 +462,19 @@ __global__ void __launch_bounds__(256, 1) k_mlp(MlpArgs A) {
     // ---- phase 3: layer 3, then this wave's K-slice of layer 4 -------------
 #pragma unroll
     for (int it = 0; it < 2; ++it) { z3[it][0] = f32x4{0, 0, 0, 0}; z3[it][1] = f32x4{0, 0, 0, 0}; }
-    gemm128<false>(A.P.W3, pre, Y, w, il, q, z3);
+    gemm128<false, (MODE == MODE_TRAIN ? 1 : 2)>(A.P.W3, pre, Y, w, il, q, z3, B3s, h);
     if (MODE == MODE_TRAIN) prefetch_w<true>(A.P.W3, w, il, q, pre);   // W3^T for dgrad
     else prefetch_w<false>(A.P.W2, w, il, q, pre);                     // next tile's layer 2
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const f32x4 bb = *reinterpret_cast<const f32x4*>(B3s + 32 * w + 16 * it + 4 * q);
-      z3[it][0] += bb;
-      if (MODE != MODE_TRAIN) z3[it][1] += bb;
+    {
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(B3s + 32 * w + 16 + 4 * q);
+      z3[1][0] += bb;
+      if (MODE != MODE_TRAIN) z3[1][1] += bb;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (MODE == MODE_TRAIN) {
-          float s0, s1, s2; swish012(z3[it][0][r], s0, s1, s2);
-          h[it][0][r] = s0; h[it][1][r] = s1 * z3[it][1][r];
-        } else { h[it][0][r] = swish0(z3[it][0][r]); h[it][1][r] = swish0(z3[it][1][r]); }
+          float s0, s1, s2; swish012(z3[1][0][r], s0, s1, s2);
+          h[1][0][r] = s0; h[1][1][r] = s1 * z3[1][1][r];
+        } else { h[1][0][r] = swish0(z3[1][0][r]); h[1][1][r] = swish0(z3[1][1][r]); }
       }
     }
     if (MODE == MODE_TRAIN) store_act(Z, w, il, q, h);   // h3 is the dW4 operand later
@@ -457,7 +555,7 @@ __global__ void __launch_bounds__(256, 1) k_mlp(MlpArgs A) {
       STAMP(4);
 
       // ---- phase 5: layer-4 backward, dW4, Swish' on layer 3 --------------
-      f32x4 g[2][2], zb[2][2];
+      f32x4 g[2][2];
 #pragma unroll
       for (int it = 0; it < 2; ++it) { g[it][0] = f32x4{0, 0, 0, 0}; g[it][1] = f32x4{0, 0, 0, 0}; }
       for (int s = 0; s < A.d4; ++s) {
@@ -468,34 +566,31 @@ __global__ void __launch_bounds__(256, 1) k_mlp(MlpArgs A) {
         g[0][0] = mfma16(a0, bP, g[0][0]); g[0][1] = mfma16(a0, bT, g[0][1]);
         g[1][0] = mfma16(a1, bP, g[1][0]); g[1][1] = mfma16(a1, bT, g[1][1]);
       }
-      wgrad<OT>(Z, ABAR, SM_P, w, il, q, dW4);          // dW4^T[feat][o] += h3 . abar
-      swish_bwd(z3, g, zb);
-      db3[0] += zb[0][0]; db3[1] += zb[1][0];
-      store_act(U, w, il, q, zb);
+      wgrad_swish<OT>(Z, ABAR, SM_P, w, il, q, dW4, z3, g);       // dW4^T[feat][o] += h3 . abar, Swish' hidden
+      db3[0] += g[0][0]; db3[1] += g[1][0];
+      store_act(U, w, il, q, g);
       __syncthreads();
       STAMP(5);
 
       // ---- phase 6: dgrad layer 3 (W3^T), dW3, Swish' on layer 2 -----------
 #pragma unroll
       for (int it = 0; it < 2; ++it) { g[it][0] = f32x4{0, 0, 0, 0}; g[it][1] = f32x4{0, 0, 0, 0}; }
-      gemm128<true>(A.P.W3, pre, U, w, il, q, g);
+      gemm128<true, 0>(A.P.W3, pre, U, w, il, q, g, nullptr, h);
       prefetch_w<true>(A.P.W2, w, il, q, pre);           // W2^T for the next dgrad
-      wgrad<8>(U, Y, ACT_P, w, il, q, dW3);
-      swish_bwd(z2, g, zb);
-      db2[0] += zb[0][0]; db2[1] += zb[1][0];
-      store_act(Z, w, il, q, zb);                          // h3 is dead after phase 5
+      wgrad_swish<8>(U, Y, ACT_P, w, il, q, dW3, z2, g);
+      db2[0] += g[0][0]; db2[1] += g[1][0];
+      store_act(Z, w, il, q, g);                           // h3 is dead after phase 5
       __syncthreads();
       STAMP(6);
 
       // ---- phase 7: dgrad layer 2 (W2^T), dW2, Swish' on layer 1 -----------
 #pragma unroll
       for (int it = 0; it < 2; ++it) { g[it][0] = f32x4{0, 0, 0, 0}; g[it][1] = f32x4{0, 0, 0, 0}; }
-      gemm128<true>(A.P.W2, pre, Z, w, il, q, g);
+      gemm128<true, 0>(A.P.W2, pre, Z, w, il, q, g, nullptr, h);
       prefetch_w<false>(A.P.W2, w, il, q, pre);          // next tile's layer 2
-      wgrad<8>(Z, X, ACT_P, w, il, q, dW2);
-      swish_bwd(z1, g, zb);
-      db1[0] += zb[0][0]; db1[1] += zb[1][0];
-      store_act(U, w, il, q, zb);                          // zbar3 is dead after phase 6
+      wgrad_swish<8>(Z, X, ACT_P, w, il, q, dW2, z1, g);
+      db1[0] += g[0][0]; db1[1] += g[1][0];
+      store_act(U, w, il, q, g);                           // zbar3 is dead after phase 6
       __syncthreads();
       STAMP(7);
 

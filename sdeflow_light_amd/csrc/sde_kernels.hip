@@ -22,6 +22,18 @@ __global__ void k_fill(float* __restrict__ out, int64_t n, const uint64_t* __res
   }
 }
 
+// Device-side clock of a graph-replayed sampler step: i = *step; t_dev = ts[i]; s_out[b] = T - t (the
+// reverse-time argument of the score net, SDEs.py:556-557).  The step counter itself is bumped by
+// msgm_counter_inc at the END of the step so every kernel of the step reads the same i.
+__global__ void k_time_tick(const float* __restrict__ ts, const int64_t* __restrict__ step, int64_t n_ts, float T,
+                            float* __restrict__ t_dev, float* __restrict__ s_out, int64_t B) {
+  int64_t i = step[0];
+  if (i >= n_ts) i = n_ts - 1;
+  const float t = ts[i];
+  if (blockIdx.x == 0 && threadIdx.x == 0) t_dev[0] = t;
+  for (int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; b < B; b += (int64_t)gridDim.x * blockDim.x) s_out[b] = T - t;
+}
+
 // ============================================================ K1 perturb_vp
 // t_b = clamp(u_b T) (SDEs.py:688-693), y = eps*sqrt(var(t)) + mean_weight(t)*x0
 // (SDEs.py:139-142).  One thread per element-quad of the flat (B*d) tensor.
@@ -119,11 +131,15 @@ struct StageArgs {
   float* inc_out;              // optional: the bare increment
   const float* delta_rows;     // optional per-row step length (MSGM short-time rows, SDEs.py:112-117)
   float t_frac;                // with delta_rows: t_b = t + t_frac * delta_b
+  const float* t_dev;          // optional device scalar overriding t   (graph replay: time lives on the device)
+  const int64_t* step_dev;     // optional device scalar overriding rng_step
 };
 
+__device__ __forceinline__ uint64_t stage_step(const StageArgs& A) { return A.step_dev ? (uint64_t)A.step_dev[0] : A.rng_step; }
+__device__ __forceinline__ float stage_time(const StageArgs& A) { return A.t_dev ? A.t_dev[0] : A.t; }
 __device__ __forceinline__ float stage_noise(const StageArgs& A, int64_t e, float sqrt_delta) {
   if (A.dW) return A.dW[e];
-  float zz = A.z ? A.z[e] : philox_normal1(A.rng, A.rng_step, RNG_STREAM_DW, (uint64_t)e);
+  float zz = A.z ? A.z[e] : philox_normal1(A.rng, stage_step(A), RNG_STREAM_DW, (uint64_t)e);
   return sqrt_delta * zz;                                  // delta**0.5 * randn   sde_scheme.py:84
 }
 
@@ -133,7 +149,8 @@ __device__ __forceinline__ float stage_noise(const StageArgs& A, int64_t e, floa
 __global__ void k_stage_diag_flat(StageArgs A) {
   const int64_t n = A.B * A.n;
   const int64_t nq = (n + 3) >> 2;
-  const float s = A.proc == MSGM_PROC_REVERSE ? A.T - A.t : A.t;
+  const float tnow = stage_time(A);
+  const float s = A.proc == MSGM_PROC_REVERSE ? A.T - tnow : tnow;
   const float beta = sde_beta(A.b0, A.b1, s);
   const float sb = sqrtf(beta);
   const float ca = (1.0f - 0.5f * A.lmbd);
@@ -151,7 +168,7 @@ __global__ void k_stage_diag_flat(StageArgs A) {
       if (A.base) bv = (A.base == A.x) ? xv : *reinterpret_cast<const f32x4*>(A.base + e0);
       if (A.dW) wv = *reinterpret_cast<const f32x4*>(A.dW + e0);
       else {
-        f32x4 zz = A.z ? *reinterpret_cast<const f32x4*>(A.z + e0) : philox_normal4(A.rng, A.rng_step, RNG_STREAM_DW, q);
+        f32x4 zz = A.z ? *reinterpret_cast<const f32x4*>(A.z + e0) : philox_normal4(A.rng, stage_step(A), RNG_STREAM_DW, q);
         wv = A.sqrt_delta * zz;
       }
     } else {
@@ -213,7 +230,8 @@ __global__ void k_stage_rows(StageArgs A) {
     if (live) {
       const float delta = A.delta_rows ? A.delta_rows[b] : A.delta;
       const float sqd = A.delta_rows ? sqrtf(delta) : A.sqrt_delta;
-      const float tb = A.delta_rows ? A.t + A.t_frac * delta : A.t;
+      const float tnow = stage_time(A);
+      const float tb = A.delta_rows ? tnow + A.t_frac * delta : tnow;
       const float s = A.proc == MSGM_PROC_REVERSE ? A.T - tb : tb;
       const float beta = sde_beta(A.b0, A.b1, s);
       const float sb = sqrtf(beta);
@@ -456,6 +474,13 @@ int msgm_rng_advance(uint64_t* rng, uint64_t n, msgm_stream_t stream) {
   return msgm_check_launch();
 }
 
+int msgm_time_tick(const float* ts, const int64_t* step, int64_t n_ts, float T, float* t_dev, float* s_out, int64_t B,
+                   msgm_stream_t stream) {
+  if (!ts || !step || !t_dev || !s_out || n_ts <= 0 || B <= 0) return MSGM_E_BADARG;
+  hipLaunchKernelGGL(k_time_tick, dim3(grid_for(B, 256, 256)), dim3(256), 0, S(stream), ts, step, n_ts, T, t_dev, s_out, B);
+  return msgm_check_launch();
+}
+
 int msgm_counter_inc(int64_t* ctr, msgm_stream_t stream) {
   if (!ctr) return MSGM_E_BADARG;
   hipLaunchKernelGGL(k_counter_inc, dim3(1), dim3(1), 0, S(stream), ctr);
@@ -510,7 +535,7 @@ int msgm_sde_stage(float* out, const float* base, float c_out, const float* x, c
                    const float* z, float sqrt_delta, const uint64_t* rng, uint64_t rng_step, float* dW_out,
                    float* inc_out, int64_t B, int64_t n, const msgm_sde_t* sde, int32_t proc, int32_t strato, float t,
                    float delta, float lmbd, const float* norm0, const float* delta_rows, float t_frac,
-                   msgm_stream_t stream) {
+                   const float* t_dev, const int64_t* step_dev, msgm_stream_t stream) {
   if (!out || !x || !sde || B <= 0 || n <= 0) return MSGM_E_BADARG;
   if (!dW && !z && !rng) return MSGM_E_BADARG;
   if (proc == MSGM_PROC_REVERSE && !a) return MSGM_E_BADARG;
@@ -520,7 +545,7 @@ int msgm_sde_stage(float* out, const float* base, float c_out, const float* x, c
   if (sde->kind == MSGM_SDE_MSGM_DENSE && n > 64) return MSGM_E_UNSUPPORTED;
   if (sde->kind < 0 || sde->kind > 2) return MSGM_E_BADARG;
   StageArgs A{out, base, c_out, x, a, dW, z, sqrt_delta, rng, rng_step, dW_out, B, n, sde->kind, proc, strato,
-              sde->beta_min, sde->beta_max, sde->T, t, delta, lmbd, sde->G, sde->L_G, norm0, inc_out, delta_rows, t_frac};
+              sde->beta_min, sde->beta_max, sde->T, t, delta, lmbd, sde->G, sde->L_G, norm0, inc_out, delta_rows, t_frac, t_dev, step_dev};
   if (sde->kind == MSGM_SDE_SGM && !norm0 && !delta_rows) {
     hipLaunchKernelGGL(k_stage_diag_flat, dim3(grid_for((B * n + 3) / 4, 256)), dim3(256), 0, S(stream), A);
     return msgm_check_launch();

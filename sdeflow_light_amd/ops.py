@@ -72,7 +72,8 @@ def sde_stage(out: torch.Tensor, base: Optional[torch.Tensor], c_out: float, x: 
               dW: Optional[torch.Tensor] = None, z: Optional[torch.Tensor] = None, rng: Optional[PhiloxState] = None,
               rng_step: int = 0, dW_out: Optional[torch.Tensor] = None, norm0: Optional[torch.Tensor] = None,
               inc_out: Optional[torch.Tensor] = None, delta_rows: Optional[torch.Tensor] = None,
-              t_frac: float = 0.0) -> torch.Tensor:
+              t_frac: float = 0.0, t_dev: Optional[torch.Tensor] = None,
+              step_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
     """One integrator stage (K2/K3/K4): out = base + c_out*(drift*delta + sigma.dW)."""
     if x.dim() != 2:
         raise MsgmError("state must be 2-D (B,n)")
@@ -84,7 +85,7 @@ def sde_stage(out: torch.Tensor, base: Optional[torch.Tensor], c_out: float, x: 
     check(lib().msgm_sde_stage(ptr(f32(out)), ptr(base), float(c_out), ptr(f32(x)), ptr(a), ptr(dW), ptr(z),
                                float(delta ** 0.5), _rng_ptr(rng), int(rng_step), ptr(dW_out), ptr(inc_out), B, n, sde,
                                int(proc), int(bool(strato)), float(t), float(delta), float(lmbd), ptr(norm0),
-                               ptr(delta_rows), float(t_frac), stream()),
+                               ptr(delta_rows), float(t_frac), ptr(t_dev), ptr(step_dev), stream()),
           "msgm_sde_stage")
     return out
 
@@ -147,6 +148,11 @@ def adam_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor
             raise MsgmError(f"{nm} has {tt.numel()} elements, expected {n}")
     check(lib().msgm_adam_step(ptr(f32(p)), ptr(f32(g)), ptr(f32(m)), ptr(f32(v)), n, lr, beta1, beta2, eps,
                                float(gscale), int(step), ptr(step_dev), stream()), "msgm_adam_step")
+
+
+def time_tick(ts: torch.Tensor, step: torch.Tensor, T: float, t_dev: torch.Tensor, s_out: torch.Tensor):
+    check(lib().msgm_time_tick(ptr(f32(ts)), ptr(step), ts.numel(), float(T), ptr(f32(t_dev)), ptr(f32(s_out)), s_out.numel(),
+                               stream()), "msgm_time_tick")
 
 
 def counter_inc(ctr: torch.Tensor):

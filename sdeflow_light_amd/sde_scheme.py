@@ -267,3 +267,61 @@ class GraphedEMSampler:
         self.x.copy_(x_0)
         self.graph.replay()
         return self.x
+
+
+class GraphedStepSampler:
+    """Euler–Maruyama with ANY HIP score net (U-Nets): ONE step — device clock tick, score-net forward (hundreds
+    of kernels), fused stage kernel, step-counter bump — is captured as a hipGraph and replayed num_steps times.
+    The time grid (fp32 ``linspace`` as upstream, sde_scheme.py:59) and the step index live on the device, so the
+    replays need no host scalar (the reference does ``ts[i].item()`` + ``fill_`` every step, sde_scheme.py:81)."""
+
+    def __init__(self, sde, B, n, num_steps, lmbd=0.0, norm_correction=False):
+        from .SDEs import PluginReverseSDE
+        if not isinstance(sde, PluginReverseSDE):
+            raise MsgmError("GraphedStepSampler integrates a PluginReverseSDE")
+        base = sde.base_sde
+        dev = sde.T.device
+        self.sde, self.N, self.B, self.n = sde, num_steps, B, n
+        T = base.T_float()
+        self.ts = (torch.linspace(0, 1, num_steps + 1) * T).to(dev)
+        self.step = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.t_dev = torch.zeros(1, device=dev)
+        self.s = torch.zeros(B, device=dev)
+        self.x = torch.zeros(B, n, device=dev)
+        self.other = torch.zeros(B, n, device=dev) if base.kind != L.SDE_SGM else None
+        self.norm0 = torch.zeros(B, device=dev) if norm_correction else None
+        self.rng = base.philox(dev)
+        st, delta = base.struct(), T / num_steps
+        self._keep = st
+        inplace = base.kind == L.SDE_SGM
+
+        def body():
+            ops.time_tick(self.ts, self.step, T, self.t_dev, self.s)
+            a = sde.a(self.x, self.s).contiguous()
+            out = self.x if inplace else self.other
+            ops.sde_stage(out, self.x, 1.0, self.x, a, st, L.PROC_REVERSE, False, 0.0, delta, lmbd, rng=self.rng,
+                          norm0=self.norm0, t_dev=self.t_dev, step_dev=self.step)
+            if not inplace:
+                self.x.copy_(out)
+            ops.counter_inc(self.step)
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            body()                                   # warm-up outside capture
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            body()
+
+    @torch.no_grad()
+    def run(self, x_0):
+        self.x.copy_(x_0)
+        if self.norm0 is not None:
+            self.norm0.copy_(ops.row_norm(self.x))
+        self.step.zero_()
+        for _ in range(self.N):
+            self.graph.replay()
+        self.rng.advance(self.N)
+        return self.x

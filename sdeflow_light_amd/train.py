@@ -37,7 +37,9 @@ class MLPScoreTrainer:
         self.step_dev = torch.zeros(1, dtype=torch.int64, device=self.dev)
         self.rng = L.PhiloxState(seed * 1000003 + 17, self.dev)
         self.ws = ops.mlp_ssm_workspace(self.d, net.pre is not None, self.dev)
-        self.loss = torch.zeros(1, dtype=torch.float32, device=self.dev)
+        # ONE all-reduce bucket per step: [flat gradient | mean loss]
+        self.gbuf = torch.zeros(self.n + 1, dtype=torch.float32, device=self.dev)
+        self.gflat, self.loss = self.gbuf[: self.n], self.gbuf[self.n:]
         self.x = torch.zeros(batch_local, self.d, dtype=torch.float32, device=self.dev)
         self.y = torch.empty_like(self.x)
         self.t = torch.empty(batch_local, dtype=torch.float32, device=self.dev)
@@ -70,8 +72,7 @@ class MLPScoreTrainer:
         else:
             ops.check(lib.msgm_mlp_ssm_reduce(self.d, pre, self.ws.data_ptr(), nsl.value, self.inv_batch,
                                               self.gflat.data_ptr(), self.loss.data_ptr(), s), "msgm_mlp_ssm_reduce")
-            parallel.allreduce_sum_(self.gflat)   # grads already carry 1/global_batch
-            parallel.allreduce_sum_(self.loss)
+            parallel.allreduce_sum_(self.gbuf)    # grads and loss already carry 1/global_batch
             ops.adam_step(self.flat, self.gflat, self.m, self.v, step=0, lr=self.lr, step_dev=self.step_dev)
             self.rng.advance(1)
 
@@ -113,6 +114,7 @@ class UNetScoreTrainer:
         self.B, self.d, self.world, self.lr = batch_local, dim, world, lr
         self.flat, self.gflat = net.flat_parameters()
         self.m, self.v = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
+        self.gbuf = torch.zeros(self.flat.numel() + 1, dtype=torch.float32, device=self.dev)   # [grads | loss] for N>1
         self.step_dev = torch.zeros(1, dtype=torch.int64, device=self.dev)
         self.rng = L.PhiloxState(seed * 1000003 + 29, self.dev)
         self.x = torch.zeros(batch_local, dim, dtype=torch.float32, device=self.dev)
@@ -132,9 +134,12 @@ class UNetScoreTrainer:
         per = self.net.ssm_grad(self.y, self.t, self.vp, self.st, self.inv_batch)
         self.flat, self.gflat = self.net.flat_parameters()
         self.loss = per.sum() * self.inv_batch
-        if self.world > 1:
-            parallel.allreduce_sum_(self.gflat)
-            parallel.allreduce_sum_(self.loss)
-        ops.adam_step(self.flat, self.gflat, self.m, self.v, step=0, lr=self.lr, step_dev=self.step_dev)
+        g = self.gflat
+        if self.world > 1:                       # ONE collective: flat gradient bucket + the loss scalar
+            n = self.gflat.numel()
+            self.gbuf[:n].copy_(self.gflat); self.gbuf[n:].copy_(self.loss.reshape(1))
+            parallel.allreduce_sum_(self.gbuf)
+            g, self.loss = self.gbuf[:n], self.gbuf[n]
+        ops.adam_step(self.flat, g, self.m, self.v, step=0, lr=self.lr, step_dev=self.step_dev)
         self.rng.advance(1)
         return self.loss

@@ -183,3 +183,22 @@ def test_unet2d_ssm_vs_oracle_32():
     flat = torch.cat([pp.grad.reshape(-1).cpu() for _, pp in gen.a.named_parameters()])
     ref = torch.cat([gref[k].reshape(-1) for k, _ in gen.a.named_parameters()])
     assert rel_l2(flat, ref) <= 1e-3, rel_l2(flat, ref)
+
+
+def test_graphed_step_sampler_unet2d_equals_eager():
+    """C5 path: one hipGraph-captured EM step (device-side clock) replayed N times == the eager integrator."""
+    from sdeflow_light_amd import sde_scheme as SS
+    from test_host_gpu import make_gen
+    torch.manual_seed(0)
+    net = _vunet(16, "F")
+    gen = make_gen("sgm", net)
+    B, n, N = 6, 256, 5
+    x0 = torch.randn(B, n, device=DEV)
+    gs = SS.GraphedStepSampler(gen, B, n, N)
+    st = gen.base_sde.rng.state.clone()
+    a = gs.run(x0).clone()
+    gen.base_sde.rng.state.copy_(st)
+    b = SS.euler_maruyama_sampler(gen, x0, num_steps=N, keep_all_samples=False)
+    assert rel_l2(a.cpu(), b) <= 1e-5, rel_l2(a.cpu(), b)
+    c = gs.run(x0).clone()
+    assert not torch.equal(a, c) and torch.isfinite(c).all()
