@@ -292,7 +292,7 @@ def main():
         import ctypes as C
         lib = ops.lib()
         nsl = C.c_int32(0)
-        fn = lambda: ops.check(lib.msgm_mlp_ssm_partial(tr.P, tr.y.data_ptr(), tr.t.data_ptr(), tr.vp.data_ptr(), B_C2,
+        fn = lambda: ops.check(lib.msgm_mlp_ssm_partial(tr.P, tr.y.data_ptr(), tr.t.data_ptr(), tr.vp.data_ptr(), None, None, B_C2,
                                                         tr.st, tr.inv_batch, None, tr.ws.data_ptr(), tr.ws.numel() * 4,
                                                         C.byref(nsl), ops.stream()), "partial")
         tk = time_kernel_events(fn, 50, dev)

@@ -147,6 +147,18 @@ int msgm_time_tick(const float* ts, const int64_t* step, int64_t n_ts, float T, 
 int msgm_ssm_loss_diag(const float* out, const float* v, const float* t, float* per, float* g,
                        int64_t B, int64_t n, const msgm_sde_t* sde, float inv_batch, msgm_stream_t stream);
 
+/* u = (d mu_to_div / d a)^T v and the a-independent constant of the SSM loss
+ * (SDEs.py:560-561,631-642) for the three SDE families — with them
+ *   loss_b = adot.u + cst + 1/2 |a|^2       (adot = J_a v):
+ *   SGM: u = sqrt(beta) v, cst = 1/2 beta |v|^2;
+ *   MSGM: u_k = sqrt(beta) sum_ij G_ijk y_j v_i (sparse: c sqrt(beta) (v_k y_{k+1} - v_{k+1} y_k)), cst = 0. */
+int msgm_ssm_terms(const float* y, const float* v, const float* t, float* u, float* cst, int64_t B, int64_t n,
+                   const msgm_sde_t* sde, msgm_stream_t stream);
+/* K12, general form: per[b] = adot.u + cst + 1/2|a|^2; g = [a ; u] * inv_batch, with
+ * `out` the (primal | tangent) stacked net output [2B][n]. */
+int msgm_ssm_loss(const float* out, const float* u, const float* cst, float* per, float* g, int64_t B, int64_t n,
+                  float inv_batch, msgm_stream_t stream);
+
 /* out = c0*a + c1*b + c2*c (b, c may be NULL): stage points of Heun / RK4
  * (x + K/2, sde_scheme.py:148,234,240,246). */
 int msgm_lincomb(float* out, const float* a, float c0, const float* b, float c1,
@@ -209,6 +221,9 @@ int msgm_mlp_em_step(const msgm_mlp_params_t* P, float* x, int64_t B, const msgm
  *   per sample: a = MLP(y,t), adot = J_a v (forward-mode), loss_b =
  *   sqrt(beta) v.adot + 1/2 beta |v|^2 + 1/2 |a|^2, then the backward pass of
  *   mean_b(loss_b) w.r.t. every parameter, all inside one persistent kernel.
+ * u (B,d), cst (B): optional general form of the loss from msgm_ssm_terms
+ * (loss_b = adot.u + cst + 1/2|a|^2) — required for the MSGM families, NULL
+ * selects the SGM closed form above.
  * Inputs y,t,v are (B,d),(B),(B,d).  Outputs: grads (flat, layout =
  * [W1,b1,W2,b2,W3,b3,W4,b4], n_params floats), loss_per (B, optional),
  * loss_sum (1 float, optional).  inv_batch scales the mean (1/global batch).
@@ -217,6 +232,7 @@ int msgm_mlp_em_step(const msgm_mlp_params_t* P, float* x, int64_t B, const msgm
 size_t msgm_mlp_ssm_workspace(int32_t d, int32_t premodule);
 int64_t msgm_mlp_num_params(int32_t d, int32_t premodule);
 int msgm_mlp_ssm_grad(const msgm_mlp_params_t* P, const float* y, const float* t, const float* v,
+                      const float* u, const float* cst,
                       int64_t B, const msgm_sde_t* sde, float inv_batch,
                       float* grads, float* loss_per, float* loss_sum,
                       void* workspace, size_t workspace_bytes, msgm_stream_t stream);
@@ -226,6 +242,7 @@ int msgm_mlp_ssm_grad(const msgm_mlp_params_t* P, const float* y, const float* t
  * per-workgroup gradient slabs into the workspace; n_slabs is a HOST int) and
  * the deterministic slab reduction. */
 int msgm_mlp_ssm_partial(const msgm_mlp_params_t* P, const float* y, const float* t, const float* v,
+                         const float* u, const float* cst,
                          int64_t B, const msgm_sde_t* sde, float inv_batch, float* loss_per,
                          void* workspace, size_t workspace_bytes, int32_t* n_slabs_host,
                          msgm_stream_t stream);

@@ -343,8 +343,9 @@ class VorticityUNet(nn.Module, FlatParamMixin):
 
     # ------------------------------------------------------------------ training
     @torch.no_grad()
-    def ssm_grad(self, y, t, v, sde_struct, inv_batch):
-        """Per-sample SSM loss (B,), SGM base SDE; gradients of sum_b loss_b*inv_batch into .grad."""
+    def ssm_grad(self, y, t, v, u, cst, inv_batch):
+        """Per-sample SSM loss (B,) in the general form loss_b = adot.u + cst + |a|^2/2 (u, cst from
+        ``msgm_ssm_terms``: any SDE family); gradients of sum_b loss_b*inv_batch into .grad."""
         B, d = y.shape
         N = 2 * B
         S_, Cc = self.in_space, self.channels
@@ -366,7 +367,7 @@ class VorticityUNet(nn.Module, FlatParamMixin):
         tt = t.reshape(-1).contiguous().float()
         out = self._run(img, tt, N, B, True, tape)
         a_flat = ops.image_to_flat(out, N, Cc, S_, S_, forder, float(scale_image))      # [2B][d]: a | adot
-        per, g = ops.ssm_loss_diag(a_flat.view(-1), v.contiguous().float(), tt, sde_struct, inv_batch)
+        per, g = ops.ssm_loss(a_flat.view(-1), u, cst, inv_batch)
         gimg = ops.flat_to_image(g.view(N, d), N, Cc, S_, S_, forder, float(scale_image))   # adjoint of (x5, unflatten)
         self._backward(tape, gimg, N, B)
         for op in x["all"]:

@@ -160,9 +160,10 @@ class UNet1D(nn.Module, FlatParamMixin):
 
     # ------------------------------------------------------------------ training
     @torch.no_grad()
-    def ssm_grad(self, y: torch.Tensor, t: torch.Tensor, v: torch.Tensor, sde_struct, inv_batch: float):
-        """Per-sample SSM loss (B,) for the SGM base SDE; d(sum_b loss_b * inv_batch)/d(params) is
-        written into ``.grad`` (the flat gradient bucket)."""
+    def ssm_grad(self, y: torch.Tensor, t: torch.Tensor, v: torch.Tensor, u: torch.Tensor, cst: torch.Tensor,
+                 inv_batch: float):
+        """Per-sample SSM loss (B,) in the general form loss_b = adot.u + cst + |a|^2/2 (u, cst from
+        ``msgm_ssm_terms``: any SDE family); d(sum_b loss_b * inv_batch)/d(params) is written into ``.grad``."""
         B, L = y.shape
         N = 2 * B
         flat, gflat = self.flat_parameters()
@@ -176,7 +177,7 @@ class UNet1D(nn.Module, FlatParamMixin):
         tape = []
         h0 = torch.cat([y.contiguous().float(), v.contiguous().float()], 0).reshape(-1)
         out = self._run(h0, t.reshape(-1).contiguous().float(), N, B, L, True, tape)
-        per, g = ops.ssm_loss_diag(out, v.contiguous().float(), t.reshape(-1).contiguous().float(), sde_struct, inv_batch)
+        per, g = ops.ssm_loss(out, u, cst, inv_batch)
         self._backward(tape, g, N, B)
         for op in o.values():
             op.unpack_grads()

@@ -369,20 +369,19 @@ class PluginReverseSDE(nn.Module):
             t = u.reshape(-1, 1) * T
             m = (t <= base.t_epsilon).float()
             t = m * base.t_epsilon + (1. - m) * t
-            return t, x, base.sample(t, x)
+            nm, ns = eps if isinstance(eps, (tuple, list)) else (None, None)     # (noise_main, noise_short)
+            return t, x, base.sample(t, x, noise_main=nm, noise_short=ns)
         rng = None if (u is not None and eps is not None) else base.philox(x.device)
         y, t = ops.perturb_vp(x.contiguous(), base.struct(), u=u, eps=eps, rng=rng)
         return t.reshape(-1, 1), x, y
 
-    def ssm(self, x, u=None, eps=None, u_v=None):
+    def ssm(self, x, u=None, eps=None, u_v=None, y=None, t_given=None):
         """Per-sample SSM loss (B,), gradients of its mean accumulated into the
         score net's ``.grad`` (see class docstring).  ``u``/``eps``/``u_v``
         inject the three draws of SDEs.py:688,141,515 (parity tests)."""
         from .NN import MLP
         base = self.base_sde
         net = self.a
-        if base.kind != L.SDE_SGM:
-            raise MsgmError("fused SSM training is built for SGMsde in this round (MSGM training is next, DESIGN.md)")
         if not (isinstance(net, MLP) or hasattr(net, "ssm_grad")):
             raise MsgmError(f"no HIP SSM path for score net {type(net).__name__}")
         if self.vtype != 'rademacher' and u_v is None:
@@ -391,28 +390,38 @@ class PluginReverseSDE(nn.Module):
         B, d = x.shape
         dev = x.device
         rng = base.philox(dev)
-        t, _, y = self.sample_txy(x, u=u, eps=eps)
+        if y is None:
+            t, _, y = self.sample_txy(x, u=u, eps=eps)
+        else:                                        # (t, y) given: the ssm_loss(t_, x, y) entry of the reference
+            t = t_given.reshape(-1, 1).contiguous().float()
+            y = y.contiguous().float()
         v = ops.rademacher((B, d), dev, u=u_v, rng=None if u_v is not None else rng)
-        if u is None or eps is None or u_v is None:
+        if u_v is None or (t_given is None and (u is None or eps is None)):
             rng.advance(1)
+        st = base.struct()
+        uu = cst = None
+        if base.kind != L.SDE_SGM or not isinstance(net, MLP):
+            # general form of the loss: loss_b = adot.u + cst + |a|^2/2 (u = G(y)^T v for the multiplicative SDE)
+            uu, cst = ops.ssm_terms(y, v, t.reshape(-1).contiguous(), st)
         flat, gflat = net.flat_parameters()
         if isinstance(net, MLP):
             if self._ws is None or self._ws.device != dev:
                 self._ws = ops.mlp_ssm_workspace(d, net.pre is not None, dev)
             per = torch.empty(B, dtype=torch.float32, device=dev)
             gtmp = torch.empty_like(gflat)
-            ops.mlp_ssm_grad(net.kernel_params(), y, t.reshape(-1), v, base.struct(), 1.0 / B, gtmp, self._ws, loss_per=per)
+            ops.mlp_ssm_grad(net.kernel_params(), y, t.reshape(-1), v, st, 1.0 / B, gtmp, self._ws, loss_per=per, u=uu, cst=cst)
         else:
             # U-Nets: dual-number forward + hand-written backward; the net writes its flat .grad bucket
             keep = gflat.clone()
-            per = net.ssm_grad(y, t.reshape(-1), v, base.struct(), 1.0 / B)
+            per = net.ssm_grad(y, t.reshape(-1), v, uu, cst, 1.0 / B)
             flat, gflat = net.flat_parameters()
             gtmp = gflat.clone()
             gflat.copy_(keep)
         return _SSMGradBridge.apply(per, gtmp, gflat, net, B, next(net.parameters()))
 
-    def ssm_loss(self, t_, x, y, v=None):
-        raise MsgmError("ssm_loss(t,x,y) with autograd double-backward is replaced by the fused forward-mode kernel; use ssm(x)")
+    def ssm_loss(self, t_, x, y, u_v=None):
+        """Reference entry point (SDEs.py:616-646) with (t, y) given: same fused forward-mode kernels as ``ssm``."""
+        return self.ssm(x, u_v=u_v, y=y, t_given=t_)
 
     def latent_sample(self, num_samples, n):
         return self.base_sde.latent_sample(num_samples, n)

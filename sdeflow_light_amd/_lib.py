@@ -87,11 +87,13 @@ SIGNATURES = {
     "msgm_mlp_em_step": (C.c_int, [C.POINTER(MlpParamsT), _P, _I64, C.POINTER(SdeT), _F, _F, _F, _P, _P, _U64, _P]),
     "msgm_mlp_ssm_workspace": (_SZ, [_I32, _I32]),
     "msgm_mlp_num_params": (_I64, [_I32, _I32]),
-    "msgm_mlp_ssm_partial": (C.c_int, [C.POINTER(MlpParamsT), _P, _P, _P, _I64, C.POINTER(SdeT), _F, _P, _P, _SZ,
+    "msgm_mlp_ssm_partial": (C.c_int, [C.POINTER(MlpParamsT), _P, _P, _P, _P, _P, _I64, C.POINTER(SdeT), _F, _P, _P, _SZ,
                                        C.POINTER(C.c_int32), _P]),
     "msgm_mlp_ssm_reduce": (C.c_int, [_I32, _I32, _P, _I32, _F, _P, _P, _P]),
     "msgm_mlp_ssm_reduce_adam": (C.c_int, [_I32, _I32, _P, _I32, _F, _P, _P, _P, _P, _P, _D, _D, _D, _D, _P, _P, _P]),
-    "msgm_mlp_ssm_grad": (C.c_int, [C.POINTER(MlpParamsT), _P, _P, _P, _I64, C.POINTER(SdeT), _F, _P, _P, _P, _P, _SZ, _P]),
+    "msgm_mlp_ssm_grad": (C.c_int, [C.POINTER(MlpParamsT), _P, _P, _P, _P, _P, _I64, C.POINTER(SdeT), _F, _P, _P, _P, _P, _SZ, _P]),
+    "msgm_ssm_terms": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, C.POINTER(SdeT), _P]),
+    "msgm_ssm_loss": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _F, _P]),
 }
 
 _lib: Optional[C.CDLL] = None

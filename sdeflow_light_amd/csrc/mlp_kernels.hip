@@ -67,6 +67,8 @@ struct MlpArgs {
   const float* y;        // (B,d) inputs (x_t for the sampler)
   const float* t;        // (B) per-sample time, or null => t_scalar
   const float* v;        // (B,d) probe (train)
+  const float* u;        // (B,d) optional: cotangent direction of adot, loss_b = adot.u + cst + |a|^2/2 (MSGM); null => SGM closed form
+  const float* cst;      // (B) optional per-sample constant of the loss
   float* out;            // forward: a (B,d); EM: x updated in place (== y)
   int64_t B;
   int in_dim, in4, d4;   // in_dim = d + 1 (+1 with premodule); in4 = ceil(in/4); d4 = ceil(d/4)
@@ -535,20 +537,30 @@ __global__ void __launch_bounds__(256, 1) k_mlp(MlpArgs A) {
         const bool live = smp < A.B;
         const float wgt = live ? A.inv_batch : 0.f;
         float beta = 0.f, sb = 0.f;
-        if (live) { beta = sde_beta(A.b0, A.b1, A.t[smp]); sb = sqrtf(beta); }
+        if (live && !A.u) { beta = sde_beta(A.b0, A.b1, A.t[smp]); sb = sqrtf(beta); }
         float lj = 0.f;
         for (int o = 0; o < d; ++o) {
           float a = B4s[o], ad = 0.f;
 #pragma unroll
           for (int ww = 0; ww < 4; ++ww) { a += PART[(ww * 32 + tid) * SM_P + o]; ad += PART[(ww * 32 + 16 + tid) * SM_P + o]; }
-          const float vo = live ? A.v[smp * d + o] : 0.f;
-          // loss_b = sum_o v_o (sqrt(beta) adot_o + 1/2 beta v_o) + 1/2 a_o^2     SDEs.py:631-646
-          lj += vo * (sb * ad + 0.5f * beta * vo) + 0.5f * a * a;
-          const float ab = a * wgt, adb = sb * vo * wgt;
+          float adb;
+          if (A.u) {
+            // general form: loss_b = sum_o adot_o u_o + cst_b + 1/2 a_o^2, u = (d mu/d a)^T v  (MSGM: G(y)^T v)
+            const float uo = live ? A.u[smp * d + o] : 0.f;
+            lj += ad * uo + 0.5f * a * a;
+            adb = uo * wgt;
+          } else {
+            const float vo = live ? A.v[smp * d + o] : 0.f;
+            // SGM: loss_b = sum_o v_o (sqrt(beta) adot_o + 1/2 beta v_o) + 1/2 a_o^2     SDEs.py:631-646
+            lj += vo * (sb * ad + 0.5f * beta * vo) + 0.5f * a * a;
+            adb = sb * vo * wgt;
+          }
+          const float ab = a * wgt;
           ABAR[tid * SM_P + o] = ab;
           ABAR[(16 + tid) * SM_P + o] = adb;
           DB4[tid * DPAD + o] += ab;
         }
+        if (live && A.u && A.cst) lj += A.cst[smp];
         if (live) { loss_acc += lj; if (A.loss_per) A.loss_per[smp] = lj; }
       }
       __syncthreads();
@@ -777,16 +789,16 @@ int msgm_mlp_em_step(const msgm_mlp_params_t* P, float* x, int64_t B, const msgm
   return launch_mlp<MODE_EM>(A, (int)(tiles < MLP_MAX_GRID ? tiles : MLP_MAX_GRID), S(stream));
 }
 
-int msgm_mlp_ssm_partial(const msgm_mlp_params_t* P, const float* y, const float* t, const float* v, int64_t B,
-                         const msgm_sde_t* sde, float inv_batch, float* loss_per, void* workspace,
-                         size_t workspace_bytes, int32_t* n_slabs, msgm_stream_t stream) {
+int msgm_mlp_ssm_partial(const msgm_mlp_params_t* P, const float* y, const float* t, const float* v, const float* u,
+                         const float* cst, int64_t B, const msgm_sde_t* sde, float inv_batch, float* loss_per,
+                         void* workspace, size_t workspace_bytes, int32_t* n_slabs, msgm_stream_t stream) {
   MlpArgs A{};
   int rc = fill_common(A, P, B);
   if (rc) return rc;
   if (!y || !t || !v || !sde || !workspace || !n_slabs) return MSGM_E_BADARG;
-  if (sde->kind != MSGM_SDE_SGM) return MSGM_E_UNSUPPORTED;
+  if (sde->kind != MSGM_SDE_SGM && !u) return MSGM_E_UNSUPPORTED;      // MSGM needs u = G(y)^T v (msgm_ssm_terms)
   if (workspace_bytes < msgm_mlp_ssm_workspace(P->d, P->premodule)) return MSGM_E_WORKSPACE;
-  A.y = y; A.t = t; A.v = v;
+  A.y = y; A.t = t; A.v = v; A.u = u; A.cst = cst;
   A.b0 = sde->beta_min; A.b1 = sde->beta_max; A.T = sde->T;
   A.inv_batch = inv_batch; A.loss_per = loss_per; A.slabs = reinterpret_cast<float*>(workspace);
   A.n_params = msgm_mlp_num_params(P->d, P->premodule);
@@ -819,12 +831,12 @@ int msgm_mlp_ssm_reduce_adam(int32_t d, int32_t premodule, const void* workspace
   return msgm_check_launch();
 }
 
-int msgm_mlp_ssm_grad(const msgm_mlp_params_t* P, const float* y, const float* t, const float* v, int64_t B,
-                      const msgm_sde_t* sde, float inv_batch, float* grads, float* loss_per, float* loss_sum,
-                      void* workspace, size_t workspace_bytes, msgm_stream_t stream) {
+int msgm_mlp_ssm_grad(const msgm_mlp_params_t* P, const float* y, const float* t, const float* v, const float* u,
+                      const float* cst, int64_t B, const msgm_sde_t* sde, float inv_batch, float* grads, float* loss_per,
+                      float* loss_sum, void* workspace, size_t workspace_bytes, msgm_stream_t stream) {
   if (!grads) return MSGM_E_BADARG;
   int32_t n_slabs = 0;
-  int rc = msgm_mlp_ssm_partial(P, y, t, v, B, sde, inv_batch, loss_per, workspace, workspace_bytes, &n_slabs, stream);
+  int rc = msgm_mlp_ssm_partial(P, y, t, v, u, cst, B, sde, inv_batch, loss_per, workspace, workspace_bytes, &n_slabs, stream);
   if (rc) return rc;
   return msgm_mlp_ssm_reduce(P->d, P->premodule, workspace, n_slabs, inv_batch, grads, loss_sum, stream);
 }

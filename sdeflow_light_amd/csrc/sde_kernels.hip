@@ -356,6 +356,80 @@ __global__ void k_ssm_loss_diag(const float* __restrict__ out, const float* __re
   }
 }
 
+// u = (d mu_to_div / d a)^T v and the a-independent constant of the SSM loss, for the three SDE families:
+//   mu_to_div = G(t,y) a - f + 1/2 divSigma (SDEs.py:560-561,631-632); along v its derivative is
+//   G(y) adot + [G(v) a] + d(-f + 1/2 divSigma).v, so loss_b = adot.u + cst + 1/2|a|^2 with
+//   SGM  : u = sqrt(beta) v,                    cst = 1/2 beta |v|^2
+//   MSGM : u_k = sqrt(beta) sum_ij G_ijk y_j v_i, cst = 0   (-f + 1/2 divSigma == 0; v^T G(v) a == 0 since
+//          every G[:,:,k] is skew-symmetric — upstream carries that term as rounding noise only)
+//   sparse: u_k = c sqrt(beta) (v_k y_{k+1} - v_{k+1} y_k)   (entries of SDEs.py:369-383)
+template <int GS>
+__global__ void k_ssm_terms(const float* __restrict__ y, const float* __restrict__ v, const float* __restrict__ t,
+                            float* __restrict__ u, float* __restrict__ cst, int64_t B, int64_t n, int kind, float b0,
+                            float b1, const float* __restrict__ G) {
+  const int lane = threadIdx.x & (GS - 1);
+  const int64_t gpb = blockDim.x / GS;
+  const int64_t gid = blockIdx.x * gpb + threadIdx.x / GS;
+  const int64_t gstride = (int64_t)gridDim.x * gpb;
+  const int64_t rows_pad = ((B + gstride - 1) / gstride) * gstride;
+  const float cV = 0.5f * sqrtf(2.0f);
+  for (int64_t b = gid; b < rows_pad; b += gstride) {
+    float acc = 0.f;
+    if (b < B) {
+      const float beta = sde_beta(b0, b1, t[b]);
+      const float sb = sqrtf(beta);
+      const float* yr = y + b * n;
+      const float* vr = v + b * n;
+      for (int64_t k = lane; k < n; k += GS) {
+        float uk;
+        if (kind == MSGM_SDE_SGM) {
+          uk = sb * vr[k];
+          acc += 0.5f * beta * vr[k] * vr[k];
+        } else if (kind == MSGM_SDE_MSGM_SPARSE) {
+          const int64_t kp = (k + 1 == n) ? 0 : k + 1;
+          uk = (cV * sb) * (vr[k] * yr[kp] - vr[kp] * yr[k]);
+        } else {
+          float s = 0.f;
+          for (int64_t i = 0; i < n; ++i) {
+            float r = 0.f;
+            for (int64_t j = 0; j < n; ++j) r += G[(i * n + j) * n + k] * yr[j];
+            s += r * vr[i];
+          }
+          uk = sb * s;
+        }
+        u[b * n + k] = uk;
+      }
+    }
+#pragma unroll
+    for (int o = GS >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, GS);
+    if (b < B && lane == 0) cst[b] = acc;
+  }
+}
+
+// generic K12: per[b] = adot.u + cst + 1/2|a|^2 ; g[:B] = a w ; g[B:] = u w      (out = [a ; adot] stacked)
+template <int GS>
+__global__ void k_ssm_loss_generic(const float* __restrict__ out, const float* __restrict__ u, const float* __restrict__ cst,
+                                   float* __restrict__ per, float* __restrict__ g, int64_t B, int64_t n, float w) {
+  const int lane = threadIdx.x & (GS - 1);
+  const int64_t gpb = blockDim.x / GS;
+  const int64_t gid = blockIdx.x * gpb + threadIdx.x / GS;
+  const int64_t gstride = (int64_t)gridDim.x * gpb;
+  const int64_t rows_pad = ((B + gstride - 1) / gstride) * gstride;
+  for (int64_t b = gid; b < rows_pad; b += gstride) {
+    float acc = 0.f;
+    if (b < B)
+      for (int64_t i = lane; i < n; i += GS) {
+        const float a = out[b * n + i], ad = out[(B + b) * n + i], ui = u[b * n + i];
+        acc += ad * ui + 0.5f * a * a;
+        g[b * n + i] = a * w;
+        g[(B + b) * n + i] = ui * w;
+      }
+#pragma unroll
+    for (int o = GS >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, GS);
+    if (b < B && lane == 0) per[b] = acc + cst[b];
+  }
+}
+
 // out = c0*a + c1*b + c2*c (b, c optional) — glue for Heun / RK4 stage points
 __global__ void k_lincomb(float* __restrict__ out, const float* __restrict__ a, float c0, const float* __restrict__ b,
                           float c1, const float* __restrict__ c, float c2, int64_t n) {
@@ -590,6 +664,34 @@ int msgm_ssm_loss_diag(const float* out, const float* v, const float* t, float* 
       case 32: hipLaunchKernelGGL(k_ssm_loss_diag<32>, dim3(grid), dim3(block), 0, S(stream), out, v, t, per, g, B, n, sde->beta_min, sde->beta_max, inv_batch); break;
       default: hipLaunchKernelGGL(k_ssm_loss_diag<64>, dim3(grid), dim3(block), 0, S(stream), out, v, t, per, g, B, n, sde->beta_min, sde->beta_max, inv_batch); break;
     }
+  });
+}
+
+#define ROWS_DISPATCH(KERNEL, ...)                                                                              \
+  switch (gs) {                                                                                                  \
+    case 2: hipLaunchKernelGGL(KERNEL<2>, dim3(grid), dim3(block), 0, S(stream), __VA_ARGS__); break;           \
+    case 4: hipLaunchKernelGGL(KERNEL<4>, dim3(grid), dim3(block), 0, S(stream), __VA_ARGS__); break;           \
+    case 8: hipLaunchKernelGGL(KERNEL<8>, dim3(grid), dim3(block), 0, S(stream), __VA_ARGS__); break;           \
+    case 16: hipLaunchKernelGGL(KERNEL<16>, dim3(grid), dim3(block), 0, S(stream), __VA_ARGS__); break;         \
+    case 32: hipLaunchKernelGGL(KERNEL<32>, dim3(grid), dim3(block), 0, S(stream), __VA_ARGS__); break;         \
+    default: hipLaunchKernelGGL(KERNEL<64>, dim3(grid), dim3(block), 0, S(stream), __VA_ARGS__); break;         \
+  }
+
+int msgm_ssm_terms(const float* y, const float* v, const float* t, float* u, float* cst, int64_t B, int64_t n,
+                   const msgm_sde_t* sde, msgm_stream_t stream) {
+  if (!y || !v || !t || !u || !cst || !sde || B <= 0 || n <= 0) return MSGM_E_BADARG;
+  if (sde->kind < 0 || sde->kind > 2) return MSGM_E_BADARG;
+  if (sde->kind == MSGM_SDE_MSGM_DENSE && (!sde->G || n > 64)) return sde->G ? MSGM_E_UNSUPPORTED : MSGM_E_BADARG;
+  return launch_rows(B, n, [&](int gs, int grid, int block) {
+    ROWS_DISPATCH(k_ssm_terms, y, v, t, u, cst, B, n, sde->kind, sde->beta_min, sde->beta_max, sde->G)
+  });
+}
+
+int msgm_ssm_loss(const float* out, const float* u, const float* cst, float* per, float* g, int64_t B, int64_t n,
+                  float inv_batch, msgm_stream_t stream) {
+  if (!out || !u || !cst || !per || !g || B <= 0 || n <= 0) return MSGM_E_BADARG;
+  return launch_rows(B, n, [&](int gs, int grid, int block) {
+    ROWS_DISPATCH(k_ssm_loss_generic, out, u, cst, per, g, B, n, inv_batch)
   });
 }
 

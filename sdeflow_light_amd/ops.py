@@ -202,9 +202,31 @@ def mlp_ssm_workspace(d: int, premodule: bool, device) -> torch.Tensor:
     return torch.empty(nbytes // 4, dtype=torch.float32, device=device)
 
 
+def ssm_terms(y: torch.Tensor, v: torch.Tensor, t: torch.Tensor, sde: L.SdeT):
+    """(u (B,n), cst (B)): loss_b = adot.u + cst + |a|^2/2 for any SDE family."""
+    B, n = y.shape
+    if tuple(v.shape) != (B, n) or t.numel() != B:
+        raise MsgmError("ssm_terms: y, v (B,n) and t (B)")
+    u, cst = torch.empty_like(y), torch.empty(B, dtype=torch.float32, device=y.device)
+    check(lib().msgm_ssm_terms(ptr(f32(y)), ptr(f32(v)), ptr(f32(t)), ptr(u), ptr(cst), B, n, sde, stream()), "msgm_ssm_terms")
+    return u, cst
+
+
+def ssm_loss(out: torch.Tensor, u: torch.Tensor, cst: torch.Tensor, inv_batch: float):
+    B, n = u.shape
+    if out.numel() != 2 * B * n or cst.numel() != B:
+        raise MsgmError("ssm_loss: out must be [2B][n]")
+    per = torch.empty(B, dtype=torch.float32, device=u.device)
+    g = torch.empty(2 * B * n, dtype=torch.float32, device=u.device)
+    check(lib().msgm_ssm_loss(ptr(f32(out)), ptr(f32(u)), ptr(f32(cst)), ptr(per), ptr(g), B, n, float(inv_batch), stream()),
+          "msgm_ssm_loss")
+    return per, g
+
+
 def mlp_ssm_grad(P: L.MlpParamsT, y: torch.Tensor, t: torch.Tensor, v: torch.Tensor, sde: L.SdeT, inv_batch: float,
                  grads: torch.Tensor, workspace: torch.Tensor, loss_per: Optional[torch.Tensor] = None,
-                 loss_sum: Optional[torch.Tensor] = None):
+                 loss_sum: Optional[torch.Tensor] = None, u: Optional[torch.Tensor] = None,
+                 cst: Optional[torch.Tensor] = None):
     B, d = y.shape
     if d != P.d:
         raise MsgmError(f"input has d={d}, the MLP was built for d={P.d}")
@@ -214,7 +236,9 @@ def mlp_ssm_grad(P: L.MlpParamsT, y: torch.Tensor, t: torch.Tensor, v: torch.Ten
     _same_shape(loss_per, (B,), "loss_per")
     if grads.numel() != mlp_num_params(d, bool(P.premodule)):
         raise MsgmError("grads bucket has the wrong size")
-    check(lib().msgm_mlp_ssm_grad(P, ptr(f32(y)), ptr(f32(t)), ptr(f32(v)), B, sde, float(inv_batch), ptr(f32(grads)),
+    _same_shape(u, (B, d), "u")
+    _same_shape(cst, (B,), "cst")
+    check(lib().msgm_mlp_ssm_grad(P, ptr(f32(y)), ptr(f32(t)), ptr(f32(v)), ptr(u), ptr(cst), B, sde, float(inv_batch), ptr(f32(grads)),
                                   ptr(loss_per), ptr(loss_sum), ptr(workspace), workspace.numel() * 4, stream()),
           "msgm_mlp_ssm_grad")
 

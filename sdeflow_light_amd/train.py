@@ -60,7 +60,7 @@ class MLPScoreTrainer:
         ops.check(lib.msgm_ssm_prep(self.x.data_ptr(), self.y.data_ptr(), self.t.data_ptr(), self.vp.data_ptr(), self.B,
                                     self.d, self.st, self.rng.ptr(), self.step_dev.data_ptr(), s), "msgm_ssm_prep")
         nsl = C.c_int32(0)
-        ops.check(lib.msgm_mlp_ssm_partial(self.P, self.y.data_ptr(), self.t.data_ptr(), self.vp.data_ptr(), self.B,
+        ops.check(lib.msgm_mlp_ssm_partial(self.P, self.y.data_ptr(), self.t.data_ptr(), self.vp.data_ptr(), None, None, self.B,
                                            self.st, self.inv_batch, None, self.ws.data_ptr(), self.ws.numel() * 4,
                                            C.byref(nsl), s), "msgm_mlp_ssm_partial")
         pre = int(self.net.pre is not None)
@@ -131,7 +131,8 @@ class UNetScoreTrainer:
         lib, s = ops.lib(), ops.stream()
         ops.check(lib.msgm_ssm_prep(self.x.data_ptr(), self.y.data_ptr(), self.t.data_ptr(), self.vp.data_ptr(), self.B,
                                     self.d, self.st, self.rng.ptr(), self.step_dev.data_ptr(), s), "msgm_ssm_prep")
-        per = self.net.ssm_grad(self.y, self.t, self.vp, self.st, self.inv_batch)
+        u, cst = ops.ssm_terms(self.y, self.vp, self.t, self.st)
+        per = self.net.ssm_grad(self.y, self.t, self.vp, u, cst, self.inv_batch)
         self.flat, self.gflat = self.net.flat_parameters()
         self.loss = per.sum() * self.inv_batch
         g = self.gflat

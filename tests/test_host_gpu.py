@@ -303,3 +303,61 @@ def test_unet1d_sampler_runs_and_matches_oracle():
     p = {k: v.cpu() for k, v in net.state_dict().items()}
     ref = S.euler_maruyama(S.ReverseProcess(S.SdeSpec(), lambda y, s: N.unet1d_forward(p, y, s)), x0, 6, z)
     assert rel_l2(xs, ref) <= 1e-4, rel_l2(xs, ref)
+
+
+# ------------------------------------------------------------------ multiplicative SDE training (MSGM)
+@pytest.mark.parametrize("tag,kind,d,pre", [("sp", "sparse", 6, "NormalizeLogRadius"), ("dn", "dense", 4, None)])
+def test_ssm_msgm_mlp_golden(tag, kind, d, pre):
+    """SSM loss + parameter gradients for the multiplicative SDE (u = G(y)^T v) vs the reference (g14)."""
+    from sdeflow_light_amd.NN import MLP
+    g = load_golden("g14_ssm_msgm")
+    gen = make_gen(kind, MLP(d, premodule=pre), g, tag + "::", nsf=4, n=d, G=g.get("dn_G") if kind == "dense" else None)
+    gen.zero_grad()
+    per = gen.ssm_loss(g[tag + "_t"].to(DEV), g[tag + "_y"].to(DEV), g[tag + "_y"].to(DEV), u_v=g[tag + "_u_v"].to(DEV))
+    assert rel_l2(per.detach().cpu(), g[tag + "_per"]) <= 2e-5, rel_l2(per.detach().cpu(), g[tag + "_per"])
+    per.mean().backward()
+    for k, p in gen.named_parameters():
+        if p.requires_grad:
+            assert rel_l2(p.grad.cpu(), g[f"{tag}_grad::{k}"]) <= 3e-4, (k, rel_l2(p.grad.cpu(), g[f"{tag}_grad::{k}"]))
+
+
+def test_ssm_msgm_end_to_end_runs():
+    """ssm(x) for MSGM: device-resident RK4 perturbation + probe + fused kernel, Philox noise; loss finite, grads flow."""
+    from sdeflow_light_amd.NN import MLP
+    from sdeflow_light_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    gen = make_gen("sparse", MLP(6, premodule="NormalizeLogRadius"), n=6, nsf=8)
+    opt = FusedAdam(gen.parameters(), lr=1e-3)
+    x = torch.randn(256, 6, device=DEV)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = gen.ssm(x).mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(abs(l) < 1e6 and l == l for l in losses) and len(set(losses)) == 3
+
+
+def test_ssm_unet1d_msgm_sparse_vs_oracle():
+    """U-Net + multiplicative SDE through the general (u, cst) loss form, against the CPU oracle."""
+    from test_oracle_golden import unet1d_shapes
+    from oracle import sde_ref as S, nets_ref as N, ssm_ref as LR
+    from oracle.det_params import det_state_dict
+    torch.manual_seed(0)
+    L_ = 64
+    net = _unet1d(L_)
+    gen = make_gen("sparse", net, n=L_, nsf=4)
+    B = 3
+    t, y, uv = torch.rand(B, 1).clamp_min(1e-3), torch.randn(B, L_), torch.rand(B, L_)
+    gen.zero_grad()
+    per = gen.ssm_loss(t.to(DEV), y.to(DEV), y.to(DEV), u_v=uv.to(DEV))
+    per.mean().backward()
+    sp = S.SdeSpec(kind=S.MSGM_SPARSE, n=L_)
+    p = det_state_dict(unet1d_shapes(L_, None))
+    score = lambda prm, yy, tt: N.unet1d_forward(prm, yy, tt, None)
+    loss, per_ref, gref = LR.ssm_mean_and_grads(sp, score, p, t, y, S.rademacher_from_uniform(uv))
+    assert rel_l2(per.detach().cpu(), per_ref) <= 1e-4, rel_l2(per.detach().cpu(), per_ref)
+    flat = torch.cat([pp.grad.reshape(-1).cpu() for _, pp in gen.a.named_parameters()])
+    ref = torch.cat([gref[k].reshape(-1) for k, _ in gen.a.named_parameters()])
+    assert rel_l2(flat, ref) <= 1e-3, rel_l2(flat, ref)

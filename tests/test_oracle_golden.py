@@ -353,3 +353,17 @@ def test_g13_misc():
     r_T = torch.log(torch.linalg.norm(g["lat_xinit"], dim=1) + 1e-6)
     close(r_T, g["lat_rT"], 1e-7)
     close(S.msgm_latent(g["lat_rT"], g["lat_u"], g["lat_z"], log_map=True), g["lat_x0"], 1e-6)
+
+
+@pytest.mark.parametrize("tag,kind,d,pre", [("sp", S.MSGM_SPARSE, 6, "NormalizeLogRadius"), ("dn", S.MSGM_DENSE, 4, None)])
+@pytest.mark.parametrize("form", ["jvp", "double_backward"])
+def test_g14_ssm_msgm(tag, kind, d, pre, form):
+    g = load_golden("g14_ssm_msgm")
+    sp = spec(kind, n=d, num_steps_forward=4, G=g.get("dn_G") if kind == S.MSGM_DENSE else None)
+    p = {k[2:]: v for k, v in g.sub(tag + "::").items() if k.startswith("a.")}
+    v = S.rademacher_from_uniform(g[tag + "_u_v"])
+    score = lambda prm, yy, tt: N.mlp_forward(prm, yy, tt, pre)
+    loss, per, grads = L.ssm_mean_and_grads(sp, score, p, g[tag + "_t"], g[tag + "_y"], v, form=form)
+    close(per, g[tag + "_per"], 1e-5)
+    for k, gr in grads.items():
+        close(gr, g[f"{tag}_grad::a.{k}"], 5e-5)

@@ -395,6 +395,36 @@ def g10_ssm():
     save("g10_ssm_unets", **out)
 
 
+def g14_ssm_msgm():
+    """SSM loss of the multiplicative SDE (sparse + dense tensor) with an MLP: ssm_loss(t, x, y) with the
+    probe draw forced (SDEs.py:616-646)."""
+    torch.manual_seed(14)
+    out = {}
+    B = 48
+    for tag, d, dense, pre in (("sp", 6, False, "NormalizeLogRadius"), ("dn", 4, True, None)):
+        net = MLP(d, premodule=pre)
+        base = msgm(torch.randn(64, d) * 1.5, dense=dense, nsf=4)
+        rev = PluginReverseSDE(base, net, Tparam())
+        t_ = torch.rand(B, 1).clamp_min(1e-3)
+        y = torch.randn(B, d) * 1.3
+        u_v = torch.rand(B, d)
+        o = torch.rand
+        torch.rand = lambda *a, **k: u_v.clone()
+        try:
+            rev.zero_grad()
+            yy = y.clone().requires_grad_(True)
+            per = rev.ssm_loss(t_, y, yy)
+            per.mean().backward()
+        finally:
+            torch.rand = o
+        out.update({f"{tag}::" + k: v for k, v in sd_np(rev.state_dict()).items()})
+        out.update({f"{tag}_t": t_, f"{tag}_y": y, f"{tag}_u_v": u_v, f"{tag}_per": per.detach()})
+        out.update({f"{tag}_grad::" + k: p.grad.detach().clone() for k, p in rev.named_parameters() if p.grad is not None})
+        if dense:
+            out["dn_G"] = base.G
+    save("g14_ssm_msgm", **out)
+
+
 def g11_train3():
     torch.manual_seed(11)
     B, d, steps = 128, 2, 3

@@ -30,7 +30,7 @@ for vi, flags in enumerate(variants):
         st = _lib.sde_struct(0, 0.1, 20.0, 1.0, 1e-3)
         ws = torch.empty(int(L.msgm_mlp_ssm_workspace(d, 0)) // 4, device=dev)
         nsl = C.c_int32(0)
-        run = lambda: L.msgm_mlp_ssm_partial(P, y.data_ptr(), t.data_ptr(), v.data_ptr(), B, st, 1.0 / B, None, ws.data_ptr(),
+        run = lambda: L.msgm_mlp_ssm_partial(P, y.data_ptr(), t.data_ptr(), v.data_ptr(), None, None, B, st, 1.0 / B, None, ws.data_ptr(),
                                              ws.numel() * 4, C.byref(nsl), torch.cuda.current_stream().cuda_stream)
         for _ in range(5):
             assert run() == 0
