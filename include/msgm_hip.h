@@ -266,14 +266,15 @@ typedef struct {
   int32_t mode, ups;
 } msgm_conv_geom_t;
 
-/* out[m][co] (+)= sum_tap sum_c in[src(m,tap)][c] Wp[tap][co][c] (+ bias[co] + samp_bias[n][co] for n < n_bias).
+/* out[m][co] (+)= sum_tap sum_c in[src(m,tap)][c] Wp[tap][co][c] (+ bias[co] for n < n_bias, + samp_bias[n][co] for n < n_samp:
+ * the per-sample embedding bias; n_samp = N when the embedding itself carries a tangent).
  * Up to two inputs are concatenated along channels without materialising the
  * concat (src1 may be NULL).  Wp is the packed weight [taps][CoutP][Ktot]
  * (msgm_pack_weight; CoutP multiple of 16, each source's channels padded to 16).
  * A Linear layer is the 1x1 case with H = W = 1. */
 int msgm_conv_forward(const msgm_conv_geom_t* geom, const float* src0, int32_t C0, const float* src1, int32_t C1,
                       const float* Wp, int32_t Cout, int32_t CoutP, int32_t Ktot, const float* bias,
-                      const float* samp_bias, int32_t n_bias, float* out, int32_t accumulate,
+                      const float* samp_bias, int32_t n_bias, int32_t n_samp, float* out, int32_t accumulate,
                       msgm_stream_t stream);
 
 /* dWp[tap][co][koff + c] += sum_m gy[m][co] in[src(m,tap)][c] (float atomics across

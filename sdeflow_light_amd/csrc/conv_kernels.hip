@@ -41,8 +41,8 @@ struct ConvArgs {
   const float* Wp;            // [taps][CoutP][Ktot], zero padded
   int Cout, CoutP, Ktot;
   const float* bias;          // [Cout] or null          (rows n < n_bias only)
-  const float* samp_bias;     // [n_bias][Cout] or null   (rows n < n_bias only)
-  int n_bias;
+  const float* samp_bias;     // [n_samp][Cout] or null   (rows n < n_samp only)
+  int n_bias, n_samp;
   float* out;                 // [N][Ho][Wo][Cout]
   int accumulate;             // out += result (fused residual / skip add)
 };
@@ -64,7 +64,11 @@ __device__ __forceinline__ bool src_coord(const ConvGeom& g, int o, int k, int i
   return true;
 }
 
-template <int MT, int NT>
+// FAST: every source has C % 16 == 0 (no channel predicate, pure 16-B loads).  The inner loop is kept lean on
+// purpose — with 32 MFMAs (1024 matrix-pipe cycles) per iteration the vector ALU must stay well below that:
+// pointers advance by constants, the 3-deep fragment pipeline is unrolled by 3 (no register rotation), and all
+// index arithmetic happens once per (tap, source) segment.
+template <int MT, int NT, bool FAST>
 __global__ void __launch_bounds__(256) k_conv_gemm(ConvArgs A) {
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, il = lane & 15, q = lane >> 4;
   const ConvGeom g = A.g;
@@ -100,50 +104,60 @@ __global__ void __launch_bounds__(256) k_conv_gemm(ConvArgs A) {
   for (int s = 0; s < CONV_MAX_SRC; ++s) { groups[s] = s < A.nsrc ? (A.C[s] + 15) >> 4 : 0; per_tap += groups[s]; }
   const int total = taps * per_tap;
 
-  // ---- loader state (runs PF iterations ahead of the MFMAs) ----------------
-  int l_tap = 0, l_s = 0, l_g = 0;
+  // ---- loader state (runs two iterations ahead of the MFMAs) ----------------
+  int l_tap = 0, l_s = 0, g_left = 0, cb = 4 * q, Cseg = 0;
+  bool done = total == 0;
+  const float* ap = nullptr;
   const float* bptr[NT];
   bool bval[NT];
-  auto setup = [&](int tap, int s) {
-    const int kh = tap / g.KW, kw = tap - kh * g.KW;
-    const int C = A.C[s];
+  const size_t a_mt_stride = (size_t)16 * A.Ktot;
+  const float* a_lane = A.Wp + (size_t)(co0 + il) * A.Ktot + 4 * q;
+  auto begin_segment = [&]() {
+    const int kh = l_tap / g.KW, kw = l_tap - kh * g.KW;
+    Cseg = A.C[l_s];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       int ih = 0, iw = 0;
-      const bool ok = pin[nt] && src_coord(g, poh[nt], kh, Hup, g.strideH, g.padH, ih) && src_coord(g, pow_[nt], kw, Wup, g.strideW, g.padW, iw);
+      const bool ok = pin[nt] && src_coord(g, poh[nt], kh, Hup, g.strideH, g.padH, ih) &&
+                      src_coord(g, pow_[nt], kw, Wup, g.strideW, g.padW, iw);
       bval[nt] = ok;
-      bptr[nt] = A.src[s] + ((size_t)(pn[nt] * g.Hi + ih) * g.Wi + iw) * C;
+      bptr[nt] = A.src[l_s] + ((size_t)(pn[nt] * g.Hi + ih) * g.Wi + iw) * Cseg + 4 * q;
     }
+    ap = a_lane + (size_t)l_tap * A.CoutP * A.Ktot + A.koff[l_s];
+    g_left = groups[l_s];
+    cb = 4 * q;
   };
-  setup(0, 0);
+  if (!done) begin_segment();
   auto load = [&](f32x4 (&fa)[MT], f32x4 (&fb)[NT]) {
-    if (l_tap < taps) {
-      const int C = A.C[l_s];
-      const int cb = 16 * l_g + 4 * q;
-      const float* wp = A.Wp + ((size_t)(l_tap * A.CoutP + co0 + il) * A.Ktot + A.koff[l_s] + cb);
+    if (!done) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) fa[mt] = *reinterpret_cast<const f32x4*>(wp + (size_t)16 * mt * A.Ktot);
-      if ((C & 3) == 0) {
+      for (int mt = 0; mt < MT; ++mt) fa[mt] = *reinterpret_cast<const f32x4*>(ap + mt * a_mt_stride);
+      if (FAST) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) fb[nt] = bval[nt] ? *reinterpret_cast<const f32x4*>(bptr[nt]) : f32x4{0, 0, 0, 0};
+      } else if ((Cseg & 3) == 0) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          fb[nt] = (bval[nt] && cb < C) ? *reinterpret_cast<const f32x4*>(bptr[nt] + cb) : f32x4{0, 0, 0, 0};
+          fb[nt] = (bval[nt] && cb < Cseg) ? *reinterpret_cast<const f32x4*>(bptr[nt]) : f32x4{0, 0, 0, 0};
       } else {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           f32x4 v = {0, 0, 0, 0};
           if (bval[nt]) {
-            if (cb + 0 < C) v[0] = bptr[nt][cb + 0];
-            if (cb + 1 < C) v[1] = bptr[nt][cb + 1];
-            if (cb + 2 < C) v[2] = bptr[nt][cb + 2];
-            if (cb + 3 < C) v[3] = bptr[nt][cb + 3];
+            if (cb + 0 < Cseg) v[0] = bptr[nt][0];
+            if (cb + 1 < Cseg) v[1] = bptr[nt][1];
+            if (cb + 2 < Cseg) v[2] = bptr[nt][2];
+            if (cb + 3 < Cseg) v[3] = bptr[nt][3];
           }
           fb[nt] = v;
         }
       }
-      if (++l_g == groups[l_s]) {
-        l_g = 0;
+      ap += 16; cb += 16;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bptr[nt] += 16;
+      if (--g_left == 0) {
         if (++l_s == A.nsrc) { l_s = 0; ++l_tap; }
-        if (l_tap < taps) setup(l_tap, l_s);
+        if (l_tap < taps) begin_segment(); else done = true;
       }
     } else {
 #pragma unroll
@@ -152,22 +166,22 @@ __global__ void __launch_bounds__(256) k_conv_gemm(ConvArgs A) {
       for (int nt = 0; nt < NT; ++nt) fb[nt] = f32x4{0, 0, 0, 0};
     }
   };
-
-  f32x4 a0[MT], b0[NT], a1[MT], b1[NT], a2[MT], b2[NT];
-  load(a0, b0);
-  load(a1, b1);
-  for (int it = 0; it < total; ++it) {
-    load(a2, b2);
+  auto mma = [&](const f32x4 (&fa)[MT], const f32x4 (&fb)[NT]) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16c(a0[mt][r], b0[nt][r], acc[mt][nt]);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) { a0[mt] = a1[mt]; a1[mt] = a2[mt]; }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) { b0[nt] = b1[nt]; b1[nt] = b2[nt]; }
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16c(fa[mt][r], fb[nt][r], acc[mt][nt]);
+  };
+
+  f32x4 a0[MT], b0[NT], a1[MT], b1[NT], a2[MT], b2[NT];
+  load(a0, b0);
+  load(a1, b1);
+  for (int it = 0; it < total; it += 3) {       // iterations past `total` multiply zero fragments
+    load(a2, b2); mma(a0, b0);
+    load(a0, b0); mma(a1, b1);
+    load(a1, b1); mma(a2, b2);
   }
 
   // ---- epilogue: lane (position il of tile nt, q) holds channels co0+16mt+4q+r
@@ -187,7 +201,7 @@ __global__ void __launch_bounds__(256) k_conv_gemm(ConvArgs A) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) if (co + r < A.Cout) v[r] += A.bias[co + r];
       }
-      if (primal && A.samp_bias) {
+      if (A.samp_bias && pn[nt] < A.n_samp) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) if (co + r < A.Cout) v[r] += A.samp_bias[(size_t)pn[nt] * A.Cout + co + r];
       }
@@ -238,35 +252,39 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(WgradArgs A) {
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) acc[mt][kt] = f32x4{0, 0, 0, 0};
 
-  // the four waves interleave groups of 4 positions
+  // the four waves interleave groups of 4 positions; (n, oh, ow) of this lane's position advance by 16 per
+  // iteration with carries instead of two integer divisions per step
+  int m = mbeg + 4 * w + q;
+  int n = m / HoWo, oh, ow;
+  { const int r = m - n * HoWo; oh = r / g.Wo; ow = r - oh * g.Wo; }
+  const float* gyp[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) gyp[mt] = A.gy + (size_t)m * A.Cout + co0 + 16 * mt + il;
+  bool vco[MT], vc[KT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) vco[mt] = co0 + 16 * mt + il < A.Cout;
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) vc[kt] = c0 + 16 * kt + il < A.C;
+  const size_t gy_step = (size_t)16 * A.Cout;
   for (int mg = mbeg + 4 * w; mg < mend; mg += 16) {     // wave-uniform trip count
-    const int m = mg + q;
     const bool pin = m < mend;
     float a[MT], b[KT];
     int ih = 0, iw = 0;
-    bool ok = false;
-    int n = 0;
-    if (pin) {
-      n = m / HoWo;
-      const int r = m - n * HoWo;
-      const int oh = r / g.Wo, ow = r - oh * g.Wo;
-      ok = src_coord(g, oh, kh, Hup, g.strideH, g.padH, ih) && src_coord(g, ow, kw, Wup, g.strideW, g.padW, iw);
-    }
+    const bool ok = pin && src_coord(g, oh, kh, Hup, g.strideH, g.padH, ih) && src_coord(g, ow, kw, Wup, g.strideW, g.padW, iw);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int co = co0 + 16 * mt + il;
-      a[mt] = (pin && co < A.Cout) ? A.gy[(size_t)m * A.Cout + co] : 0.f;
-    }
-    const float* sp = A.src + ((size_t)(n * g.Hi + ih) * g.Wi + iw) * A.C;
+    for (int mt = 0; mt < MT; ++mt) a[mt] = (pin && vco[mt]) ? *gyp[mt] : 0.f;
+    const float* sp = A.src + ((size_t)(n * g.Hi + ih) * g.Wi + iw) * A.C + c0 + il;
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-      const int c = c0 + 16 * kt + il;
-      b[kt] = (ok && c < A.C) ? sp[c] : 0.f;
-    }
+    for (int kt = 0; kt < KT; ++kt) b[kt] = (ok && vc[kt]) ? sp[16 * kt] : 0.f;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) acc[mt][kt] = mfma16c(a[mt], b[kt], acc[mt][kt]);
+    m += 16; ow += 16;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) gyp[mt] += gy_step;
+    while (ow >= g.Wo) { ow -= g.Wo; ++oh; }
+    while (oh >= g.Ho) { oh -= g.Ho; ++n; }
   }
   // cross-wave sum, then one atomic per element per workgroup
 #pragma unroll
@@ -438,7 +456,8 @@ extern "C" {
 
 int msgm_conv_forward(const msgm_conv_geom_t* geom, const float* src0, int32_t C0, const float* src1, int32_t C1,
                       const float* Wp, int32_t Cout, int32_t CoutP, int32_t Ktot, const float* bias,
-                      const float* samp_bias, int32_t n_bias, float* out, int32_t accumulate, msgm_stream_t stream) {
+                      const float* samp_bias, int32_t n_bias, int32_t n_samp, float* out, int32_t accumulate,
+                      msgm_stream_t stream) {
   int rc = check_geom(geom);
   if (rc) return rc;
   if (!src0 || !Wp || !out || C0 <= 0 || Cout <= 0 || (src1 && C1 <= 0)) return MSGM_E_BADARG;
@@ -450,17 +469,21 @@ int msgm_conv_forward(const msgm_conv_geom_t* geom, const float* src0, int32_t C
   A.src[1] = src1; A.C[1] = src1 ? C1 : 0; A.koff[1] = k0;
   A.nsrc = src1 ? 2 : 1;
   A.Wp = Wp; A.Cout = Cout; A.CoutP = CoutP; A.Ktot = Ktot;
-  A.bias = bias; A.samp_bias = samp_bias; A.n_bias = n_bias; A.out = out; A.accumulate = accumulate;
+  A.bias = bias; A.samp_bias = samp_bias; A.n_bias = n_bias; A.n_samp = n_samp; A.out = out; A.accumulate = accumulate;
   const int64_t Mtot = (int64_t)geom->N * geom->Ho * geom->Wo;
+  const bool fast = (C0 % 16 == 0) && (!src1 || C1 % 16 == 0);
   if (CoutP >= 64 && CoutP % 64 == 0) {
     dim3 grid((unsigned)((Mtot + 4 * 32 - 1) / (4 * 32)), (unsigned)(CoutP / 64));
-    hipLaunchKernelGGL((k_conv_gemm<4, 2>), grid, dim3(256), 0, S(stream), A);
+    if (fast) hipLaunchKernelGGL((k_conv_gemm<4, 2, true>), grid, dim3(256), 0, S(stream), A);
+    else hipLaunchKernelGGL((k_conv_gemm<4, 2, false>), grid, dim3(256), 0, S(stream), A);
   } else if (CoutP % 32 == 0) {
     dim3 grid((unsigned)((Mtot + 4 * 64 - 1) / (4 * 64)), (unsigned)(CoutP / 32));
-    hipLaunchKernelGGL((k_conv_gemm<2, 4>), grid, dim3(256), 0, S(stream), A);
+    if (fast) hipLaunchKernelGGL((k_conv_gemm<2, 4, true>), grid, dim3(256), 0, S(stream), A);
+    else hipLaunchKernelGGL((k_conv_gemm<2, 4, false>), grid, dim3(256), 0, S(stream), A);
   } else {
     dim3 grid((unsigned)((Mtot + 4 * 64 - 1) / (4 * 64)), (unsigned)(CoutP / 16));
-    hipLaunchKernelGGL((k_conv_gemm<1, 4>), grid, dim3(256), 0, S(stream), A);
+    if (fast) hipLaunchKernelGGL((k_conv_gemm<1, 4, true>), grid, dim3(256), 0, S(stream), A);
+    else hipLaunchKernelGGL((k_conv_gemm<1, 4, false>), grid, dim3(256), 0, S(stream), A);
   }
   return msgm_check_launch();
 }

@@ -247,14 +247,31 @@ __global__ void __launch_bounds__(256) k_bmm(BmmArgs P) {
           for (int n = 0; n < NT; ++n) acc[m][n] = mfma16u(a[m][r], bb[n][r], acc[m][n]);
     }
   } else {
+    // lane (., q) walks k = q, q+4, ...: pointers advance by 4 strides, one iteration ahead in registers
+    const size_t stepA = (size_t)4 * P.sAk, stepB = (size_t)4 * P.sBk;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) ap[m] += (size_t)q * P.sAk;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) bp[n] += (size_t)q * P.sBk;
+    float na[MT], nb[NT];
+    {
+      const bool vk = q < P.K;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) na[m] = (vi[m] && vk) ? *ap[m] : 0.f;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) nb[n] = (vj[n] && vk) ? *bp[n] : 0.f;
+    }
     for (int k0 = 0; k0 < P.K; k0 += 4) {
-      const int k = k0 + q;
-      const bool vk = k < P.K;
       float a[MT], bb[NT];
 #pragma unroll
-      for (int m = 0; m < MT; ++m) a[m] = (vi[m] && vk) ? ap[m][(size_t)k * P.sAk] : 0.f;
+      for (int m = 0; m < MT; ++m) { a[m] = na[m]; ap[m] += stepA; }
 #pragma unroll
-      for (int n = 0; n < NT; ++n) bb[n] = (vj[n] && vk) ? bp[n][(size_t)k * P.sBk] : 0.f;
+      for (int n = 0; n < NT; ++n) { bb[n] = nb[n]; bp[n] += stepB; }
+      const bool vk = k0 + 4 + q < P.K;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) na[m] = (vi[m] && vk) ? *ap[m] : 0.f;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) nb[n] = (vj[n] && vk) ? *bp[n] : 0.f;
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll

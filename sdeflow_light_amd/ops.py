@@ -258,7 +258,7 @@ def pad16(c: int) -> int:
 def conv_forward(geom: L.ConvGeomT, src0: torch.Tensor, C0: int, Wp: torch.Tensor, Cout: int, out: torch.Tensor,
                  src1: Optional[torch.Tensor] = None, C1: int = 0, bias: Optional[torch.Tensor] = None,
                  samp_bias: Optional[torch.Tensor] = None, n_bias: int = 0, accumulate: bool = False,
-                 CoutP: Optional[int] = None) -> torch.Tensor:
+                 CoutP: Optional[int] = None, n_samp: Optional[int] = None) -> torch.Tensor:
     """out[N][Ho][Wo][Cout] (+)= implicit-GEMM convolution of channels-last inputs (K6/K11)."""
     CoutP = pad16(Cout) if CoutP is None else CoutP
     Ktot = pad16(C0) + (pad16(C1) if src1 is not None else 0)
@@ -273,10 +273,11 @@ def conv_forward(geom: L.ConvGeomT, src0: torch.Tensor, C0: int, Wp: torch.Tenso
         raise MsgmError("packed weight too small")
     if bias is not None and bias.numel() != Cout:
         raise MsgmError("bias size")
-    if samp_bias is not None and samp_bias.numel() != n_bias * Cout:
-        raise MsgmError("samp_bias must be [n_bias][Cout]")
+    n_samp = n_bias if n_samp is None else n_samp
+    if samp_bias is not None and samp_bias.numel() != n_samp * Cout:
+        raise MsgmError("samp_bias must be [n_samp][Cout]")
     check(lib().msgm_conv_forward(geom, ptr(f32(src0)), C0, ptr(src1), C1, ptr(f32(Wp)), Cout, CoutP, Ktot, ptr(bias),
-                                  ptr(samp_bias), int(n_bias), ptr(f32(out)), int(bool(accumulate)), stream()),
+                                  ptr(samp_bias), int(n_bias), int(n_samp), ptr(f32(out)), int(bool(accumulate)), stream()),
           "msgm_conv_forward")
     return out
 
