@@ -344,6 +344,16 @@ int msgm_softmax_dual_backward(const float* P, const float* Wd, float* Pb, float
 /* [cos(t f_j), sin(t f_j)], f_j = exp(-ln(max_period) j/half) (model/nn_utils.py:130-148). */
 int msgm_timestep_embedding(const float* t, float* emb, int32_t B, int32_t dim, float max_period, msgm_stream_t stream);
 
+/* The same on dual numbers when the argument depends on the input (log-radius
+ * conditioning, NNUnet.py:101-105): t = [t ; tdot] (2*Bp), emb = [emb ; embdot]. */
+int msgm_timestep_embedding_dual(const float* t, float* emb, int32_t Bp, int32_t dim, float max_period,
+                                 msgm_stream_t stream);
+/* NormalizeLogRadius premodule (NN.py:56-70) + the sqrt(n) rescale (NNUnet.py:205,
+ * NNUnet1D.py:134) on a (primal | tangent) stacked (2*Bp, n) input:
+ * out = scale x/(|x|+eps) (and its tangent), logr = [log r ; rdot/r]. */
+int msgm_normalize_dual(const float* x, float* out, float* logr, int32_t Bp, int32_t n, int32_t dual, float scale,
+                        float eps, msgm_stream_t stream);
+
 /* flat (B, C*H*W) [channel-major; per channel 'C' (h*W+w) or 'F' (w*H+h) order]
  * <-> channels-last image [B][H][W][C], times `scale` (the /5, x5 of NNUnet.py:19-77). */
 int msgm_flat_to_image(const float* flat, float* img, int32_t B, int32_t C, int32_t H, int32_t W, int32_t forder,

@@ -88,13 +88,14 @@ class UNetModelWithLogNorm(nn.Module):
         if dims != 2 or not conv_resample or num_classes is not None or num_heads != 1 or use_scale_shift_norm or \
                 learn_potential or dropout != 0:
             raise MsgmError("HIP U-Net is built for the driver's options (dims=2, conv_resample, 1 head, dropout 0)")
-        if use_log_norm:
-            raise MsgmError("use_log_norm / NormalizeLogRadius conditioning is not built yet for the HIP U-Net")
+        self.use_log_norm = use_log_norm
         self.in_channels, self.model_channels, self.out_channels = in_channels, model_channels, out_channels
         self.channel_mult, self.num_res_blocks = tuple(channel_mult), num_res_blocks
         self.attention_resolutions = tuple(attention_resolutions)
         ted = model_channels * 4
         self.time_embed = nn.Sequential(nn.Linear(model_channels, ted), nn.Identity(), nn.Linear(ted, ted))
+        if use_log_norm:               # mirrors the time MLP for log||x|| (NNUnet.py:88-94)
+            self.scale_embed = nn.Sequential(nn.Linear(model_channels, ted), nn.Identity(), nn.Linear(ted, ted))
         ch = model_channels * channel_mult[0]
         self.input_blocks = nn.ModuleList([nn.Sequential(nn.Conv2d(in_channels, ch, 3, padding=1))])
         chans, ds = [ch], 1
@@ -154,9 +155,7 @@ class VorticityUNet(nn.Module, FlatParamMixin):
                  flatten_order: Literal["C", "F"] = "C", channels: int = 1):
         super().__init__()
         assert premodule in (None, "NormalizeLogRadius")
-        if premodule is not None:
-            raise MsgmError("VorticityUNet on HIP: premodule='NormalizeLogRadius' is not built yet (SGM configs use None)")
-        self.pre = None
+        self.pre = premodule == "NormalizeLogRadius" or None
         self.in_space = int(in_space)
         assert flatten_order in ("C", "F")
         self.flatten_order = flatten_order
@@ -166,7 +165,8 @@ class VorticityUNet(nn.Module, FlatParamMixin):
                                          attention_resolutions=attention_resolutions, dropout=dropout,
                                          channel_mult=tuple(channel_mults), conv_resample=conv_resample, dims=2,
                                          num_classes=None, use_checkpoint=use_checkpoint, num_heads=num_heads,
-                                         use_scale_shift_norm=False, learn_potential=learn_potential, use_log_norm=False)
+                                         use_scale_shift_norm=False, learn_potential=learn_potential,
+                                         use_log_norm=(premodule == "NormalizeLogRadius"))
         self._x = None
         self._flat = None
 
@@ -180,6 +180,9 @@ class VorticityUNet(nn.Module, FlatParamMixin):
         mc = core.model_channels
         x = {"t0": ConvOp(core.time_embed[0].weight, core.time_embed[0].bias, "linear", (1,), 1, 0, [mc]),
              "t2": ConvOp(core.time_embed[2].weight, core.time_embed[2].bias, "linear", (1,), 1, 0, [4 * mc])}
+        if core.use_log_norm:
+            x["s0"] = ConvOp(core.scale_embed[0].weight, core.scale_embed[0].bias, "linear", (1,), 1, 0, [mc])
+            x["s2"] = ConvOp(core.scale_embed[2].weight, core.scale_embed[2].bias, "linear", (1,), 1, 0, [4 * mc])
 
         def wrap(seq):
             out = []
@@ -203,7 +206,7 @@ class VorticityUNet(nn.Module, FlatParamMixin):
         x["mid"] = wrap(core.middle_block)
         x["outb"] = [wrap(b) for b in core.output_blocks]
         x["fin"] = ConvOp(core.out[2].weight, core.out[2].bias, "conv", (3, 3), 1, 1, [core.out[2].in_channels])
-        allops = [x["t0"], x["t2"], x["fin"]]
+        allops = [x["t0"], x["t2"], x["fin"]] + ([x["s0"], x["s2"]] if core.use_log_norm else [])
         for blk in x["in"] + [x["mid"]] + x["outb"]:
             for kind, o in blk:
                 allops += o.ops if kind in ("res", "attn") else [o]
@@ -218,11 +221,11 @@ class VorticityUNet(nn.Module, FlatParamMixin):
         out = ops.groupnorm_dual_forward(h, gnm.weight.detach(), gnm.bias.detach(), Bp, P, C, G, dual, silu, stats=stats)
         return out, stats
 
-    def _res_fwd(self, r: _Res, x, N, Bp, H, W, semb, dual, tape):
+    def _res_fwd(self, r: _Res, x, N, Bp, H, W, semb, dual, tape, er):
         P = H * W
         h1, st1 = self._gn(r.m.in_layers[0], x, Bp, P, r.ci, dual, True, tape)
-        eo, _, _ = r.lin.forward([semb], Bp, 1, 1, Bp)
-        h2, _, _ = r.conv1.forward([h1], N, H, W, Bp, samp_bias=eo)
+        eo, _, _ = r.lin.forward([semb], er, 1, 1, Bp)           # er rows carry an embedding (N with log-radius conditioning)
+        h2, _, _ = r.conv1.forward([h1], N, H, W, Bp, samp_bias=eo, emb_rows=er)
         h3, st2 = self._gn(r.m.out_layers[0], h2, Bp, P, r.co, dual, True, tape)
         if r.skip is not None:
             out, _, _ = r.skip.forward([x], N, H, W, Bp)
@@ -264,8 +267,9 @@ class VorticityUNet(nn.Module, FlatParamMixin):
             tape.append(("attn", a, x, H, W, hn, st, qkv, S, Wd, Pd, att))
         return out
 
-    def _run(self, img, t, N, Bp, dual, tape):
-        """img: channels-last [N][H][W][Cin].  Returns channels-last [N][H][W][Cout]."""
+    def _run(self, img, t, N, Bp, dual, tape, logr=None):
+        """img: channels-last [N][H][W][Cin].  Returns channels-last [N][H][W][Cout].
+        logr: [log r ; rdot/r] (N,) with NormalizeLogRadius conditioning."""
         x = self._build()
         for op in x["all"]:
             op.pack()
@@ -276,9 +280,20 @@ class VorticityUNet(nn.Module, FlatParamMixin):
         z1, _, _ = x["t0"].forward([e0.view(-1)], Bp, 1, 1, Bp)
         a1 = ops.act_dual_forward(SILU, z1, torch.empty_like(z1), False)
         emb, _, _ = x["t2"].forward([a1], Bp, 1, 1, Bp)
-        semb = ops.act_dual_forward(SILU, emb, torch.empty_like(emb), False)     # emb_layers[0] = SiLU, shared
+        er, pre = Bp, None
+        if core.use_log_norm:
+            # emb += scale_embed(timestep_embedding(log r)) — it has a tangent (rows Bp..N-1)        NNUnet.py:101-105
+            le = ops.timestep_embedding_dual(logr, Bp, mc) if dual else ops.timestep_embedding(logr, mc)
+            zs, _, _ = x["s0"].forward([le.view(-1)], N, 1, 1, Bp)
+            as_ = ops.act_dual_forward(SILU, zs, torch.empty_like(zs), dual)
+            es, _, _ = x["s2"].forward([as_], N, 1, 1, Bp)
+            pv = es[: emb.numel()]
+            ops.lincomb(pv, pv, 1.0, emb, 1.0)
+            pre = (le, zs, as_)
+            emb, er = es, N
+        semb = ops.act_dual_forward(SILU, emb, torch.empty_like(emb), dual and er == N and N != Bp)   # emb_layers[0] = SiLU
         if tape is not None:
-            tape.append(("emb", e0, z1, a1, emb, semb))
+            tape.append(("emb", e0, z1, a1, emb, semb, pre, er))
 
         def run_block(blk, h, C, H, W):
             for kind, o in blk:
@@ -288,7 +303,7 @@ class VorticityUNet(nn.Module, FlatParamMixin):
                     h, H, W = o.forward([h], N, H, W, Bp)
                     C = o.Cout
                 elif kind == "res":
-                    h = self._res_fwd(o, h, N, Bp, H, W, semb, dual, tape)
+                    h = self._res_fwd(o, h, N, Bp, H, W, semb, dual, tape, er)
                     C = o.co
                 elif kind == "attn":
                     h = self._attn_fwd(o, h, N, Bp, H, W, dual, tape)
@@ -336,8 +351,12 @@ class VorticityUNet(nn.Module, FlatParamMixin):
             raise ValueError(f"Unexpected input shape {tuple(x.shape)}")
         if t.numel() == 1 and B != 1:
             t = t.expand(B).contiguous()
+        logr = None
+        if self.pre:
+            d = flat.shape[1]
+            flat, logr = ops.normalize_dual(flat, B, d, False, float(d) ** 0.5)      # NNUnet.py:203-205
         img = ops.flat_to_image(flat, B, Cc, S_, S_, forder, sc_in)
-        out = self._run(img, t, B, B, False, None)
+        out = self._run(img, t, B, B, False, None, logr=logr)
         y = ops.image_to_flat(out, B, Cc, S_, S_, forder, sc_out)
         return y if need_flat else y.view(B, Cc, S_, S_)
 
@@ -362,10 +381,13 @@ class VorticityUNet(nn.Module, FlatParamMixin):
             gn.weight.grad.zero_(); gn.bias.grad.zero_()
         forder = self.flatten_order == "F"
         stacked = torch.cat([y.contiguous().float(), v.contiguous().float()], 0)
+        logr = None
+        if self.pre:
+            stacked, logr = ops.normalize_dual(stacked, B, d, True, float(d) ** 0.5)
         img = ops.flat_to_image(stacked, N, Cc, S_, S_, forder, 1.0 / scale_image)
         tape = []
         tt = t.reshape(-1).contiguous().float()
-        out = self._run(img, tt, N, B, True, tape)
+        out = self._run(img, tt, N, B, True, tape, logr=logr)
         a_flat = ops.image_to_flat(out, N, Cc, S_, S_, forder, float(scale_image))      # [2B][d]: a | adot
         per, g = ops.ssm_loss(a_flat.view(-1), u, cst, inv_batch)
         gimg = ops.flat_to_image(g.view(N, d), N, Cc, S_, S_, forder, float(scale_image))   # adjoint of (x5, unflatten)
@@ -385,7 +407,7 @@ class VorticityUNet(nn.Module, FlatParamMixin):
         x = self._x
         dev = g.device
         emb_rec = tape[0]
-        _, e0, z1, a1, emb, semb = emb_rec
+        _, e0, z1, a1, emb, semb, pre, er = emb_rec
         dsemb = torch.zeros_like(semb)
         dh = g
         pend = []                       # gradients w.r.t. the skip (hs) tensors, in pop order
@@ -402,9 +424,9 @@ class VorticityUNet(nn.Module, FlatParamMixin):
                 P = H * W
                 (dh3,) = rb.conv2.backward(dh, [h3], N, H, W, Bp)
                 dh2 = self._gn_bwd(rb.m.out_layers[0], h2, st2, dh3, Bp, P, rb.co, True)
-                deo = torch.empty(Bp * rb.co, device=dev)
-                (dh1,) = rb.conv1.backward(dh2, [h1], N, H, W, Bp, dsamp_bias=deo)
-                rb.lin.backward(deo, [semb], Bp, 1, 1, Bp, dsrc=[dsemb], dacc=[True])
+                deo = torch.empty(er * rb.co, device=dev)
+                (dh1,) = rb.conv1.backward(dh2, [h1], N, H, W, Bp, dsamp_bias=deo, emb_rows=er)
+                rb.lin.backward(deo, [semb], er, 1, 1, Bp, dsrc=[dsemb], dacc=[True])
                 dx = self._gn_bwd(rb.m.in_layers[0], xin, st1, dh1, Bp, P, rb.ci, True)
                 if rb.skip is not None:
                     rb.skip.backward(dh, [xin], N, H, W, Bp, dsrc=[dx], dacc=[True])
@@ -436,11 +458,19 @@ class VorticityUNet(nn.Module, FlatParamMixin):
                 else:
                     ops.lincomb(dh, dh, 1.0, sk, 1.0)
             i -= 1
-        # time-embedding MLP (primal rows): Linear -> SiLU -> Linear -> SiLU (shared emb_layers[0])
-        z = torch.zeros_like(emb)
-        ge = torch.cat([dsemb, z])
-        ops.act_dual_backward(SILU, torch.cat([emb, z]), ge)
-        (da1,) = x["t2"].backward(ge[: emb.numel()].contiguous(), [a1], Bp, 1, 1, Bp)
+        # embedding MLPs: Linear -> SiLU -> Linear -> SiLU (shared emb_layers[0])
+        if pre is not None:
+            le, zs, as_ = pre
+            ops.act_dual_backward(SILU, emb, dsemb)                       # (primal | tangent) rows
+            ge = dsemb
+            (das,) = x["s2"].backward(ge, [as_], N, 1, 1, Bp)
+            ops.act_dual_backward(SILU, zs, das)
+            x["s0"].backward(das, [le.view(-1)], N, 1, 1, Bp, need=[False])
+        else:
+            z = torch.zeros_like(emb)
+            ge = torch.cat([dsemb, z])
+            ops.act_dual_backward(SILU, torch.cat([emb, z]), ge)
+        (da1,) = x["t2"].backward(ge[: z1.numel()].contiguous(), [a1], Bp, 1, 1, Bp)
         z1z = torch.zeros_like(z1)
         g1 = torch.cat([da1, z1z])
         ops.act_dual_backward(SILU, torch.cat([z1, z1z]), g1)

@@ -42,12 +42,12 @@ class UNet1D(nn.Module, FlatParamMixin):
         super().__init__()
         self.input_dim = input_dim
         assert premodule in (None, "NormalizeLogRadius")
-        if premodule is not None:
-            raise MsgmError("UNet1D on HIP: premodule='NormalizeLogRadius' is not built yet (SGM configs use None)")
-        self.premodule = None
+        self.premodule = NormalizeLogRadius() if premodule == "NormalizeLogRadius" else None
         self.emb_dim = emb_dim
         self.time_mlp = nn.Sequential(nn.Linear(1, emb_dim), nn.GELU(), nn.Linear(emb_dim, emb_dim))
-        self.scale_embed = None
+        # log-radius conditioning: scalar log||x|| -> emb_dim, added to the time embedding (NNUnet1D.py:59-69,137-145)
+        self.scale_embed = nn.Sequential(nn.Linear(1, emb_dim), nn.GELU(), nn.Linear(emb_dim, emb_dim)) \
+            if self.premodule is not None else None
         chs = [base_channels * m for m in channel_mults]
         self.chs = chs
         self.enc_blocks, self.downs = nn.ModuleList(), nn.ModuleList()
@@ -76,6 +76,9 @@ class UNet1D(nn.Module, FlatParamMixin):
         E, chs = self.emb_dim, self.chs
         o = {"t0": ConvOp(self.time_mlp[0].weight, self.time_mlp[0].bias, "linear", (1,), 1, 0, [1]),
              "t2": ConvOp(self.time_mlp[2].weight, self.time_mlp[2].bias, "linear", (1,), 1, 0, [E])}
+        if self.scale_embed is not None:
+            o["s0"] = ConvOp(self.scale_embed[0].weight, self.scale_embed[0].bias, "linear", (1,), 1, 0, [1])
+            o["s2"] = ConvOp(self.scale_embed[2].weight, self.scale_embed[2].bias, "linear", (1,), 1, 0, [E])
         cin = 1
         for i, c in enumerate(chs):
             b = self.enc_blocks[i].net
@@ -111,10 +114,22 @@ class UNet1D(nn.Module, FlatParamMixin):
         ze, _, _ = o["t0"].forward([tt], Bp, 1, 1, Bp)
         he = ops.act_dual_forward(GELU, ze, torch.empty_like(ze), False)
         emb, _, _ = o["t2"].forward([he], Bp, 1, 1, Bp)
-        rec(("emb", tt, ze, he, emb))
+        er, pre = Bp, None
+        if self.premodule is not None:
+            # x <- sqrt(L) x/(|x|+eps); log-radius embedding carries a tangent (rows Bp..N-1) when dual
+            h0, logr = ops.normalize_dual(h0, Bp, L, dual, float(L) ** 0.5)
+            h0 = h0.view(-1)
+            zs, _, _ = o["s0"].forward([logr], N, 1, 1, Bp)
+            hs_ = ops.act_dual_forward(GELU, zs, torch.empty_like(zs), dual)
+            sv, _, _ = o["s2"].forward([hs_], N, 1, 1, Bp)
+            pv = sv[: Bp * self.emb_dim]
+            ops.lincomb(pv, pv, 1.0, emb, 1.0)                      # t_emb + scale_vec        NNUnet1D.py:145
+            pre = (logr, zs, hs_)
+            emb, er = sv, N
+        rec(("emb", tt, ze, he, emb, pre, er))
 
         def block(ka, kb, srcs, Lc):
-            z1, _, _ = o[ka].forward(srcs, N, 1, Lc, Bp, emb=emb)
+            z1, _, _ = o[ka].forward(srcs, N, 1, Lc, Bp, emb=emb, emb_rows=er)
             h1 = act(z1)
             z2, _, _ = o[kb].forward([h1], N, 1, Lc, Bp)
             h2 = act(z2)
@@ -187,9 +202,9 @@ class UNet1D(nn.Module, FlatParamMixin):
         o = self._ops
         dev = g.device
         E = self.emb_dim
-        demb = torch.zeros(Bp * E, device=dev)
         emb_rec = tape[0]
-        emb = emb_rec[4]
+        emb, pre, er = emb_rec[4], emb_rec[5], emb_rec[6]
+        demb = torch.zeros(er * E, device=dev)
         pending_skip = []                      # gradients w.r.t. skip tensors, consumed by the encoder
         dh = g
         for r in reversed(tape[1:]):
@@ -203,7 +218,8 @@ class UNet1D(nn.Module, FlatParamMixin):
                 (dh1,) = o[kb].backward(g2, [h1], N, 1, Lc, Bp)
                 g1 = ops.act_dual_backward(GELU, z1, dh1)
                 first = ka == "e0a"
-                ds = o[ka].backward(g1, srcs, N, 1, Lc, Bp, emb=emb, demb=demb, need=[not first] + [True] * (len(srcs) - 1))
+                ds = o[ka].backward(g1, srcs, N, 1, Lc, Bp, emb=emb, demb=demb, need=[not first] + [True] * (len(srcs) - 1),
+                                    emb_rows=er)
                 if len(srcs) == 2:
                     pending_skip.append(ds[1])
                 dh = ds[0]
@@ -217,9 +233,14 @@ class UNet1D(nn.Module, FlatParamMixin):
                 _, kd, h, Lc = r
                 dskip = pending_skip.pop()
                 (dh,) = o[kd].backward(dh, [h], N, 1, Lc, Bp, dsrc=[dskip], dacc=[True])
+        if pre is not None:                    # log-radius embedding (primal | tangent rows): Linear -> GELU -> Linear
+            logr, zs, hs_ = pre
+            (dhs,) = o["s2"].backward(demb, [hs_], N, 1, 1, Bp)
+            ops.act_dual_backward(GELU, zs, dhs)
+            o["s0"].backward(dhs, [logr], N, 1, 1, Bp, need=[False])
         # time MLP (primal rows only): Linear -> GELU -> Linear
-        _, tt, ze, he, _ = emb_rec
-        (dhe,) = o["t2"].backward(demb, [he], Bp, 1, 1, Bp)
+        tt, ze, he = emb_rec[1], emb_rec[2], emb_rec[3]
+        (dhe,) = o["t2"].backward(demb[: Bp * E].contiguous(), [he], Bp, 1, 1, Bp)
         zz = torch.cat([ze, torch.zeros_like(ze)])
         gg = torch.cat([dhe, torch.zeros_like(dhe)])
         ops.act_dual_backward(GELU, zz, gg)

@@ -80,6 +80,8 @@ SIGNATURES = {
     "msgm_softmax_dual_forward": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P]),
     "msgm_softmax_dual_backward": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P]),
     "msgm_timestep_embedding": (C.c_int, [_P, _P, _I32, _I32, _F, _P]),
+    "msgm_timestep_embedding_dual": (C.c_int, [_P, _P, _I32, _I32, _F, _P]),
+    "msgm_normalize_dual": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _F, _F, _P]),
     "msgm_flat_to_image": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _F, _P]),
     "msgm_image_to_flat": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _F, _P]),
     "msgm_sum2x2": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P]),

@@ -119,14 +119,18 @@ class ConvOp:
 
     # -------------------------------------------------------------- forward
     def forward(self, srcs: List[torch.Tensor], N: int, Hi: int, Wi: int, n_bias: int, emb: Optional[torch.Tensor] = None,
-                samp_bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, accumulate=False):
+                samp_bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, accumulate=False,
+                emb_rows: Optional[int] = None):
+        """emb_rows: rows that carry an embedding / per-sample bias (n_bias by default; N when the embedding itself
+        has a tangent — NormalizeLogRadius conditioning)."""
         geom, Ho, Wo = self._geom(N, Hi, Wi)
         dev = srcs[0].device
         if out is None:
             out = torch.empty(N * Ho * Wo * self.Cout, device=dev)
         sb = samp_bias
+        er = n_bias if emb_rows is None else emb_rows
         if self.embC:
-            Bp = n_bias
+            Bp = er
             g1 = ops.conv_geom(Bp, 1, 1, 1, 1, 1, 1, 1, 0)
             E = [torch.empty(Bp * self.Cout, device=dev) for _ in range(3)]
             per = self.Cout * pad16(self.embC)
@@ -138,18 +142,19 @@ class ConvOp:
         ops.conv_forward(geom, srcs[0], self.srcC[0], self.Wp, self.Cout, out,
                          src1=srcs[1] if len(srcs) > 1 else None, C1=self.srcC[1] if len(srcs) > 1 else 0,
                          bias=self.bias.detach() if self.bias is not None else None, samp_bias=sb, n_bias=n_bias,
-                         accumulate=accumulate, CoutP=self.CoutP)
+                         accumulate=accumulate, CoutP=self.CoutP, n_samp=er)
         if self.embC:
-            # taps 0 / 2 fall on the zero padding at l = 0 / L-1 (primal rows only)
-            ops.add_row(out, self._E[0], n_bias, Ho * Wo, self.Cout, 0, -1.0)
-            ops.add_row(out, self._E[2], n_bias, Ho * Wo, self.Cout, Ho * Wo - 1, -1.0)
+            # taps 0 / 2 fall on the zero padding at l = 0 / L-1 (rows that carry an embedding)
+            ops.add_row(out, self._E[0], er, Ho * Wo, self.Cout, 0, -1.0)
+            ops.add_row(out, self._E[2], er, Ho * Wo, self.Cout, Ho * Wo - 1, -1.0)
         return out, Ho, Wo
 
     # -------------------------------------------------------------- backward
     def backward(self, gy: torch.Tensor, srcs: List[torch.Tensor], N: int, Hi: int, Wi: int, n_bias: int,
                  emb: Optional[torch.Tensor] = None, demb: Optional[torch.Tensor] = None,
                  need: Optional[Sequence[bool]] = None, dsrc: Optional[List[Optional[torch.Tensor]]] = None,
-                 dacc: Optional[Sequence[bool]] = None, dsamp_bias: Optional[torch.Tensor] = None):
+                 dacc: Optional[Sequence[bool]] = None, dsamp_bias: Optional[torch.Tensor] = None,
+                 emb_rows: Optional[int] = None):
         """gy: cotangent of the output [N][Ho][Wo][Cout].  Accumulates the packed
         weight gradient, writes bias.grad, adds to ``demb`` / writes ``dsamp_bias``
         (per-sample bias cotangent, primal rows) and returns d(src_s)."""
@@ -159,13 +164,14 @@ class ConvOp:
         for s, C in enumerate(self.srcC):
             ops.conv_wgrad(geom, gy, srcs[s], C, self.koff[s], self.dWp, self.Cout, self.CoutP, self.Ktot)
         S = None
+        er = n_bias if emb_rows is None else emb_rows
         if self.bias is not None or self.embC or dsamp_bias is not None:
-            S = dsamp_bias if dsamp_bias is not None else torch.empty(n_bias * self.Cout, device=dev)
-            ops.colsum(gy, n_bias, P, self.Cout, out=S)                       # primal rows only
-            if self.bias is not None:
+            S = dsamp_bias if dsamp_bias is not None else torch.empty(er * self.Cout, device=dev)
+            ops.colsum(gy, er, P, self.Cout, out=S)                           # rows that carry a bias / embedding
+            if self.bias is not None:                                         # the bias itself: primal rows only
                 ops.colsum(S, 1, n_bias, self.Cout, out=self.bias.grad.view(1, -1))
         if self.embC:
-            Bp, E = n_bias, self.embC
+            Bp, E = er, self.embC
             g0 = ops.gather_row(gy, Bp, P, self.Cout, 0)
             gL = ops.gather_row(gy, Bp, P, self.Cout, P - 1)
             G = [torch.empty(Bp * self.Cout, device=dev), S, torch.empty(Bp * self.Cout, device=dev)]

@@ -365,6 +365,51 @@ __global__ void k_timestep_embedding(const float* __restrict__ t, float* __restr
     emb[e] = v;
   }
 }
+// dual-number version for an argument that depends on the input (log-radius conditioning, NNUnet.py:101-105):
+// rows b < Bp primal, rows Bp + b hold the tangent tdot:  d/dt cos(t f) = -f sin(t f) tdot, d/dt sin = f cos tdot
+__global__ void k_timestep_embedding_dual(const float* __restrict__ t, float* __restrict__ emb, int Bp, int dim, float max_period) {
+  const int half = dim / 2;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < Bp * dim; e += gridDim.x * blockDim.x) {
+    const int b = e / dim, j = e - b * dim;
+    float v = 0.f, vd = 0.f;
+    if (j < 2 * half) {
+      const int jj = j < half ? j : j - half;
+      const float f = expf(-logf(max_period) * (float)jj / (float)half);
+      const float arg = t[b] * f, td = t[Bp + b];
+      const float c = cosf(arg), s = sinf(arg);
+      v = j < half ? c : s;
+      vd = j < half ? -f * s * td : f * c * td;
+    }
+    emb[e] = v;
+    emb[(size_t)Bp * dim + e] = vd;
+  }
+}
+
+// NormalizeLogRadius on dual numbers (NN.py:56-70 followed by the x sqrt(n) rescale of NNUnet.py:205 /
+// NNUnet1D.py:134): r = |x| + eps; out = scale x / r; logr = log r; tangent: rdot = x.xdot/|x|,
+// outdot = scale (xdot / r - x rdot / r^2), logr_dot = rdot / r.   One wave per row.
+__global__ void __launch_bounds__(256) k_normalize_dual(const float* __restrict__ x, float* __restrict__ out,
+                                                        float* __restrict__ logr, int Bp, int n, int dual, float scale,
+                                                        float eps) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= Bp) return;
+  const float* xp = x + (size_t)b * n;
+  const float* xt = x + (size_t)(b + Bp) * n;
+  float ss = 0.f, sd = 0.f;
+  for (int i = lane; i < n; i += 64) { const float v = xp[i]; ss += v * v; if (dual) sd += v * xt[i]; }
+  ss = wave_sum(ss);
+  if (dual) sd = wave_sum(sd);
+  const float nr = sqrtf(ss), r = nr + eps;
+  const float rdot = dual ? sd / nr : 0.f;
+  for (int i = lane; i < n; i += 64) {
+    const float v = xp[i];
+    out[(size_t)b * n + i] = scale * (v / r);
+    if (dual) out[(size_t)(b + Bp) * n + i] = scale * (xt[i] / r - v * rdot / (r * r));
+  }
+  if (lane == 0) { logr[b] = logf(r); if (dual) logr[Bp + b] = rdot / r; }
+}
+
 // flat (B, C*H*W) channel-major, per-channel 'C' (h*W+w) or 'F' (w*H+h) order  <->  [B][H][W][C], with scale
 __global__ void k_flat_to_cl(const float* __restrict__ flat, float* __restrict__ img, int B, int C, int H, int W, int forder,
                              float scale) {
@@ -482,6 +527,19 @@ int msgm_softmax_dual_backward(const float* Pm, const float* Wd, float* Pb, floa
 int msgm_timestep_embedding(const float* t, float* emb, int32_t B, int32_t dim, float max_period, msgm_stream_t stream) {
   if (!t || !emb || B <= 0 || dim <= 0) return MSGM_E_BADARG;
   hipLaunchKernelGGL(k_timestep_embedding, dim3(grid_for((int64_t)B * dim, 256)), dim3(256), 0, S(stream), t, emb, B, dim, max_period);
+  return msgm_check_launch();
+}
+
+int msgm_timestep_embedding_dual(const float* t, float* emb, int32_t Bp, int32_t dim, float max_period, msgm_stream_t stream) {
+  if (!t || !emb || Bp <= 0 || dim <= 0) return MSGM_E_BADARG;
+  hipLaunchKernelGGL(k_timestep_embedding_dual, dim3(grid_for((int64_t)Bp * dim, 256)), dim3(256), 0, S(stream), t, emb, Bp, dim, max_period);
+  return msgm_check_launch();
+}
+
+int msgm_normalize_dual(const float* x, float* out, float* logr, int32_t Bp, int32_t n, int32_t dual, float scale, float eps,
+                        msgm_stream_t stream) {
+  if (!x || !out || !logr || Bp <= 0 || n <= 0) return MSGM_E_BADARG;
+  hipLaunchKernelGGL(k_normalize_dual, dim3((Bp + 3) / 4), dim3(256), 0, S(stream), x, out, logr, Bp, n, dual, scale, eps);
   return msgm_check_launch();
 }
 

@@ -427,6 +427,28 @@ def timestep_embedding(t, dim, max_period=10000.0):
     return emb
 
 
+def timestep_embedding_dual(t, Bp, dim, max_period=10000.0):
+    """t = [t ; tdot] (2*Bp) -> [emb ; embdot] (2*Bp, dim)."""
+    t = t.reshape(-1).contiguous()
+    if t.numel() != 2 * Bp:
+        raise MsgmError("timestep_embedding_dual: t must hold 2*Bp values")
+    emb = torch.empty(2 * Bp, dim, dtype=torch.float32, device=t.device)
+    check(lib().msgm_timestep_embedding_dual(ptr(f32(t)), ptr(emb), Bp, dim, float(max_period), stream()), "msgm_timestep_embedding_dual")
+    return emb
+
+
+def normalize_dual(x, Bp, n, dual, scale):
+    """NormalizeLogRadius (+ rescale) on a stacked (N, n) input; returns (out (N,n), logr (N,))."""
+    N = 2 * Bp if dual else Bp
+    if x.numel() != N * n:
+        raise MsgmError("normalize_dual: size mismatch")
+    out = torch.empty(N, n, dtype=torch.float32, device=x.device)
+    logr = torch.empty(N, dtype=torch.float32, device=x.device)
+    check(lib().msgm_normalize_dual(ptr(f32(x)), ptr(out), ptr(logr), Bp, n, int(bool(dual)), float(scale), 1e-6, stream()),
+          "msgm_normalize_dual")
+    return out, logr
+
+
 def flat_to_image(flat, B, C, H, W, forder, scale):
     if flat.numel() != B * C * H * W:
         raise MsgmError("flat_to_image: size mismatch")

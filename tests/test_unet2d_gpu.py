@@ -202,3 +202,80 @@ def test_graphed_step_sampler_unet2d_equals_eager():
     assert rel_l2(a.cpu(), b) <= 1e-5, rel_l2(a.cpu(), b)
     c = gs.run(x0).clone()
     assert not torch.equal(a, c) and torch.isfinite(c).all()
+
+
+# ------------------------------------------------------------------ NormalizeLogRadius conditioning (MSGM default)
+def test_normalize_and_embedding_dual_kernels():
+    from sdeflow_light_amd import ops
+    from oracle import nets_ref as N
+    torch.manual_seed(3)
+    B, n = 5, 300
+    x, xd = torch.randn(B, n) * 2, torch.randn(B, n)
+    f = lambda a: tuple(N.normalize_log_radius(a))
+    (xn, lr), (xnd, lrd) = torch.func.jvp(f, (x,), (xd,))
+    out, logr = ops.normalize_dual(torch.cat([x, xd]).to(DEV), B, n, True, math.sqrt(n))
+    assert rel_l2(out[:B].cpu(), xn * math.sqrt(n)) <= 1e-6 and rel_l2(out[B:].cpu(), xnd * math.sqrt(n)) <= 1e-5
+    assert rel_l2(logr[:B].cpu(), lr.reshape(-1)) <= 1e-6 and rel_l2(logr[B:].cpu(), lrd.reshape(-1)) <= 1e-5
+    t, td = torch.randn(B) * 3, torch.randn(B)
+    e, ed = torch.func.jvp(lambda a: N.sinusoidal_embedding(a, 32), (t,), (td,))
+    emb = ops.timestep_embedding_dual(torch.cat([t, td]).to(DEV), B, 32)
+    assert rel_l2(emb[:B].cpu(), e) <= 1e-6 and rel_l2(emb[B:].cpu(), ed) <= 1e-5
+
+
+def test_unet_premodule_forward_golden():
+    from sdeflow_light_amd.NNUnet import VorticityUNet
+    from sdeflow_light_amd.NNUnet1D import UNet1D
+    from oracle.det_params import load_det_
+    g2, g1 = load_golden("g09_unet2d"), load_golden("g09_unet1d")
+    net = VorticityUNet(base_channels=32, channel_mults=(1, 2, 4), num_res_blocks=2, premodule="NormalizeLogRadius", in_space=16,
+                        attention_resolutions=(2, 4), flatten_order="F")
+    load_det_(net)
+    out = net.to(DEV)(g2["u2d16Fn_x"].to(DEV), g2["u2d16Fn_t"].to(DEV))
+    assert rel_l2(out.cpu(), g2["u2d16Fn_out"]) <= 1e-4, rel_l2(out.cpu(), g2["u2d16Fn_out"])
+    n1 = UNet1D(input_dim=1024, premodule="NormalizeLogRadius")
+    load_det_(n1)
+    out = n1.to(DEV)(g1["u1dn_x"].to(DEV), g1["u1dn_t"].to(DEV))
+    assert rel_l2(out.cpu(), g1["u1dn_out"]) <= 1e-4, rel_l2(out.cpu(), g1["u1dn_out"])
+
+
+@pytest.mark.parametrize("which", ["1d", "2d"])
+def test_unet_premodule_ssm_msgm_vs_oracle(which):
+    """The reference's MSGM default (sparse tensor + NormalizeLogRadius U-Net): the log-radius embedding has a
+    tangent, so the embedding path itself runs on dual numbers."""
+    from sdeflow_light_amd.NNUnet import VorticityUNet
+    from sdeflow_light_amd.NNUnet1D import UNet1D
+    from test_oracle_golden import unet1d_shapes, unet2d_shapes
+    from test_host_gpu import make_gen
+    from oracle import sde_ref as S, nets_ref as N, ssm_ref as LR
+    from oracle.det_params import det_state_dict, load_det_
+    torch.manual_seed(1)
+    pre = "NormalizeLogRadius"
+    if which == "1d":
+        n = 64
+        net = UNet1D(input_dim=n, premodule=pre)
+        p = det_state_dict(unet1d_shapes(n, pre))
+        score = lambda prm, yy, tt: N.unet1d_forward(prm, yy, tt, pre)
+    else:
+        n = 256
+        net = VorticityUNet(base_channels=32, channel_mults=(1, 2, 4), num_res_blocks=2, premodule=pre, in_space=16,
+                            attention_resolutions=(2, 4), flatten_order="F")
+        cfg = N.UNet2DConfig(in_space=16, use_log_norm=True)
+        p = det_state_dict(unet2d_shapes(cfg, "core."))
+        score = lambda prm, yy, tt: N.vorticity_unet_forward(prm, yy, tt, cfg, pre, "F")
+    load_det_(net)
+    gen = make_gen("sparse", net.to(DEV), n=n, nsf=4)
+    B = 2
+    t, y, uv = torch.rand(B, 1).clamp_min(1e-3), torch.randn(B, n) * 2, torch.rand(B, n)
+    gen.zero_grad()
+    per = gen.ssm_loss(t.to(DEV), y.to(DEV), y.to(DEV), u_v=uv.to(DEV))
+    per.mean().backward()
+    sp = S.SdeSpec(kind=S.MSGM_SPARSE, n=n)
+    loss, per_ref, gref = LR.ssm_mean_and_grads(sp, score, p, t, y, S.rademacher_from_uniform(uv))
+    assert rel_l2(per.detach().cpu(), per_ref) <= 2e-4, rel_l2(per.detach().cpu(), per_ref)
+    names = [k for k, _ in gen.a.named_parameters()]
+    flat = torch.cat([pp.grad.reshape(-1).cpu() for _, pp in gen.a.named_parameters()])
+    ref = torch.cat([gref[k].reshape(-1) for k in names])
+    assert rel_l2(flat, ref) <= 2e-3, rel_l2(flat, ref)
+    for k, pp in gen.a.named_parameters():            # the embedding MLPs must receive their tangent contributions
+        if "scale_embed" in k:
+            assert rel_l2(pp.grad.cpu(), gref[k]) <= 5e-3, (k, rel_l2(pp.grad.cpu(), gref[k]))
