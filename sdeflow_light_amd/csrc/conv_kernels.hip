@@ -18,6 +18,7 @@
 // second half of the batch (n >= n_bias): convolutions are linear, only the bias
 // distinguishes the halves.
 #include "common.h"
+#include <stdlib.h>
 
 #define CONV_MAX_SRC 2
 
@@ -204,6 +205,173 @@ __global__ void __launch_bounds__(256) k_conv_gemm(ConvArgs A) {
       if (A.samp_bias && pn[nt] < A.n_samp) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) if (co + r < A.Cout) v[r] += A.samp_bias[(size_t)pn[nt] * A.Cout + co + r];
+      }
+      if (full) {
+        if (A.accumulate) v += *reinterpret_cast<const f32x4*>(op);
+        *reinterpret_cast<f32x4*>(op) = v;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (co + r < A.Cout) op[r] = A.accumulate ? op[r] + v[r] : v[r];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ stride-1 "same" convolutions: halo tile in LDS
+// k_conv_gemm re-reads every input pixel once per tap from L2 (9x for 3x3) and, at small Cout, that fragment
+// traffic — not the MFMA pipe — sets its speed.  For stride-1, pad=(K-1)/2 convolutions (the bulk of both U-Nets,
+// forward AND dgrad) a workgroup instead stages a (TH+KH-1) x (TW+KW-1) halo tile of KC=32 channels in LDS once
+// per chunk (coalesced 16-B rows, zero-filled outside the image) and serves all taps from it:
+//   * 256 threads = 4 waves; the TH x TW = 128 output pixels are split 32 per wave (2 MFMA column tiles);
+//   * the activation (B) fragments are ds_read_b128 from the tile at (ty+kh, tx+kw) — pitch 36 floats is
+//     conflict-free for the 16 consecutive pixels of a lane group;
+//   * the weight (A) fragments stream L2 -> registers one (tap, 16-channel group) ahead (all waves read the same
+//     few KB, they stay in L1);
+//   * chunks are double-buffered: the next chunk's global loads are in flight during the MFMAs of this one.
+// flip = 1 evaluates the transposed stride-1 gather i = o + pad - k (the dgrad of the same convolution).
+#define CT_KC 32
+#define CT_P 36
+template <int TH, int TW, int NCO>
+__global__ void __launch_bounds__(256) k_conv_tile(ConvArgs A, int flip, int tiles_x, int tiles_y) {
+  extern __shared__ __attribute__((aligned(16))) float ct_lds[];
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, il = lane & 15, q = lane >> 4;
+  const ConvGeom g = A.g;
+  const int KH = g.KH, KW = g.KW, taps = KH * KW;
+  const int HH = TH + KH - 1, HW = TW + KW - 1, halo = HH * HW;
+  float* buf0 = ct_lds;
+  float* buf1 = ct_lds + halo * CT_P;
+  int bx = blockIdx.x;
+  const int tx_i = bx % tiles_x; bx /= tiles_x;
+  const int ty_i = bx % tiles_y;
+  const int n = bx / tiles_y;
+  const int y0 = ty_i * TH, x0 = tx_i * TW;
+  const int co0 = blockIdx.y * (NCO * 16);
+  // this lane's two output pixels
+  int pty[2], ptx[2];
+  bool pin[2];
+#pragma unroll
+  for (int pt = 0; pt < 2; ++pt) {
+    const int p = 32 * w + 16 * pt + il;
+    pty[pt] = p / TW; ptx[pt] = p - pty[pt] * TW;
+    pin[pt] = (y0 + pty[pt] < g.Ho) && (x0 + ptx[pt] < g.Wo);
+  }
+  f32x4 acc[NCO][2];
+#pragma unroll
+  for (int c = 0; c < NCO; ++c) { acc[c][0] = f32x4{0, 0, 0, 0}; acc[c][1] = f32x4{0, 0, 0, 0}; }
+
+  // chunk list: (source, channel offset), flattened
+  int nch[CONV_MAX_SRC];
+  int total_chunks = 0;
+#pragma unroll
+  for (int s = 0; s < CONV_MAX_SRC; ++s) { nch[s] = s < A.nsrc ? (A.C[s] + CT_KC - 1) / CT_KC : 0; total_chunks += nch[s]; }
+
+  // ---- staging: halo pixel hp, 16-B column c4 (8 per pixel)
+  constexpr int MAXST = ((TH + 2) * (TW + 2) * (CT_KC / 4) + 255) / 256;
+  f32x4 st[MAXST];
+  const int n_items = halo * (CT_KC / 4);
+  const int padH = g.padH, padW = g.padW;
+  auto stage_load = [&](int s, int c0) {
+    const int C = A.C[s];
+    const float* base = A.src[s] + (size_t)n * g.Hi * g.Wi * C;
+#pragma unroll
+    for (int k = 0; k < MAXST; ++k) {
+      const int idx = tid + 256 * k;
+      f32x4 v = {0, 0, 0, 0};
+      if (idx < n_items) {
+        const int hp = idx >> 3, c4 = idx & 7;
+        const int hy = hp / HW, hx = hp - hy * HW;
+        const int iy = y0 + hy - padH, ix = x0 + hx - padW;
+        const int c = c0 + 4 * c4;
+        if (iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi && c < C)
+          v = *reinterpret_cast<const f32x4*>(base + ((size_t)iy * g.Wi + ix) * C + c);
+      }
+      st[k] = v;
+    }
+  };
+  auto stage_store = [&](float* buf) {
+#pragma unroll
+    for (int k = 0; k < MAXST; ++k) {
+      const int idx = tid + 256 * k;
+      if (idx < n_items) *reinterpret_cast<f32x4*>(buf + (idx >> 3) * CT_P + 4 * (idx & 7)) = st[k];
+    }
+  };
+
+  int cs = 0, cc = 0;                    // current chunk: source cs, chunk index cc within it
+  stage_load(0, 0);
+  stage_store(buf0);
+  __syncthreads();
+  float* cur = buf0;
+  float* nxt = buf1;
+  const size_t a_co_stride = (size_t)16 * A.Ktot;
+  for (int ch = 0; ch < total_chunks; ++ch) {
+    // next chunk coordinates
+    int ns = cs, nc = cc + 1;
+    if (nc == nch[cs]) { ns = cs + 1; nc = 0; }
+    const bool more = ch + 1 < total_chunks;
+    if (more) stage_load(ns, nc * CT_KC);
+    // ---- MFMAs of this chunk: (tap, 16-channel group) pairs, weight fragments one pair ahead
+    const int C = A.C[cs];
+    const int c0 = cc * CT_KC;
+    const int ngrp = (C - c0 >= CT_KC) ? 2 : ((C - c0 + 15) >> 4);
+    const float* wbase = A.Wp + (size_t)(co0 + il) * A.Ktot + A.koff[cs] + c0 + 4 * q;
+    const int npairs = taps * ngrp;
+    f32x4 an[NCO];
+#pragma unroll
+    for (int c = 0; c < NCO; ++c) an[c] = *reinterpret_cast<const f32x4*>(wbase + c * a_co_stride);   // tap 0, group 0
+    int tap = 0, grp = 0;
+    for (int pr = 0; pr < npairs; ++pr) {
+      f32x4 a[NCO];
+#pragma unroll
+      for (int c = 0; c < NCO; ++c) a[c] = an[c];
+      int ntap = tap, ngr = grp + 1;
+      if (ngr == ngrp) { ngr = 0; ++ntap; }
+      if (pr + 1 < npairs) {
+        const float* wp = wbase + (size_t)ntap * A.CoutP * A.Ktot + 16 * ngr;
+#pragma unroll
+        for (int c = 0; c < NCO; ++c) an[c] = *reinterpret_cast<const f32x4*>(wp + c * a_co_stride);
+      }
+      const int kh = tap / KW, kw = tap - kh * KW;
+      const int oy = flip ? (KH - 1 - kh) : kh, ox = flip ? (KW - 1 - kw) : kw;
+      f32x4 b[2];
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt)
+        b[pt] = *reinterpret_cast<const f32x4*>(cur + ((pty[pt] + oy) * HW + ptx[pt] + ox) * CT_P + 16 * grp + 4 * q);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < NCO; ++c) {
+          acc[c][0] = mfma16c(a[c][r], b[0][r], acc[c][0]);
+          acc[c][1] = mfma16c(a[c][r], b[1][r], acc[c][1]);
+        }
+      tap = ntap; grp = ngr;
+    }
+    if (more) stage_store(nxt);
+    __syncthreads();
+    float* t = cur; cur = nxt; nxt = t;
+    cs = ns; cc = nc;
+  }
+
+  // ---- epilogue (same contract as k_conv_gemm)
+#pragma unroll
+  for (int pt = 0; pt < 2; ++pt) {
+    if (!pin[pt]) continue;
+    const size_t m = ((size_t)n * g.Ho + y0 + pty[pt]) * g.Wo + x0 + ptx[pt];
+    const bool primal = n < A.n_bias;
+#pragma unroll
+    for (int c = 0; c < NCO; ++c) {
+      const int co = co0 + 16 * c + 4 * q;
+      if (co >= A.Cout) continue;
+      f32x4 v = acc[c][pt];
+      float* op = A.out + m * A.Cout + co;
+      const bool full = (co + 3 < A.Cout) && ((A.Cout & 3) == 0);
+      if (primal && A.bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (co + r < A.Cout) v[r] += A.bias[co + r];
+      }
+      if (A.samp_bias && n < A.n_samp) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (co + r < A.Cout) v[r] += A.samp_bias[(size_t)n * A.Cout + co + r];
       }
       if (full) {
         if (A.accumulate) v += *reinterpret_cast<const f32x4*>(op);
@@ -472,6 +640,28 @@ int msgm_conv_forward(const msgm_conv_geom_t* geom, const float* src0, int32_t C
   A.bias = bias; A.samp_bias = samp_bias; A.n_bias = n_bias; A.n_samp = n_samp; A.out = out; A.accumulate = accumulate;
   const int64_t Mtot = (int64_t)geom->N * geom->Ho * geom->Wo;
   const bool fast = (C0 % 16 == 0) && (!src1 || C1 % 16 == 0);
+  // stride-1 "same" convolution (or its dgrad) on a big enough image: halo-tile kernel
+  const bool same = geom->strideH == 1 && geom->strideW == 1 && !geom->ups && geom->Hi == geom->Ho && geom->Wi == geom->Wo &&
+                    (geom->KH & 1) && (geom->KW & 1) && geom->padH == (geom->KH - 1) / 2 && geom->padW == (geom->KW - 1) / 2 &&
+                    geom->KH <= 3 && geom->KW <= 3;
+  if (same && fast && CoutP % 32 == 0 && (int64_t)geom->Ho * geom->Wo >= 64 && !getenv("MSGM_NO_CONV_TILE")) {
+    const bool two_d = geom->Ho > 1;
+    const int TH = two_d ? 8 : 1, TW = two_d ? 16 : 128;
+    const int tiles_x = (geom->Wo + TW - 1) / TW, tiles_y = (geom->Ho + TH - 1) / TH;
+    const int halo = (TH + geom->KH - 1) * (TW + geom->KW - 1);
+    const size_t lds = (size_t)2 * halo * CT_P * sizeof(float);
+    const int nco = (CoutP % 64 == 0) ? 4 : 2;
+    dim3 grid((unsigned)(tiles_x * tiles_y * geom->N), (unsigned)(CoutP / (16 * nco)));
+    const int flip = geom->mode;
+    if (two_d) {
+      if (nco == 4) hipLaunchKernelGGL((k_conv_tile<8, 16, 4>), grid, dim3(256), lds, S(stream), A, flip, tiles_x, tiles_y);
+      else hipLaunchKernelGGL((k_conv_tile<8, 16, 2>), grid, dim3(256), lds, S(stream), A, flip, tiles_x, tiles_y);
+    } else {
+      if (nco == 4) hipLaunchKernelGGL((k_conv_tile<1, 128, 4>), grid, dim3(256), lds, S(stream), A, flip, tiles_x, tiles_y);
+      else hipLaunchKernelGGL((k_conv_tile<1, 128, 2>), grid, dim3(256), lds, S(stream), A, flip, tiles_x, tiles_y);
+    }
+    return msgm_check_launch();
+  }
   if (CoutP >= 64 && CoutP % 64 == 0) {
     dim3 grid((unsigned)((Mtot + 4 * 32 - 1) / (4 * 32)), (unsigned)(CoutP / 64));
     if (fast) hipLaunchKernelGGL((k_conv_gemm<4, 2, true>), grid, dim3(256), 0, S(stream), A);

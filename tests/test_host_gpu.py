@@ -361,3 +361,43 @@ def test_ssm_unet1d_msgm_sparse_vs_oracle():
     flat = torch.cat([pp.grad.reshape(-1).cpu() for _, pp in gen.a.named_parameters()])
     ref = torch.cat([gref[k].reshape(-1) for k, _ in gen.a.named_parameters()])
     assert rel_l2(flat, ref) <= 1e-3, rel_l2(flat, ref)
+
+
+def test_checkpoint_roundtrip_and_torch_adam_compat(tmp_path):
+    """N3: save_checkpoint / load_checkpoint keep the reference's dictionary layout (NN.py:13-42); the optimizer
+    state loads into torch.optim.Adam and back, and a resumed run continues bit-identically."""
+    from sdeflow_light_amd.NN import MLP, save_checkpoint, load_checkpoint
+    from sdeflow_light_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    x = torch.randn(512, 2, device=DEV)
+    noise = [(torch.rand(512, device=DEV), torch.randn(512, 2, device=DEV), torch.rand(512, 2, device=DEV)) for _ in range(4)]
+
+    def run(gen, opt, steps):
+        for u, e, uv in steps:
+            opt.zero_grad()
+            gen.ssm(x, u=u, eps=e, u_v=uv).mean().backward()
+            opt.step()
+    torch.manual_seed(1)
+    gen = make_gen("sgm", MLP(2))
+    opt = FusedAdam(gen.parameters(), lr=1e-3)
+    run(gen, opt, noise[:2])
+    path = str(tmp_path / "ck.pt")
+    save_checkpoint(path, gen, opt, 1)
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    assert set(ck) == {"iteration", "model", "optimizer", "torch_rng", "numpy_rng", "python_rng"}
+    assert {"T", "base_sde.T", "a.main.0.weight", "a.main.6.bias"} <= set(ck["model"])
+    # the optimizer state is torch.optim.Adam's: it loads into a stock Adam over same-shaped parameters
+    ref_params = [torch.nn.Parameter(v.clone()) for k, v in ck["model"].items()]
+    ref_opt = torch.optim.Adam(ref_params, lr=1e-3)
+    ref_opt.load_state_dict(ck["optimizer"])
+    assert len(ref_opt.state) == 8 and all(int(st["step"]) == 2 for st in ref_opt.state.values())
+    run(gen, opt, noise[2:])
+    final = gen.a.flat_parameters()[0].clone()
+    # resume from the checkpoint in a fresh object graph
+    torch.manual_seed(2)
+    gen2 = make_gen("sgm", MLP(2))
+    opt2 = FusedAdam(gen2.parameters(), lr=1e-3)
+    it = load_checkpoint(path, gen2, opt2, DEV)
+    assert it == 1
+    run(gen2, opt2, noise[2:])
+    assert torch.equal(gen2.a.flat_parameters()[0], final)
