@@ -387,7 +387,7 @@ def test_checkpoint_roundtrip_and_torch_adam_compat(tmp_path):
     assert set(ck) == {"iteration", "model", "optimizer", "torch_rng", "numpy_rng", "python_rng"}
     assert {"T", "base_sde.T", "a.main.0.weight", "a.main.6.bias"} <= set(ck["model"])
     # the optimizer state is torch.optim.Adam's: it loads into a stock Adam over same-shaped parameters
-    ref_params = [torch.nn.Parameter(v.clone()) for k, v in ck["model"].items()]
+    ref_params = [torch.nn.Parameter(p_.detach().cpu().clone(), requires_grad=p_.requires_grad) for p_ in gen.parameters()]
     ref_opt = torch.optim.Adam(ref_params, lr=1e-3)
     ref_opt.load_state_dict(ck["optimizer"])
     assert len(ref_opt.state) == 8 and all(int(st["step"]) == 2 for st in ref_opt.state.values())
