@@ -326,9 +326,12 @@ int msgm_groupnorm_dual_backward(const float* x, const float* gamma, const float
                                  msgm_stream_t stream);
 
 /* Batched fp32-MFMA GEMM with element strides:
- *   C[b](i,j) (+)= alpha sum_k A[b](i,k) B[b](k,j)
- * (QK^T, PV and their adjoints in QKVAttention, model/unet.py:236-250). */
-int msgm_bmm(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, int32_t batch,
+ *   C[b](i,j) (+)= alpha ( sum_k A[b](i,k) B[b](k,j) + sum_k A2[b](i,k) B2[b](k,j) )
+ * (QK^T, PV and their adjoints in QKVAttention, model/unet.py:236-250).  The
+ * optional second pair (A2, B2: same strides, may be NULL) fuses the two-term
+ * products of the dual-number attention into one pass over the output. */
+int msgm_bmm(const float* A, const float* B, const float* A2, const float* B2, float* C,
+             int32_t M, int32_t N, int32_t K, int32_t batch,
              int64_t sAb, int64_t sAi, int64_t sAk, int64_t sBb, int64_t sBk, int64_t sBj,
              int64_t sCb, int64_t sCi, int64_t sCj, float alpha, int32_t accumulate, msgm_stream_t stream);
 

@@ -251,16 +251,15 @@ class VorticityUNet(nn.Module, FlatParamMixin):
         Wd = Pd = None
         if dual:
             Wd, Pd = torch.empty_like(S), torch.empty_like(S)
-            ops.bmm(qkv, half, qkv, C, Wd, 0, T, T, C, Bp, sq, sk, sS, alpha=s2)                     # qdot k^T
-            ops.bmm(qkv, 0, qkv, half + C, Wd, 0, T, T, C, Bp, sq, sk, sS, alpha=s2, accumulate=True)  # q kdot^T
+            ops.bmm(qkv, half, qkv, C, Wd, 0, T, T, C, Bp, sq, sk, sS, alpha=s2,                     # qdot k^T + q kdot^T
+                    pair2=(qkv, 0, qkv, half + C))
         ops.softmax_dual_forward(S, T, Wd, Pd)                           # S <- P
         att = torch.empty(N * T * C, device=dev)
         sP, sv, sa = (T * T, T, 1), (T * ld, ld, 1), (T * C, C, 1)
         ops.bmm(S, 0, qkv, 2 * C, att, 0, T, C, T, Bp, sP, sv, sa)                                   # a = P v
         if dual:
             offa = Bp * T * C
-            ops.bmm(Pd, 0, qkv, 2 * C, att, offa, T, C, T, Bp, sP, sv, sa)                           # Pdot v
-            ops.bmm(S, 0, qkv, half + 2 * C, att, offa, T, C, T, Bp, sP, sv, sa, accumulate=True)     # + P vdot
+            ops.bmm(Pd, 0, qkv, 2 * C, att, offa, T, C, T, Bp, sP, sv, sa, pair2=(S, 0, qkv, half + 2 * C))   # Pdot v + P vdot
         out, _, _ = a.proj.forward([att], N, 1, T, Bp)
         ops.lincomb(out, out, 1.0, x, 1.0)
         if tape is not None:
@@ -485,27 +484,23 @@ class VorticityUNet(nn.Module, FlatParamMixin):
         ld = 3 * C
         half, offa = Bp * T * ld, Bp * T * C
         (datt,) = a.proj.backward(dout, [att], N, 1, T, Bp)             # [N][T][C]: abar | adotbar
-        dqkv = torch.zeros(N * T * ld, device=dev)
+        dqkv = torch.empty(N * T * ld, device=dev)                     # every slice is written exactly once below
         sP, sPt = (T * T, T, 1), (T * T, 1, T)                          # P(t,s) / P^T(s,t)
         sa, sq = (T * C, C, 1), (T * ld, ld, 1)
         # vbar = P^T abar + Pdot^T adotbar ; vdotbar = P^T adotbar
-        ops.bmm(Pm, 0, datt, 0, dqkv, 2 * C, T, C, T, Bp, sPt, sa, sq)
-        ops.bmm(Pd, 0, datt, offa, dqkv, 2 * C, T, C, T, Bp, sPt, sa, sq, accumulate=True)
+        ops.bmm(Pm, 0, datt, 0, dqkv, 2 * C, T, C, T, Bp, sPt, sa, sq, pair2=(Pd, 0, datt, offa))
         ops.bmm(Pm, 0, datt, offa, dqkv, half + 2 * C, T, C, T, Bp, sPt, sa, sq)
         # Pbar = abar v^T + adotbar vdot^T ; Pdotbar = adotbar v^T
         Pb, Pdb = torch.empty_like(Pm), torch.empty_like(Pm)
         svT = (T * ld, 1, ld)                                            # B(k=c, j=s) = v[s][c]
-        ops.bmm(datt, 0, qkv, 2 * C, Pb, 0, T, T, C, Bp, sa, svT, sP)
-        ops.bmm(datt, offa, qkv, half + 2 * C, Pb, 0, T, T, C, Bp, sa, svT, sP, accumulate=True)
+        ops.bmm(datt, 0, qkv, 2 * C, Pb, 0, T, T, C, Bp, sa, svT, sP, pair2=(datt, offa, qkv, half + 2 * C))
         ops.bmm(datt, offa, qkv, 2 * C, Pdb, 0, T, T, C, Bp, sa, svT, sP)
         ops.softmax_dual_backward(Pm, Wd, Pb, Pdb, T)                   # Pb <- Wbar, Pdb <- Wdotbar
         # qbar = s2 (Wbar k + Wdotbar kdot) ; qdotbar = s2 Wdotbar k
-        ops.bmm(Pb, 0, qkv, C, dqkv, 0, T, C, T, Bp, sP, sq, sq, alpha=s2)
-        ops.bmm(Pdb, 0, qkv, half + C, dqkv, 0, T, C, T, Bp, sP, sq, sq, alpha=s2, accumulate=True)
+        ops.bmm(Pb, 0, qkv, C, dqkv, 0, T, C, T, Bp, sP, sq, sq, alpha=s2, pair2=(Pdb, 0, qkv, half + C))
         ops.bmm(Pdb, 0, qkv, C, dqkv, half, T, C, T, Bp, sP, sq, sq, alpha=s2)
         # kbar = s2 (Wbar^T q + Wdotbar^T qdot) ; kdotbar = s2 Wdotbar^T q
-        ops.bmm(Pb, 0, qkv, 0, dqkv, C, T, C, T, Bp, sPt, sq, sq, alpha=s2)
-        ops.bmm(Pdb, 0, qkv, half, dqkv, C, T, C, T, Bp, sPt, sq, sq, alpha=s2, accumulate=True)
+        ops.bmm(Pb, 0, qkv, 0, dqkv, C, T, C, T, Bp, sPt, sq, sq, alpha=s2, pair2=(Pdb, 0, qkv, half))
         ops.bmm(Pdb, 0, qkv, 0, dqkv, half + C, T, C, T, Bp, sPt, sq, sq, alpha=s2)
         (dhn,) = a.qkv.backward(dqkv, [hn], N, 1, T, Bp)
         dx = self._gn_bwd(a.m.norm, xin, st, dhn, Bp, T, C, False)

@@ -203,96 +203,139 @@ __global__ void __launch_bounds__(256) k_gn_bwd_apply(GnArgs A) {
 }
 
 // ------------------------------------------------------------------ batched GEMM
-// C[b](i,j) (+)= alpha * sum_k A[b](i,k) B[b](k,j) with arbitrary element strides; one wave
-// computes a (16 MT) x (16 NT) tile, 4 waves a 2x2 arrangement of them.
+// C[b](i,j) (+)= alpha * ( sum_k A[b](i,k) B[b](k,j)  [+ sum_k A2[b](i,k) B2[b](k,j)] ) with element strides.
+// The optional second operand pair (same strides) fuses the two-term products of the dual attention
+// (Wdot = qdot k^T + q kdot^T, adot = Pdot v + P vdot, and their adjoints) into one pass over the output.
+// One wave computes a (16 MT) x (16 NT) tile, 4 waves a 2x2 arrangement.  K runs in groups of 16 with the
+// permuted mapping k = 16g + 4q + r (lane quarter q, MFMA step r): an operand that is contiguous along K is
+// read with one 16-B load per group (AVEC / BVEC), otherwise with 4 coalesced dword loads.  The host swaps the
+// operand roles so that the output's contiguous dimension is the MFMA row index: the 4 accumulator registers of
+// a lane are then 4 consecutive addresses and the tile is stored with 16-B stores (CVEC).
 struct BmmArgs {
-  const float* A; const float* B; float* C;
+  const float* A; const float* B; const float* A2; const float* B2; float* C;
   int M, N, K, batch;
   long sAb, sAi, sAk, sBb, sBk, sBj, sCb, sCi, sCj;
   float alpha; int accumulate;
 };
-template <int MT, int NT, bool KVEC>   // KVEC: sAk == 1 && sBk == 1 (both operands contiguous along K, K % 16 == 0)
+template <bool VEC>
+__device__ __forceinline__ f32x4 bmm_frag(const float* p, long sk, bool valid) {
+  if (!valid) return f32x4{0, 0, 0, 0};
+  if (VEC) return *reinterpret_cast<const f32x4*>(p);
+  return f32x4{p[0], p[sk], p[2 * sk], p[3 * sk]};
+}
+template <int MT, int NT, bool AVEC, bool BVEC>
 __global__ void __launch_bounds__(256) k_bmm(BmmArgs P) {
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, il = lane & 15, q = lane >> 4;
   const int tiles_n = (P.N + 32 * NT - 1) / (32 * NT);
   const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
   const int i0 = tm * 32 * MT + (w >> 1) * 16 * MT, j0 = tn * 32 * NT + (w & 1) * 16 * NT;
   if (i0 >= P.M || j0 >= P.N) return;
-  const float* Ab = P.A + (size_t)blockIdx.y * P.sAb;
-  const float* Bb = P.B + (size_t)blockIdx.y * P.sBb;
   f32x4 acc[MT][NT];
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0, 0, 0, 0};
   bool vi[MT], vj[NT];
-  const float* ap[MT];
-  const float* bp[NT];
 #pragma unroll
-  for (int m = 0; m < MT; ++m) { const int i = i0 + 16 * m + il; vi[m] = i < P.M; ap[m] = Ab + (size_t)(vi[m] ? i : 0) * P.sAi; }
+  for (int m = 0; m < MT; ++m) vi[m] = i0 + 16 * m + il < P.M;
 #pragma unroll
-  for (int n = 0; n < NT; ++n) { const int j = j0 + 16 * n + il; vj[n] = j < P.N; bp[n] = Bb + (size_t)(vj[n] ? j : 0) * P.sBj; }
-  if (KVEC) {
-    for (int k0 = 0; k0 < P.K; k0 += 16) {
-      f32x4 a[MT], bb[NT];
+  for (int n = 0; n < NT; ++n) vj[n] = j0 + 16 * n + il < P.N;
+  const int ngroups = P.K >> 4;                     // host guarantees K % 16 == 0
+  for (int pair = 0; pair < 2; ++pair) {
+    const float* Ab = (pair ? P.A2 : P.A);
+    const float* Bb = (pair ? P.B2 : P.B);
+    if (!Ab) break;
+    Ab += (size_t)blockIdx.y * P.sAb;
+    Bb += (size_t)blockIdx.y * P.sBb;
+    const float* ap[MT];
+    const float* bp[NT];
 #pragma unroll
-      for (int m = 0; m < MT; ++m) a[m] = vi[m] ? *reinterpret_cast<const f32x4*>(ap[m] + k0 + 4 * q) : f32x4{0, 0, 0, 0};
+    for (int m = 0; m < MT; ++m) ap[m] = Ab + (size_t)(vi[m] ? i0 + 16 * m + il : 0) * P.sAi + (size_t)(4 * q) * P.sAk;
 #pragma unroll
-      for (int n = 0; n < NT; ++n) bb[n] = vj[n] ? *reinterpret_cast<const f32x4*>(bp[n] + k0 + 4 * q) : f32x4{0, 0, 0, 0};
+    for (int n = 0; n < NT; ++n) bp[n] = Bb + (size_t)(vj[n] ? j0 + 16 * n + il : 0) * P.sBj + (size_t)(4 * q) * P.sBk;
+    const size_t stepA = (size_t)16 * P.sAk, stepB = (size_t)16 * P.sBk;
+    f32x4 na[MT], nb[NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) na[m] = bmm_frag<AVEC>(ap[m], P.sAk, vi[m]);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) nb[n] = bmm_frag<BVEC>(bp[n], P.sBk, vj[n]);
+    for (int g = 0; g < ngroups; ++g) {
+      f32x4 a[MT], b[NT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) { a[m] = na[m]; ap[m] += stepA; }
+#pragma unroll
+      for (int n = 0; n < NT; ++n) { b[n] = nb[n]; bp[n] += stepB; }
+      if (g + 1 < ngroups) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) na[m] = bmm_frag<AVEC>(ap[m], P.sAk, vi[m]);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) nb[n] = bmm_frag<BVEC>(bp[n], P.sBk, vj[n]);
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int n = 0; n < NT; ++n) acc[m][n] = mfma16u(a[m][r], bb[n][r], acc[m][n]);
-    }
-  } else {
-    // lane (., q) walks k = q, q+4, ...: pointers advance by 4 strides, one iteration ahead in registers
-    const size_t stepA = (size_t)4 * P.sAk, stepB = (size_t)4 * P.sBk;
-#pragma unroll
-    for (int m = 0; m < MT; ++m) ap[m] += (size_t)q * P.sAk;
-#pragma unroll
-    for (int n = 0; n < NT; ++n) bp[n] += (size_t)q * P.sBk;
-    float na[MT], nb[NT];
-    {
-      const bool vk = q < P.K;
-#pragma unroll
-      for (int m = 0; m < MT; ++m) na[m] = (vi[m] && vk) ? *ap[m] : 0.f;
-#pragma unroll
-      for (int n = 0; n < NT; ++n) nb[n] = (vj[n] && vk) ? *bp[n] : 0.f;
-    }
-    for (int k0 = 0; k0 < P.K; k0 += 4) {
-      float a[MT], bb[NT];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) { a[m] = na[m]; ap[m] += stepA; }
-#pragma unroll
-      for (int n = 0; n < NT; ++n) { bb[n] = nb[n]; bp[n] += stepB; }
-      const bool vk = k0 + 4 + q < P.K;
-#pragma unroll
-      for (int m = 0; m < MT; ++m) na[m] = (vi[m] && vk) ? *ap[m] : 0.f;
-#pragma unroll
-      for (int n = 0; n < NT; ++n) nb[n] = (vj[n] && vk) ? *bp[n] : 0.f;
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n) acc[m][n] = mfma16u(a[m], bb[n], acc[m][n]);
+          for (int n = 0; n < NT; ++n) acc[m][n] = mfma16u(a[m][r], b[n][r], acc[m][n]);
     }
   }
   float* Cb = P.C + (size_t)blockIdx.y * P.sCb;
+  const bool cvec = P.sCi == 1 && (P.sCj & 3) == 0 && (P.sCb & 3) == 0 && ((reinterpret_cast<uintptr_t>(P.C) & 15) == 0);
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       const int j = j0 + 16 * n + il;
       if (j >= P.N) continue;
+      const int i = i0 + 16 * m + 4 * q;
+      if (i >= P.M) continue;
+      f32x4 v = P.alpha * acc[m][n];
+      if (cvec && i + 3 < P.M) {
+        float* cp = Cb + (size_t)j * P.sCj + i;
+        if (P.accumulate) v += *reinterpret_cast<const f32x4*>(cp);
+        *reinterpret_cast<f32x4*>(cp) = v;
+      } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = i0 + 16 * m + 4 * q + r;
-        if (i >= P.M) continue;
-        float* cp = Cb + (size_t)i * P.sCi + (size_t)j * P.sCj;
-        const float v = P.alpha * acc[m][n][r];
-        *cp = P.accumulate ? *cp + v : v;
+        for (int r = 0; r < 4; ++r) {
+          if (i + r >= P.M) continue;
+          float* cp = Cb + (size_t)(i + r) * P.sCi + (size_t)j * P.sCj;
+          *cp = P.accumulate ? *cp + v[r] : v[r];
+        }
       }
+    }
+}
+
+// generic-K fallback (K % 16 != 0): scalar, one k per lane quarter
+__global__ void __launch_bounds__(256) k_bmm_slow(BmmArgs P) {
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, il = lane & 15, q = lane >> 4;
+  const int tiles_n = (P.N + 31) / 32;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+  const int i0 = tm * 32 + (w >> 1) * 16, j0 = tn * 32 + (w & 1) * 16;
+  if (i0 >= P.M || j0 >= P.N) return;
+  f32x4 acc = {0, 0, 0, 0};
+  const bool vi = i0 + il < P.M, vj = j0 + il < P.N;
+  for (int pair = 0; pair < 2; ++pair) {
+    const float* Ab = (pair ? P.A2 : P.A);
+    const float* Bb = (pair ? P.B2 : P.B);
+    if (!Ab) break;
+    Ab += (size_t)blockIdx.y * P.sAb + (size_t)(vi ? i0 + il : 0) * P.sAi;
+    Bb += (size_t)blockIdx.y * P.sBb + (size_t)(vj ? j0 + il : 0) * P.sBj;
+    for (int k0 = 0; k0 < P.K; k0 += 4) {
+      const int k = k0 + q;
+      const float a = (vi && k < P.K) ? Ab[(size_t)k * P.sAk] : 0.f;
+      const float b = (vj && k < P.K) ? Bb[(size_t)k * P.sBk] : 0.f;
+      acc = mfma16u(a, b, acc);
+    }
+  }
+  float* Cb = P.C + (size_t)blockIdx.y * P.sCb;
+  const int j = j0 + il;
+  if (j < P.N)
+    for (int r = 0; r < 4; ++r) {
+      const int i = i0 + 4 * q + r;
+      if (i >= P.M) continue;
+      float* cp = Cb + (size_t)i * P.sCi + (size_t)j * P.sCj;
+      const float v = P.alpha * acc[r];
+      *cp = P.accumulate ? *cp + v : v;
     }
 }
 
@@ -497,17 +540,33 @@ int msgm_groupnorm_dual_backward(const float* x, const float* gamma, const float
   return msgm_check_launch();
 }
 
-int msgm_bmm(const float* A, const float* B, float* C, int32_t M, int32_t N, int32_t K, int32_t batch, int64_t sAb, int64_t sAi,
-             int64_t sAk, int64_t sBb, int64_t sBk, int64_t sBj, int64_t sCb, int64_t sCi, int64_t sCj, float alpha,
-             int32_t accumulate, msgm_stream_t stream) {
-  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0) return MSGM_E_BADARG;
-  BmmArgs P{A, B, C, M, N, K, batch, sAb, sAi, sAk, sBb, sBk, sBj, sCb, sCi, sCj, alpha, accumulate};
-  const bool kvec = sAk == 1 && sBk == 1 && (K % 16 == 0) && (sAi % 4 == 0) && (sBj % 4 == 0) && (sAb % 4 == 0) &&
-                    (sBb % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0;
-  const int tiles = ((M + 63) / 64) * ((N + 63) / 64);
+int msgm_bmm(const float* A, const float* B, const float* A2, const float* B2, float* C, int32_t M, int32_t N, int32_t K,
+             int32_t batch, int64_t sAb, int64_t sAi, int64_t sAk, int64_t sBb, int64_t sBk, int64_t sBj, int64_t sCb,
+             int64_t sCi, int64_t sCj, float alpha, int32_t accumulate, msgm_stream_t stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || ((A2 == nullptr) != (B2 == nullptr))) return MSGM_E_BADARG;
+  BmmArgs P{A, B, A2, B2, C, M, N, K, batch, sAb, sAi, sAk, sBb, sBk, sBj, sCb, sCi, sCj, alpha, accumulate};
+  if (sCj == 1 && sCi != 1) {
+    // C^T = B^T A^T: make the output's contiguous dimension the MFMA row index (16-B stores)
+    P.A = B; P.B = A; P.A2 = B2; P.B2 = A2;
+    P.M = N; P.N = M;
+    P.sAb = sBb; P.sAi = sBj; P.sAk = sBk;
+    P.sBb = sAb; P.sBk = sAk; P.sBj = sAi;
+    P.sCi = sCj; P.sCj = sCi;
+  }
+  if (K % 16) {
+    dim3 grid((unsigned)(((P.M + 31) / 32) * ((P.N + 31) / 32)), (unsigned)batch);
+    hipLaunchKernelGGL(k_bmm_slow, grid, dim3(256), 0, S(stream), P);
+    return msgm_check_launch();
+  }
+  auto al16 = [](const float* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const bool avec = P.sAk == 1 && (P.sAi % 4 == 0) && (P.sAb % 4 == 0) && al16(P.A) && al16(P.A2);
+  const bool bvec = P.sBk == 1 && (P.sBj % 4 == 0) && (P.sBb % 4 == 0) && al16(P.B) && al16(P.B2);
+  const int tiles = ((P.M + 63) / 64) * ((P.N + 63) / 64);
   dim3 grid((unsigned)tiles, (unsigned)batch);
-  if (kvec) hipLaunchKernelGGL((k_bmm<2, 2, true>), grid, dim3(256), 0, S(stream), P);
-  else hipLaunchKernelGGL((k_bmm<2, 2, false>), grid, dim3(256), 0, S(stream), P);
+  if (avec && bvec) hipLaunchKernelGGL((k_bmm<2, 2, true, true>), grid, dim3(256), 0, S(stream), P);
+  else if (avec) hipLaunchKernelGGL((k_bmm<2, 2, true, false>), grid, dim3(256), 0, S(stream), P);
+  else if (bvec) hipLaunchKernelGGL((k_bmm<2, 2, false, true>), grid, dim3(256), 0, S(stream), P);
+  else hipLaunchKernelGGL((k_bmm<2, 2, false, false>), grid, dim3(256), 0, S(stream), P);
   return msgm_check_launch();
 }
 

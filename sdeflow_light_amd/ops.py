@@ -391,15 +391,22 @@ def groupnorm_dual_backward(x, gamma, beta, stats, gout, dgamma, dbeta, Bp, P, C
     return gx
 
 
-def bmm(A, a_off, B, b_off, Cm, c_off, M, N, K, batch, sA, sB, sC, alpha=1.0, accumulate=False):
-    """C[b](i,j) (+)= alpha sum_k A[b](i,k) B[b](k,j); sA = (batch, i, k), sB = (batch, k, j), sC = (batch, i, j)
-    element strides; *_off are element offsets into the given tensors (channel slices of a fused qkv tensor)."""
+def bmm(A, a_off, B, b_off, Cm, c_off, M, N, K, batch, sA, sB, sC, alpha=1.0, accumulate=False, pair2=None):
+    """C[b](i,j) (+)= alpha (sum_k A[b](i,k) B[b](k,j) [+ A2.B2]); sA = (batch, i, k), sB = (batch, k, j),
+    sC = (batch, i, j) element strides; *_off are element offsets into the given tensors (channel slices of a fused
+    qkv tensor).  pair2 = (A2, a2_off, B2, b2_off): a second product with the same strides, summed in registers."""
     def span(off, s, dims):
         return off + sum((d - 1) * st for d, st in zip(dims, s)) + 1
     if span(a_off, sA, (batch, M, K)) > A.numel() or span(b_off, sB, (batch, K, N)) > B.numel() or \
             span(c_off, sC, (batch, M, N)) > Cm.numel():
         raise MsgmError("bmm: strides run past the end of a tensor")
-    check(lib().msgm_bmm(ptr(f32(A)) + 4 * a_off, ptr(f32(B)) + 4 * b_off, ptr(f32(Cm)) + 4 * c_off, M, N, K, batch,
+    pa2 = pb2 = None
+    if pair2 is not None:
+        A2, a2_off, B2, b2_off = pair2
+        if span(a2_off, sA, (batch, M, K)) > A2.numel() or span(b2_off, sB, (batch, K, N)) > B2.numel():
+            raise MsgmError("bmm: second pair runs past the end of a tensor")
+        pa2, pb2 = ptr(f32(A2)) + 4 * a2_off, ptr(f32(B2)) + 4 * b2_off
+    check(lib().msgm_bmm(ptr(f32(A)) + 4 * a_off, ptr(f32(B)) + 4 * b_off, pa2, pb2, ptr(f32(Cm)) + 4 * c_off, M, N, K, batch,
                          sA[0], sA[1], sA[2], sB[0], sB[1], sB[2], sC[0], sC[1], sC[2], float(alpha), int(bool(accumulate)),
                          stream()), "msgm_bmm")
 
