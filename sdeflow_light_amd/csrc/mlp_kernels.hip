@@ -36,31 +36,38 @@ __device__ unsigned long long g_stamps[16];
 #define STAMP_FLUSH
 #endif
 #define ACT_P 132   // LDS pitch of an activation row ([sample][feature])
-#define SM_P 36     // LDS pitch of the small per-sample rows (h0, abar, partials)
-#define DPAD 32     // padded in/out width of the small layers
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// ---- LDS carve (floats) ----------------------------------------------------
-#define OFF_X 0
-#define OFF_Y (OFF_X + 32 * ACT_P)
-#define OFF_Z (OFF_Y + 32 * ACT_P)
-#define OFF_U (OFF_Z + 32 * ACT_P)
-#define OFF_H0 (OFF_U + 32 * ACT_P)
-#define OFF_ABAR (OFF_H0 + 32 * SM_P)
-#define OFF_PART (OFF_ABAR + 32 * SM_P)
-#define OFF_W1 (OFF_PART + 4 * 32 * SM_P)
-#define OFF_W4 (OFF_W1 + HID * SM_P)
-#define OFF_B1 (OFF_W4 + DPAD * ACT_P)
-#define OFF_B2 (OFF_B1 + HID)
-#define OFF_B3 (OFF_B2 + HID)
-#define OFF_B4 (OFF_B3 + HID)
-#define OFF_DB4 (OFF_B4 + DPAD)
-#define OFF_RED (OFF_DB4 + 16 * DPAD)
-#define LDS_FLOATS (OFF_RED + 64)
-#define LDS_BYTES (LDS_FLOATS * 4)
+// ---- LDS carve (floats), per (mode, width) ------------------------------------
+// NARROW nets (in_dim <= 16 and d <= 16) use 20-float small rows and 16 padded outputs; the forward / sampler
+// modes drop the backward-only buffers — 67 KB instead of 134 KB, so TWO workgroups share a CU there and each
+// one's barrier bubbles are filled by the other's MFMAs.
+template <int MODE, bool WIDE>
+struct MlpLds {
+  static constexpr int SMP = WIDE ? 36 : 20;       // pitch of h0 / abar / partial rows
+  static constexpr int DP = WIDE ? 32 : 16;        // padded output width
+  static constexpr bool TRAIN = MODE == 2;
+  static constexpr int X = 0;
+  static constexpr int Y = X + 32 * ACT_P;
+  static constexpr int Z = Y + 32 * ACT_P;
+  static constexpr int U = Z + (TRAIN ? 32 * ACT_P : 0);
+  static constexpr int H0 = U + (TRAIN ? 32 * ACT_P : 0);
+  static constexpr int ABAR = H0 + 32 * SMP;
+  static constexpr int PART = ABAR + (TRAIN ? 32 * SMP : 0);
+  static constexpr int W1 = PART + 4 * 32 * SMP;
+  static constexpr int W4 = W1 + HID * SMP;
+  static constexpr int B1 = W4 + DP * ACT_P;
+  static constexpr int B2 = B1 + HID;
+  static constexpr int B3 = B2 + HID;
+  static constexpr int B4 = B3 + HID;
+  static constexpr int DB4 = B4 + 32;
+  static constexpr int RED = DB4 + (TRAIN ? 16 * DP : 0);
+  static constexpr int FLOATS = RED + 64;
+  static constexpr int BYTES = FLOATS * 4;
+};
 
 struct MlpArgs {
   msgm_mlp_params_t P;
@@ -320,11 +327,13 @@ __global__ void __launch_bounds__(256, 1) k_mlp(MlpArgs A) {
   const int tid = threadIdx.x;
   const int w = tid >> 6, lane = tid & 63, il = lane & 15, q = lane >> 4;
   const int d = A.P.d;
-  float* X = lds + OFF_X; float* Y = lds + OFF_Y; float* Z = lds + OFF_Z; float* U = lds + OFF_U;
-  float* H0 = lds + OFF_H0; float* ABAR = lds + OFF_ABAR; float* PART = lds + OFF_PART;
-  float* W1s = lds + OFF_W1; float* W4s = lds + OFF_W4;
-  float* B1s = lds + OFF_B1; float* B2s = lds + OFF_B2; float* B3s = lds + OFF_B3; float* B4s = lds + OFF_B4;
-  float* DB4 = lds + OFF_DB4; float* RED = lds + OFF_RED;
+  using LO = MlpLds<MODE, WIDE>;
+  constexpr int SM_P = LO::SMP, DPAD = LO::DP;
+  float* X = lds + LO::X; float* Y = lds + LO::Y; float* Z = lds + LO::Z; float* U = lds + LO::U;
+  float* H0 = lds + LO::H0; float* ABAR = lds + LO::ABAR; float* PART = lds + LO::PART;
+  float* W1s = lds + LO::W1; float* W4s = lds + LO::W4;
+  float* B1s = lds + LO::B1; float* B2s = lds + LO::B2; float* B3s = lds + LO::B3; float* B4s = lds + LO::B4;
+  float* DB4 = lds + LO::DB4; float* RED = lds + LO::RED;
 
   // ---- one-time staging of the small layers and biases -------------------
   for (int i = tid; i < HID * SM_P; i += 256) {
@@ -336,9 +345,12 @@ __global__ void __launch_bounds__(256, 1) k_mlp(MlpArgs A) {
     W4s[i] = (r < d && c < HID) ? A.P.W4[r * HID + c] : 0.f;
   }
   for (int i = tid; i < HID; i += 256) { B1s[i] = A.P.b1[i]; B2s[i] = A.P.b2[i]; B3s[i] = A.P.b3[i]; }
-  if (tid < DPAD) B4s[tid] = tid < d ? A.P.b4[tid] : 0.f;
-  for (int i = tid; i < 16 * DPAD; i += 256) DB4[i] = 0.f;
-  for (int i = tid; i < 32 * SM_P; i += 256) { H0[i] = 0.f; ABAR[i] = 0.f; }
+  if (tid < 32) B4s[tid] = tid < d ? A.P.b4[tid] : 0.f;
+  if (MODE == MODE_TRAIN) {
+    for (int i = tid; i < 16 * DPAD; i += 256) DB4[i] = 0.f;
+    for (int i = tid; i < 32 * SM_P; i += 256) ABAR[i] = 0.f;
+  }
+  for (int i = tid; i < 32 * SM_P; i += 256) H0[i] = 0.f;
 
   // persistent accumulators (train)
   f32x4 dW2[2][8], dW3[2][8], dW1[2][KT1], dW4[2][OT], db1[2], db2[2], db3[2];
@@ -729,7 +741,7 @@ template <int MODE, bool WIDE>
 static void set_lds_attr() {
   static const int once = [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp<MODE, WIDE>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, MlpLds<MODE, WIDE>::BYTES);
     return 0;
   }();
   (void)once;
@@ -738,8 +750,8 @@ static void set_lds_attr() {
 template <int MODE>
 static int launch_mlp(const MlpArgs& A, int grid, hipStream_t st) {
   const bool wide = A.in_dim > 16 || A.P.d > 16;
-  if (wide) { set_lds_attr<MODE, true>(); hipLaunchKernelGGL((k_mlp<MODE, true>), dim3(grid), dim3(256), LDS_BYTES, st, A); }
-  else { set_lds_attr<MODE, false>(); hipLaunchKernelGGL((k_mlp<MODE, false>), dim3(grid), dim3(256), LDS_BYTES, st, A); }
+  if (wide) { set_lds_attr<MODE, true>(); hipLaunchKernelGGL((k_mlp<MODE, true>), dim3(grid), dim3(256), MlpLds<MODE, true>::BYTES, st, A); }
+  else { set_lds_attr<MODE, false>(); hipLaunchKernelGGL((k_mlp<MODE, false>), dim3(grid), dim3(256), MlpLds<MODE, false>::BYTES, st, A); }
   return msgm_check_launch();
 }
 
@@ -771,7 +783,8 @@ int msgm_mlp_forward(const msgm_mlp_params_t* P, const float* y, const float* t,
   if (!y || !t || !a) return MSGM_E_BADARG;
   A.y = y; A.t = t; A.out = a;
   const int64_t tiles = (B + 31) / 32;
-  return launch_mlp<MODE_FWD>(A, (int)(tiles < MLP_MAX_GRID ? tiles : MLP_MAX_GRID), S(stream));
+  const int64_t cap = 2 * MLP_MAX_GRID;          // forward modes fit two workgroups per CU
+  return launch_mlp<MODE_FWD>(A, (int)(tiles < cap ? tiles : cap), S(stream));
 }
 
 int msgm_mlp_em_step(const msgm_mlp_params_t* P, float* x, int64_t B, const msgm_sde_t* sde, float t, float delta,
@@ -786,7 +799,8 @@ int msgm_mlp_em_step(const msgm_mlp_params_t* P, float* x, int64_t B, const msgm
   A.delta = delta; A.sqrt_delta = (float)sqrt((double)delta); A.lmbd = lmbd;
   A.z = z; A.rng = rng; A.rng_step = rng_step;
   const int64_t tiles = (B + 31) / 32;
-  return launch_mlp<MODE_EM>(A, (int)(tiles < MLP_MAX_GRID ? tiles : MLP_MAX_GRID), S(stream));
+  const int64_t cap = 2 * MLP_MAX_GRID;
+  return launch_mlp<MODE_EM>(A, (int)(tiles < cap ? tiles : cap), S(stream));
 }
 
 int msgm_mlp_ssm_partial(const msgm_mlp_params_t* P, const float* y, const float* t, const float* v, const float* u,
