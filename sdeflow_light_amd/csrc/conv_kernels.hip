@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(256) k_conv_tile(ConvArgs A, int flip, int til
   for (int s = 0; s < CONV_MAX_SRC; ++s) { nch[s] = s < A.nsrc ? (A.C[s] + CT_KC - 1) / CT_KC : 0; total_chunks += nch[s]; }
 
   // ---- staging: halo pixel hp, 16-B column c4 (8 per pixel)
-  constexpr int MAXST = ((TH + 2) * (TW + 2) * (CT_KC / 4) + 255) / 256;
+  constexpr int MAXST = ((TH == 1 ? 1 : TH + 2) * (TW + 2) * (CT_KC / 4) + 255) / 256;   // 1-D: no vertical halo
   f32x4 st[MAXST];
   const int n_items = halo * (CT_KC / 4);
   const int padH = g.padH, padW = g.padW;
@@ -477,6 +477,159 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(WgradArgs A) {
   }
 }
 
+// ------------------------------------------------------------------ wgrad of stride-1 "same" convolutions: LDS tiles
+// k_conv_wgrad re-reads gy and the input once per (tap, channel block) with dword loads.  Here a workgroup owns a
+// (32 co) x (32 c) block of dW for ALL taps (TAPS x 2 x 2 MFMA tiles = 36 accumulators for 3x3) and walks over
+// spatial tiles of TH x TW = 128 output pixels: per tile it stages gy [pixel][co] and the input halo tile
+// [halo pixel][c] ONCE (coalesced 16-B global loads, stored transposed as [channel][pixel] so that the reduction
+// index — the pixel — is contiguous for the MFMA fragments), then every tap reads its shifted window from LDS.
+// Each wave reduces its own 32 pixels; the four partial sums meet in LDS at the end and are added to dWp with one
+// float atomic per element per workgroup.
+#define WT_GP 132
+template <int TH, int TW, int TAPS>
+__global__ void __launch_bounds__(256) k_wgrad_tile(WgradArgs A, int tiles_x, int tiles_y, int tiles_per_wg, int n_tiles) {
+  extern __shared__ __attribute__((aligned(16))) float wt_lds[];
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, il = lane & 15, q = lane >> 4;
+  const ConvGeom g = A.g;
+  const int KH = g.KH, KW = g.KW;
+  const int HH = TH + KH - 1, HW = TW + KW - 1, halo = HH * HW;
+  const int IP = ((halo + 7) & ~7) + 3;                    // pitch of an input channel row: = 3 (mod 8) keeps the
+                                                           // (channel il, pixel 4q) scalar reads at most 2 per bank
+  float* gyT[2] = {wt_lds, wt_lds + 32 * WT_GP + 32 * IP};
+  float* inT[2] = {wt_lds + 32 * WT_GP, wt_lds + 2 * 32 * WT_GP + 32 * IP};
+  const int cblocks = (A.C + 31) / 32;
+  const int coblk = blockIdx.y / cblocks, cblk = blockIdx.y - coblk * cblocks;
+  const int co0 = coblk * 32, c0 = cblk * 32;
+  const int t_beg = blockIdx.x * tiles_per_wg, t_end = min(t_beg + tiles_per_wg, n_tiles);
+  if (t_beg >= t_end) return;
+
+  f32x4 acc[TAPS][2][2];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) { acc[t][m][0] = f32x4{0, 0, 0, 0}; acc[t][m][1] = f32x4{0, 0, 0, 0}; }
+
+  constexpr int MAXIN = ((TH == 1 ? 1 : TH + 2) * (TW + 2) * 8 + 255) / 256;   // 1-D convolutions have no vertical halo
+  f32x4 sg[4], si[MAXIN];
+  const int n_in = halo * 8;
+  auto stage_load = [&](int tile) {
+    int bx = tile;
+    const int tx_i = bx % tiles_x; bx /= tiles_x;
+    const int ty_i = bx % tiles_y;
+    const int n = bx / tiles_y;
+    const int y0 = ty_i * TH, x0 = tx_i * TW;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                           // gy: 128 pixels x 8 column quads
+      const int idx = tid + 256 * k;
+      const int p = idx >> 3, c4 = idx & 7;
+      const int py = p / TW, px = p - py * TW;
+      const int oy = y0 + py, ox = x0 + px, co = co0 + 4 * c4;
+      f32x4 v = {0, 0, 0, 0};
+      if (oy < g.Ho && ox < g.Wo && co < A.Cout)
+        v = *reinterpret_cast<const f32x4*>(A.gy + (((size_t)n * g.Ho + oy) * g.Wo + ox) * A.Cout + co);
+      sg[k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < MAXIN; ++k) {
+      const int idx = tid + 256 * k;
+      f32x4 v = {0, 0, 0, 0};
+      if (idx < n_in) {
+        const int hp = idx >> 3, c4 = idx & 7;
+        const int hy = hp / HW, hx = hp - hy * HW;
+        const int iy = y0 + hy - g.padH, ix = x0 + hx - g.padW, c = c0 + 4 * c4;
+        if (iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi && c < A.C)
+          v = *reinterpret_cast<const f32x4*>(A.src + (((size_t)n * g.Hi + iy) * g.Wi + ix) * A.C + c);
+      }
+      si[k] = v;
+    }
+  };
+  auto stage_store = [&](int b) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int idx = tid + 256 * k;
+      const int p = idx >> 3, c4 = idx & 7;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gyT[b][(4 * c4 + r) * WT_GP + p] = sg[k][r];
+    }
+#pragma unroll
+    for (int k = 0; k < MAXIN; ++k) {
+      const int idx = tid + 256 * k;
+      if (idx < n_in) {
+        const int hp = idx >> 3, c4 = idx & 7;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) inT[b][(4 * c4 + r) * IP + hp] = si[k][r];
+      }
+    }
+  };
+
+  stage_load(t_beg);
+  stage_store(0);
+  __syncthreads();
+  int cur = 0;
+  for (int tile = t_beg; tile < t_end; ++tile) {
+    const bool more = tile + 1 < t_end;
+    if (more) stage_load(tile + 1);
+    const float* gT = gyT[cur];
+    const float* iT = inT[cur];
+#pragma unroll
+    for (int pg2 = 0; pg2 < 2; ++pg2) {
+      const int pg = 2 * w + pg2;                           // this wave's 16-pixel group
+      const int p0 = 16 * pg + 4 * q;                       // pixels p0..p0+3 <-> MFMA steps r = 0..3
+      const int ty = p0 / TW, tx = p0 - ty * TW;
+      f32x4 a[2];
+      a[0] = *reinterpret_cast<const f32x4*>(gT + il * WT_GP + p0);
+      a[1] = *reinterpret_cast<const f32x4*>(gT + (16 + il) * WT_GP + p0);
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {
+        const int kh = t / KW, kw = t - kh * KW;
+        const int hb = (ty + kh) * HW + tx + kw;            // halo index of pixel p0 shifted by the tap
+        float b[2][4];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) b[kt][r] = iT[(16 * kt + il) * IP + hb + r];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            acc[t][m][0] = mfma16c(a[m][r], b[0][r], acc[t][m][0]);
+            acc[t][m][1] = mfma16c(a[m][r], b[1][r], acc[t][m][1]);
+          }
+      }
+    }
+    if (more) stage_store(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+  // cross-wave reduction through LDS (reuse the staging area), then atomics
+  float* red = wt_lds;
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[w * 1024 + ((m * 2 + kt) * 4 + r) * 64 + lane] = acc[t][m][kt][r];
+    __syncthreads();
+    if (w == 0) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int idx = ((m * 2 + kt) * 4 + r) * 64 + lane;
+            const float sum = (red[idx] + red[1024 + idx]) + (red[2048 + idx] + red[3072 + idx]);
+            const int co = co0 + 16 * m + 4 * q + r, c = c0 + 16 * kt + il;
+            if (co < A.Cout && c < A.C) atomicAdd(A.dWp + ((size_t)(t * A.CoutP + co) * A.Ktot + A.koff + c), sum);
+          }
+    }
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------ weight (un)packing
 // Wp[t][r][kp_off + c] = W[r*sr + (col_off + c)*sc + t*st]   (r < rows, c < ncols); zero elsewhere is
 // provided by a memset of Wp before packing.
@@ -644,7 +797,8 @@ int msgm_conv_forward(const msgm_conv_geom_t* geom, const float* src0, int32_t C
   const bool same = geom->strideH == 1 && geom->strideW == 1 && !geom->ups && geom->Hi == geom->Ho && geom->Wi == geom->Wo &&
                     (geom->KH & 1) && (geom->KW & 1) && geom->padH == (geom->KH - 1) / 2 && geom->padW == (geom->KW - 1) / 2 &&
                     geom->KH <= 3 && geom->KW <= 3;
-  if (same && fast && CoutP % 32 == 0 && (int64_t)geom->Ho * geom->Wo >= 64 && !getenv("MSGM_NO_CONV_TILE")) {
+  if (same && fast && CoutP % 32 == 0 && (int64_t)geom->Ho * geom->Wo >= 64 && (geom->Ho > 1 || geom->KH == 1) &&
+      !getenv("MSGM_NO_CONV_TILE")) {
     const bool two_d = geom->Ho > 1;
     const int TH = two_d ? 8 : 1, TW = two_d ? 16 : 128;
     const int tiles_x = (geom->Wo + TW - 1) / TW, tiles_y = (geom->Ho + TH - 1) / TH;
@@ -686,6 +840,42 @@ int msgm_conv_wgrad(const msgm_conv_geom_t* geom, const float* gy, const float* 
   WgradArgs A{to_geom(geom), gy, src, C, koff, dWp, Cout, CoutP, Ktot, 0};
   const int64_t Mtot = (int64_t)geom->N * geom->Ho * geom->Wo;
   const int taps = geom->KH * geom->KW;
+  const bool same = geom->mode == 0 && geom->strideH == 1 && geom->strideW == 1 && !geom->ups && geom->Hi == geom->Ho &&
+                    geom->Wi == geom->Wo && (geom->KH & 1) && (geom->KW & 1) && geom->padH == (geom->KH - 1) / 2 &&
+                    geom->padW == (geom->KW - 1) / 2 && geom->KH <= 3 && geom->KW <= 3;
+  if (same && C % 4 == 0 && Cout % 4 == 0 && (int64_t)geom->Ho * geom->Wo >= 64 && (taps == 1 || taps == 3 || (taps == 9 && geom->Ho > 1)) &&
+      (geom->Ho > 1 || geom->KH == 1) && !getenv("MSGM_NO_WGRAD_TILE")) {
+    const bool two_d = geom->Ho > 1;
+    const int TH = two_d ? 8 : 1, TW = two_d ? 16 : 128;
+    const int tiles_x = (geom->Wo + TW - 1) / TW, tiles_y = (geom->Ho + TH - 1) / TH;
+    const int n_tiles = tiles_x * tiles_y * geom->N;
+    const int yblocks = ((Cout + 31) / 32) * ((C + 31) / 32);
+    int wgs = 1024 / yblocks;                              // ~4 workgroups per CU overall
+    if (wgs < 1) wgs = 1;
+    int per = (n_tiles + wgs - 1) / wgs;
+    if (per < 4) per = n_tiles < 4 ? n_tiles : 4;
+    wgs = (n_tiles + per - 1) / per;
+    const int halo = (TH + geom->KH - 1) * (TW + geom->KW - 1);
+    const int IP = ((halo + 7) & ~7) + 3;
+    size_t lds = (size_t)2 * (32 * WT_GP + 32 * IP) * sizeof(float);
+    if (lds < 4096 * sizeof(float)) lds = 4096 * sizeof(float);
+    dim3 grid((unsigned)wgs, (unsigned)yblocks);
+    // more than 64 KB of dynamic LDS has to be opted into per kernel (160 KB per CU on gfx950)
+#define WT_LAUNCH(TH_, TW_, TP_)                                                                                     \
+  do {                                                                                                               \
+    static const int once = [] {                                                                                     \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_tile<TH_, TW_, TP_>),                         \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                             \
+      return 0;                                                                                                      \
+    }();                                                                                                             \
+    (void)once;                                                                                                      \
+    hipLaunchKernelGGL((k_wgrad_tile<TH_, TW_, TP_>), grid, dim3(256), lds, S(stream), A, tiles_x, tiles_y, per, n_tiles); \
+  } while (0)
+    if (two_d) { if (taps == 9) WT_LAUNCH(8, 16, 9); else if (taps == 3) WT_LAUNCH(8, 16, 3); else WT_LAUNCH(8, 16, 1); }
+    else { if (taps == 3) WT_LAUNCH(1, 128, 3); else WT_LAUNCH(1, 128, 1); }
+#undef WT_LAUNCH
+    return msgm_check_launch();
+  }
   const int coblocks = (Cout + 31) / 32, cblocks = (C + 63) / 64;
   // aim at ~2048 workgroups overall, at least 256 positions each
   int64_t nchunks = 2048 / (int64_t)(coblocks * cblocks * taps);

@@ -750,8 +750,9 @@ static void set_lds_attr() {
 template <int MODE>
 static int launch_mlp(const MlpArgs& A, int grid, hipStream_t st) {
   const bool wide = A.in_dim > 16 || A.P.d > 16;
-  if (wide) { set_lds_attr<MODE, true>(); hipLaunchKernelGGL((k_mlp<MODE, true>), dim3(grid), dim3(256), MlpLds<MODE, true>::BYTES, st, A); }
-  else { set_lds_attr<MODE, false>(); hipLaunchKernelGGL((k_mlp<MODE, false>), dim3(grid), dim3(256), MlpLds<MODE, false>::BYTES, st, A); }
+  constexpr size_t lds_wide = MlpLds<MODE, true>::BYTES, lds_narrow = MlpLds<MODE, false>::BYTES;
+  if (wide) { set_lds_attr<MODE, true>(); hipLaunchKernelGGL((k_mlp<MODE, true>), dim3(grid), dim3(256), lds_wide, st, A); }
+  else { set_lds_attr<MODE, false>(); hipLaunchKernelGGL((k_mlp<MODE, false>), dim3(grid), dim3(256), lds_narrow, st, A); }
   return msgm_check_launch();
 }
 

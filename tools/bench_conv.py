@@ -38,8 +38,33 @@ for (H, Ci, Co) in ((64, 32, 32), (64, 96, 32), (32, 64, 64), (32, 192, 64), (16
         res.append(fl / t / 1e12)
     gy = torch.randn(N * H * H * Co, device=dev)
     dWp = torch.zeros(9 * ops.pad16(Co) * ops.pad16(Ci), device=dev)
+    os.environ["MSGM_NO_WGRAD_TILE"] = "1"
     tw = timeit(lambda: ops.conv_wgrad(geom, gy, x, Ci, 0, dWp, Co, ops.pad16(Co), ops.pad16(Ci)))
-    print(f"  {H}x{H} {Ci:3d}->{Co:3d}: gemm {res[0]:5.1f} TF/s | tile {res[1]:5.1f} TF/s | wgrad {fl / tw / 1e12:5.1f} TF/s")
+    os.environ.pop("MSGM_NO_WGRAD_TILE")
+    tw2 = timeit(lambda: ops.conv_wgrad(geom, gy, x, Ci, 0, dWp, Co, ops.pad16(Co), ops.pad16(Ci)))
+    print(f"  {H}x{H} {Ci:3d}->{Co:3d}: gemm {res[0]:5.1f} TF/s | tile {res[1]:5.1f} TF/s | wgrad {fl / tw / 1e12:5.1f} -> tile {fl / tw2 / 1e12:5.1f} TF/s")
+print("conv1d (k3 s1), dual batch 8192:")
+for (L, Ci, Co) in ((1024, 32, 32), (1024, 64, 32), (512, 64, 64), (512, 128, 64), (256, 128, 128), (256, 256, 128)):
+    Nn = 8192
+    x = torch.randn(Nn * L * Ci, device=dev)
+    Wp = torch.randn(3 * ops.pad16(Co) * ops.pad16(Ci), device=dev) * 0.05
+    out = torch.empty(Nn * L * Co, device=dev)
+    geom = ops.conv_geom(Nn, 1, L, 1, L, 1, 3, 1, 1)
+    fl = 2 * 3 * Ci * Co * Nn * L
+    res = []
+    for env in ("1", None):
+        if env:
+            os.environ["MSGM_NO_CONV_TILE"] = env
+        else:
+            os.environ.pop("MSGM_NO_CONV_TILE", None)
+        res.append(fl / timeit(lambda: ops.conv_forward(geom, x, Ci, Wp, Co, out, n_bias=Nn // 2), 5) / 1e12)
+    gy = torch.randn(Nn * L * Co, device=dev)
+    dWp = torch.zeros(3 * ops.pad16(Co) * ops.pad16(Ci), device=dev)
+    os.environ["MSGM_NO_WGRAD_TILE"] = "1"
+    tw = timeit(lambda: ops.conv_wgrad(geom, gy, x, Ci, 0, dWp, Co, ops.pad16(Co), ops.pad16(Ci)), 5)
+    os.environ.pop("MSGM_NO_WGRAD_TILE")
+    tw2 = timeit(lambda: ops.conv_wgrad(geom, gy, x, Ci, 0, dWp, Co, ops.pad16(Co), ops.pad16(Ci)), 5)
+    print(f"  L={L} {Ci:3d}->{Co:3d}: gemm {res[0]:5.1f} | tile {res[1]:5.1f} | wgrad {fl / tw / 1e12:5.1f} -> tile {fl / tw2 / 1e12:5.1f} TF/s")
 print("attention products (per block, batch = N/2):")
 for (T, C) in ((1024, 64), (256, 128)):
     Bp = N // 2
