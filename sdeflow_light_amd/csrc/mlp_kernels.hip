@@ -37,6 +37,16 @@ __device__ unsigned long long g_stamps[16];
 #endif
 #define ACT_P 132   // LDS pitch of an activation row ([sample][feature])
 
+// Workgroup barrier for LDS hand-offs inside the tile loop.  __syncthreads() also drains vmcnt, i.e. it would wait for
+// the weight fragments and the next tile's inputs that are deliberately left in flight across phase boundaries;
+// LDS traffic completes in order, so lgkmcnt(0) + s_barrier is all an LDS producer/consumer pair needs.  hipcc's
+// own waitcnt insertion still guards the first use of every in-flight load.
+#ifndef MLP_FULL_BARRIER
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#else
+__device__ __forceinline__ void lds_barrier() { __syncthreads(); }
+#endif
+
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
@@ -45,19 +55,28 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 // NARROW nets (in_dim <= 16 and d <= 16) use 20-float small rows and 16 padded outputs; the forward / sampler
 // modes drop the backward-only buffers — 67 KB instead of 134 KB, so TWO workgroups share a CU there and each
 // one's barrier bubbles are filled by the other's MFMAs.
-template <int MODE, bool WIDE>
+template <int MODE, bool WIDE, int NW>
 struct MlpLds {
   static constexpr int SMP = WIDE ? 36 : 20;       // pitch of h0 / abar / partial rows
   static constexpr int DP = WIDE ? 32 : 16;        // padded output width
   static constexpr bool TRAIN = MODE == 2;
+  static constexpr int SPT = TRAIN ? 16 : 32;      // samples per tile
+  static constexpr int DMAX = WIDE ? 32 : 16;      // raw rows are packed (pitch d), sized for d <= DMAX
+  // one raw input buffer: the tile's y | v | u chunks, t and cst, copied verbatim from global one tile ahead
+  static constexpr int RY = 0;
+  static constexpr int RV = RY + SPT * DMAX;
+  static constexpr int RU = RV + (TRAIN ? SPT * DMAX : 0);
+  static constexpr int RT = RU + (TRAIN ? SPT * DMAX : 0);
+  static constexpr int RC = RT + 32;
+  static constexpr int RAWN = RC + 16;
   static constexpr int X = 0;
   static constexpr int Y = X + 32 * ACT_P;
   static constexpr int Z = Y + 32 * ACT_P;
   static constexpr int U = Z + (TRAIN ? 32 * ACT_P : 0);
   static constexpr int H0 = U + (TRAIN ? 32 * ACT_P : 0);
-  static constexpr int ABAR = H0 + 32 * SMP;
+  static constexpr int ABAR = H0 + 2 * 32 * SMP;   // h0 is double-buffered (built one tile ahead)
   static constexpr int PART = ABAR + (TRAIN ? 32 * SMP : 0);
-  static constexpr int W1 = PART + 4 * 32 * SMP;
+  static constexpr int W1 = PART + NW * 32 * SMP;   // one layer-4 K-slice per wave
   static constexpr int W4 = W1 + HID * SMP;
   static constexpr int B1 = W4 + DP * ACT_P;
   static constexpr int B2 = B1 + HID;
@@ -65,7 +84,8 @@ struct MlpLds {
   static constexpr int B4 = B3 + HID;
   static constexpr int DB4 = B4 + 32;
   static constexpr int RED = DB4 + (TRAIN ? 16 * DP : 0);
-  static constexpr int FLOATS = RED + 64;
+  static constexpr int RAW = RED + 64;
+  static constexpr int FLOATS = RAW + 2 * RAWN;
   static constexpr int BYTES = FLOATS * 4;
 };
 
@@ -106,11 +126,25 @@ __device__ __forceinline__ float swish0(float z) { return z * __builtin_amdgcn_r
 // A fragment of one 128x128 weight for this wave's 32 output rows, k-group g:
 //  !TR: rows = out features of W (forward);  A[r] = W[32w+16it+il][16g+4q+r]
 //   TR: rows = in features (dgrad, A = W^T); A[r] = W[16g+4q+r][32w+16it+il]
+// Buffer loads (SGPR descriptor + ONE per-lane 32-bit offset + a compile-time scalar offset per fragment) keep the
+// address arithmetic out of the vector registers: with flat loads hipcc hoists a 64-bit address per (matrix, k-group)
+// out of the persistent tile loop — 32+ VGPRs — and spills.
+typedef __amdgpu_buffer_rsrc_t wrsrc_t;
+__device__ __forceinline__ wrsrc_t make_wrsrc(const float* W) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, HID * HID * 4, 0x00020000);
+}
 template <bool TR>
-__device__ __forceinline__ f32x4 load_afrag(const float* __restrict__ W, int w, int il, int q, int it, int g) {
-  if (!TR) return *reinterpret_cast<const f32x4*>(W + (32 * w + 16 * it + il) * HID + 16 * g + 4 * q);
-  const float* p = W + (16 * g + 4 * q) * HID + 32 * w + 16 * it + il;
-  return f32x4{p[0], p[HID], p[2 * HID], p[3 * HID]};
+__device__ __forceinline__ f32x4 load_afrag(wrsrc_t W, int fb, int il, int q, int it, int g) {
+  if (!TR) {
+    const int voff = ((fb + il) * HID + 4 * q) * 4;
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(W, voff, (16 * it * HID + 16 * g) * 4, 0));
+  }
+  const int voff = (4 * q * HID + fb + il) * 4;
+  const int so = (16 * g * HID + 16 * it) * 4;
+  f32x4 v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(W, voff + r * HID * 4, so, 0));
+  return v;
 }
 
 // The weights are streamed from L2 into registers PF k-groups ahead of use
@@ -135,9 +169,9 @@ __device__ __forceinline__ f32x4 load_afrag(const float* __restrict__ W, int w, 
 struct WPre { f32x4 a[PF]; };     // fragments j = 0..PF-1 of the next gemm (j = it*8 + g: row tile 0 first)
 
 template <bool TR>
-__device__ __forceinline__ void prefetch_w(const float* __restrict__ W, int w, int il, int q, WPre& pre) {
+__device__ __forceinline__ void prefetch_w(wrsrc_t W, int fb, int il, int q, WPre& pre) {
 #pragma unroll
-  for (int j = 0; j < PF; ++j) pre.a[j] = load_afrag<TR>(W, w, il, q, j >> 3, j & 7);
+  for (int j = 0; j < PF; ++j) pre.a[j] = load_afrag<TR>(W, fb, il, q, j >> 3, j & 7);
 }
 
 // acc[it][ck] += sum_k A[it][k] * buf[ck*16+il][k]   (K = 128, B operand from LDS), row tile 0 first, then
@@ -146,9 +180,11 @@ __device__ __forceinline__ void prefetch_w(const float* __restrict__ W, int w, i
 // HOOK: while the matrix pipe works on row tile 1, the VALU applies bias + Swish to the finished row tile 0
 // (an MFMA occupies the vector issue port for only 8 of its 32 cycles):
 //   HOOK 1 (train): h[0][0] = s(z), h[0][1] = s'(z) zdot;   HOOK 2 (inference): both column halves are primal.
-template <bool TR, int HOOK>
-__device__ __forceinline__ void gemm128(const float* __restrict__ W, const WPre& pre, const float* buf, int w, int il,
-                                        int q, f32x4 (&acc)[2][2], const float* bias_lds, f32x4 (&h)[2][2]) {
+template <bool TR, int HOOK, int IT>
+__device__ __forceinline__ void gemm128(wrsrc_t W, const WPre& pre, const float* buf, int fb, int il,
+                                        int q, f32x4 (&acc)[IT][2], const float* bias_lds, f32x4 (&h)[IT][2]) {
+  constexpr int NJ = 8 * IT;
+  constexpr bool OVL = MLP_OVL_FWD && HOOK && IT == 2;   // a second row tile to hide the first one's Swish under
   f32x4 ring[PF + 1];
 #pragma unroll
   for (int j = 0; j < PF; ++j) ring[j] = pre.a[j];
@@ -156,20 +192,20 @@ __device__ __forceinline__ void gemm128(const float* __restrict__ W, const WPre&
   const float* bp1 = buf + (16 + il) * ACT_P + 4 * q;
   f32x4 bn0 = *reinterpret_cast<const f32x4*>(bp0), bn1 = *reinterpret_cast<const f32x4*>(bp1);
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     const int it = j >> 3;
     const f32x4 b0 = bn0, b1 = bn1;
-    if (j + PF < 16) ring[(j + PF) % (PF + 1)] = load_afrag<TR>(W, w, il, q, (j + PF) >> 3, (j + PF) & 7);
-    if (j + 1 < 16) {
+    if (j + PF < NJ) ring[(j + PF) % (PF + 1)] = load_afrag<TR>(W, fb, il, q, (j + PF) >> 3, (j + PF) & 7);
+    if (j + 1 < NJ) {
       bn0 = *reinterpret_cast<const f32x4*>(bp0 + 16 * ((j + 1) & 7));
       bn1 = *reinterpret_cast<const f32x4*>(bp1 + 16 * ((j + 1) & 7));
     }
-    if (MLP_OVL_FWD && HOOK && j == 8) {        // row tile 0 is complete: bias
-      const f32x4 bb = *reinterpret_cast<const f32x4*>(bias_lds + 32 * w + 4 * q);
+    if (OVL && j == 8) {        // row tile 0 is complete: bias
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(bias_lds + fb + 4 * q);
       acc[0][0] += bb;
       if (HOOK == 2) acc[0][1] += bb;
     }
-    if (MLP_OVL_FWD && HOOK && j >= 8 && j < 12) {   // one register per step
+    if (OVL && j >= 8 && j < 12) {   // one register per step
       const int r = j - 8;
       if (HOOK == 1) {
         float s0, s1, s2;
@@ -182,98 +218,79 @@ __device__ __forceinline__ void gemm128(const float* __restrict__ W, const WPre&
     const f32x4 a = ring[j % (PF + 1)];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      if (it == 0) { acc[0][0] = mfma16(a[r], b0[r], acc[0][0]); acc[0][1] = mfma16(a[r], b1[r], acc[0][1]); }
-      else { acc[1][0] = mfma16(a[r], b0[r], acc[1][0]); acc[1][1] = mfma16(a[r], b1[r], acc[1][1]); }
+      acc[it][0] = mfma16(a[r], b0[r], acc[it][0]);
+      acc[it][1] = mfma16(a[r], b1[r], acc[it][1]);
     }
-    if (MLP_HINTS && HOOK && j >= 8 && j < 12) {
+    if (MLP_HINTS && OVL && j >= 8 && j < 12) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x002, 6, 0); }
     }
     if (MLP_SB) __builtin_amdgcn_sched_barrier(0);
   }
-  if (!MLP_OVL_FWD && HOOK) {
-    const f32x4 bb = *reinterpret_cast<const f32x4*>(bias_lds + 32 * w + 4 * q);
-    acc[0][0] += bb;
-    if (HOOK == 2) acc[0][1] += bb;
+}
+// row tiles whose bias + Swish the caller still has to apply after gemm128<.., HOOK != 0, IT>
+template <int IT> struct GemmTail { static constexpr int FIRST = (MLP_OVL_FWD && IT == 2) ? 1 : 0; };
+
+// bias + (dual) Swish of row tiles [first, IT): train -> h = (s(z), s'(z) zdot); inference -> both halves primal
+template <bool TRAIN, int IT>
+__device__ __forceinline__ void bias_swish(f32x4 (&z)[IT][2], f32x4 (&h)[IT][2], const float* bias_lds, int fb, int q, int first) {
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    if (it < first) continue;
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(bias_lds + fb + 16 * it + 4 * q);
+    z[it][0] += bb;
+    if (!TRAIN) z[it][1] += bb;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      if (HOOK == 1) {
-        float s0, s1, s2;
-        swish012(acc[0][0][r], s0, s1, s2);
-        h[0][0][r] = s0; h[0][1][r] = s1 * acc[0][1][r];
-      } else { h[0][0][r] = swish0(acc[0][0][r]); h[0][1][r] = swish0(acc[0][1][r]); }
+      if (TRAIN) {
+        float s0, s1, s2; swish012(z[it][0][r], s0, s1, s2);
+        h[it][0][r] = s0; h[it][1][r] = s1 * z[it][1][r];
+      } else { h[it][0][r] = swish0(z[it][0][r]); h[it][1][r] = swish0(z[it][1][r]); }
     }
   }
 }
 
 // store this wave's C-layout tile pair to an activation buffer ([sample][feature])
-__device__ __forceinline__ void store_act(float* buf, int w, int il, int q, const f32x4 (&h)[2][2]) {
+template <int IT>
+__device__ __forceinline__ void store_act(float* buf, int fb, int il, int q, const f32x4 (&h)[IT][2]) {
 #pragma unroll
-  for (int it = 0; it < 2; ++it)
+  for (int it = 0; it < IT; ++it)
 #pragma unroll
     for (int ck = 0; ck < 2; ++ck)
-      *reinterpret_cast<f32x4*>(buf + (ck * 16 + il) * ACT_P + 32 * w + 16 * it + 4 * q) = h[it][ck];
+      *reinterpret_cast<f32x4*>(buf + (ck * 16 + il) * ACT_P + fb + 16 * it + 4 * q) = h[it][ck];
 }
 
 // dW[it][kt] += sum_n ZB[feat][n] * HB[k][n] over the 32 dual columns.
 // A (lane il = feature) and B (lane il = k) are read as b32 from [sample][feature]
 // buffers, one (ck,s) step ahead of the MFMAs that consume them.
-template <int KT>
-__device__ __forceinline__ void wgrad(const float* zb, const float* hb, int hb_pitch, int w, int il, int q,
-                                      f32x4 (&dW)[2][KT]) {
-  float na0, na1, nb[KT];
+// SWISH: the dual Swish backward of the NEXT pointwise stage is hidden under the MFMAs: step st also turns
+// (gP,gT) -> (zbarP, zbarT), in place, for register (it = st>>2, r = st&3).
+template <int KT, int IT, bool SWISH>
+__device__ __forceinline__ void wgrad_core(const float* zb, const float* hb, int hb_pitch, int fb, int il, int q,
+                                           f32x4 (&dW)[IT][KT], const f32x4 (*z)[2], f32x4 (*g)[2]) {
+  float na[IT], nb[KT];
   {
     const int n = q;
-    na0 = zb[n * ACT_P + 32 * w + il]; na1 = zb[n * ACT_P + 32 * w + 16 + il];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) na[it] = zb[n * ACT_P + fb + 16 * it + il];
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) nb[kt] = hb[n * hb_pitch + 16 * kt + il];
   }
 #pragma unroll
   for (int st = 0; st < 8; ++st) {
-    const float a0 = na0, a1 = na1;
-    float b[KT];
+    float a[IT], b[KT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) a[it] = na[it];
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) b[kt] = nb[kt];
     if (st + 1 < 8) {
       const int n = ((st + 1) >> 2) * 16 + 4 * ((st + 1) & 3) + q;
-      na0 = zb[n * ACT_P + 32 * w + il]; na1 = zb[n * ACT_P + 32 * w + 16 + il];
+#pragma unroll
+      for (int it = 0; it < IT; ++it) na[it] = zb[n * ACT_P + fb + 16 * it + il];
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) nb[kt] = hb[n * hb_pitch + 16 * kt + il];
     }
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-      dW[0][kt] = mfma16(a0, b[kt], dW[0][kt]);
-      dW[1][kt] = mfma16(a1, b[kt], dW[1][kt]);
-    }
-    if (MLP_SB) __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-// wgrad of a 128x128 layer with the dual Swish backward of the NEXT pointwise stage hidden under its
-// MFMAs: step st of 8 also turns (gP,gT) -> (zbarP, zbarT), in place, for register (it = st>>2, r = st&3).
-template <int KT>
-__device__ __forceinline__ void wgrad_swish(const float* zbuf, const float* hb, int hb_pitch, int w, int il, int q,
-                                            f32x4 (&dW)[2][KT], const f32x4 (&z)[2][2], f32x4 (&g)[2][2]) {
-  float na0, na1, nb[KT];
-  {
-    const int n = q;
-    na0 = zbuf[n * ACT_P + 32 * w + il]; na1 = zbuf[n * ACT_P + 32 * w + 16 + il];
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt) nb[kt] = hb[n * hb_pitch + 16 * kt + il];
-  }
-#pragma unroll
-  for (int st = 0; st < 8; ++st) {
-    const float a0 = na0, a1 = na1;
-    float b[KT];
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt) b[kt] = nb[kt];
-    if (st + 1 < 8) {
-      const int n = ((st + 1) >> 2) * 16 + 4 * ((st + 1) & 3) + q;
-      na0 = zbuf[n * ACT_P + 32 * w + il]; na1 = zbuf[n * ACT_P + 32 * w + 16 + il];
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt) nb[kt] = hb[n * hb_pitch + 16 * kt + il];
-    }
-    if (MLP_OVL_BWD) {
+    if (SWISH && MLP_OVL_BWD && st < 4 * IT) {
       const int it = st >> 2, r = st & 3;
       float s0, s1, s2;
       swish012(z[it][0][r], s0, s1, s2);
@@ -282,19 +299,18 @@ __device__ __forceinline__ void wgrad_swish(const float* zbuf, const float* hb, 
       g[it][1][r] = gt * s1;
     }
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-      dW[0][kt] = mfma16(a0, b[kt], dW[0][kt]);
-      dW[1][kt] = mfma16(a1, b[kt], dW[1][kt]);
-    }
-    if (MLP_HINTS) {
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int it = 0; it < IT; ++it) dW[it][kt] = mfma16(a[it], b[kt], dW[it][kt]);
+    if (MLP_HINTS && SWISH) {
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); }
     }
     if (MLP_SB) __builtin_amdgcn_sched_barrier(0);
   }
-  if (!MLP_OVL_BWD) {
+  if (SWISH && !MLP_OVL_BWD) {
 #pragma unroll
-    for (int st = 0; st < 8; ++st) {
+    for (int st = 0; st < 4 * IT; ++st) {
       const int it = st >> 2, r = st & 3;
       float s0, s1, s2;
       swish012(z[it][0][r], s0, s1, s2);
@@ -304,22 +320,21 @@ __device__ __forceinline__ void wgrad_swish(const float* zbuf, const float* hb, 
     }
   }
 }
-
-// dual Swish backward in registers: (gP,gT) cotangents of (hP,hT) -> cotangents of (zP,zT)
-__device__ __forceinline__ void swish_bwd(const f32x4 (&z)[2][2], const f32x4 (&g)[2][2], f32x4 (&zb)[2][2]) {
-#pragma unroll
-  for (int it = 0; it < 2; ++it)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float s0, s1, s2;
-      swish012(z[it][0][r], s0, s1, s2);
-      zb[it][1][r] = g[it][1][r] * s1;
-      zb[it][0][r] = g[it][0][r] * s1 + g[it][1][r] * (s2 * z[it][1][r]);
-    }
+template <int KT, int IT>
+__device__ __forceinline__ void wgrad(const float* zb, const float* hb, int hb_pitch, int fb, int il, int q, f32x4 (&dW)[IT][KT]) {
+  wgrad_core<KT, IT, false>(zb, hb, hb_pitch, fb, il, q, dW, nullptr, nullptr);
+}
+template <int KT, int IT>
+__device__ __forceinline__ void wgrad_swish(const float* zbuf, const float* hb, int hb_pitch, int fb, int il, int q,
+                                            f32x4 (&dW)[IT][KT], const f32x4 (&z)[IT][2], f32x4 (&g)[IT][2]) {
+  wgrad_core<KT, IT, true>(zbuf, hb, hb_pitch, fb, il, q, dW, z, g);
 }
 
-template <int MODE, bool WIDE>
-__global__ void __launch_bounds__(256, 1) k_mlp(MlpArgs A) {
+template <int MODE, bool WIDE, int NW>
+__global__ void __launch_bounds__(64 * NW, 1) k_mlp(MlpArgs A) {
+  constexpr int NT = 64 * NW;         // threads
+  constexpr int IT = 8 / NW;          // 16-feature row tiles per wave: 4 waves x 2 or 8 waves x 1
+  constexpr int FW = 16 * IT;         // features owned by a wave
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int KT1 = WIDE ? 2 : 1;   // k-tiles of the first layer's input (in_dim <= 16 / 32)
   constexpr int OT = WIDE ? 2 : 1;    // o-tiles of the last layer's output (d <= 16 / 32)
@@ -327,7 +342,8 @@ __global__ void __launch_bounds__(256, 1) k_mlp(MlpArgs A) {
   const int tid = threadIdx.x;
   const int w = tid >> 6, lane = tid & 63, il = lane & 15, q = lane >> 4;
   const int d = A.P.d;
-  using LO = MlpLds<MODE, WIDE>;
+  const int fb = FW * w;              // this wave's first feature
+  using LO = MlpLds<MODE, WIDE, NW>;
   constexpr int SM_P = LO::SMP, DPAD = LO::DP;
   float* X = lds + LO::X; float* Y = lds + LO::Y; float* Z = lds + LO::Z; float* U = lds + LO::U;
   float* H0 = lds + LO::H0; float* ABAR = lds + LO::ABAR; float* PART = lds + LO::PART;
@@ -336,28 +352,28 @@ __global__ void __launch_bounds__(256, 1) k_mlp(MlpArgs A) {
   float* DB4 = lds + LO::DB4; float* RED = lds + LO::RED;
 
   // ---- one-time staging of the small layers and biases -------------------
-  for (int i = tid; i < HID * SM_P; i += 256) {
+  for (int i = tid; i < HID * SM_P; i += NT) {
     int r = i / SM_P, c = i - r * SM_P;
     W1s[i] = (c < A.in_dim) ? A.P.W1[r * A.in_dim + c] : 0.f;
   }
-  for (int i = tid; i < DPAD * ACT_P; i += 256) {
+  for (int i = tid; i < DPAD * ACT_P; i += NT) {
     int r = i / ACT_P, c = i - r * ACT_P;
     W4s[i] = (r < d && c < HID) ? A.P.W4[r * HID + c] : 0.f;
   }
-  for (int i = tid; i < HID; i += 256) { B1s[i] = A.P.b1[i]; B2s[i] = A.P.b2[i]; B3s[i] = A.P.b3[i]; }
+  for (int i = tid; i < HID; i += NT) { B1s[i] = A.P.b1[i]; B2s[i] = A.P.b2[i]; B3s[i] = A.P.b3[i]; }
   if (tid < 32) B4s[tid] = tid < d ? A.P.b4[tid] : 0.f;
   if (MODE == MODE_TRAIN) {
-    for (int i = tid; i < 16 * DPAD; i += 256) DB4[i] = 0.f;
-    for (int i = tid; i < 32 * SM_P; i += 256) ABAR[i] = 0.f;
+    for (int i = tid; i < 16 * DPAD; i += NT) DB4[i] = 0.f;
+    for (int i = tid; i < 32 * SM_P; i += NT) ABAR[i] = 0.f;
   }
-  for (int i = tid; i < 32 * SM_P; i += 256) H0[i] = 0.f;
+  for (int i = tid; i < 2 * 32 * SM_P; i += NT) H0[i] = 0.f;
 
   // persistent accumulators (train)
-  f32x4 dW2[2][8], dW3[2][8], dW1[2][KT1], dW4[2][OT], db1[2], db2[2], db3[2];
+  f32x4 dW2[IT][8], dW3[IT][8], dW1[IT][KT1], dW4[IT][OT], db1[IT], db2[IT], db3[IT];
   float loss_acc = 0.f;
   if (MODE == MODE_TRAIN) {
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < IT; ++it) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) { dW2[it][k] = f32x4{0, 0, 0, 0}; dW3[it][k] = f32x4{0, 0, 0, 0}; }
 #pragma unroll
@@ -368,138 +384,166 @@ __global__ void __launch_bounds__(256, 1) k_mlp(MlpArgs A) {
     }
   }
 
+  // ---- input pipeline: the tile's y / v / u / t / cst chunks (contiguous in global memory) are fetched into
+  // registers ONE TILE AHEAD (raw_issue), parked in LDS a phase later (raw_commit) and turned into the layer-1
+  // operand h0 at the end of the previous tile (build_h0) — no global-load latency sits on the tile's critical path.
+  constexpr int NR = (SPT * LO::DMAX + NT - 1) / NT;
+  float* RAW0 = lds + LO::RAW;
+  float pf_y[NR], pf_v[NR], pf_u[NR], pf_t = 0.f, pf_c = 0.f;
+  const int64_t etot = A.B * d;
+  auto raw_issue = [&](int64_t tl) {
+    const int64_t e0 = tl * SPT * d;                 // tl past the last tile => e0 >= etot => zeros
+    const int cnt = SPT * d;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int e = tid + NT * k;
+      const bool ok = e < cnt && e0 + e < etot;
+      pf_y[k] = ok ? A.y[e0 + e] : 0.f;
+      if (MODE == MODE_TRAIN) {
+        pf_v[k] = ok ? A.v[e0 + e] : 0.f;
+        pf_u[k] = (ok && A.u) ? A.u[e0 + e] : 0.f;
+      }
+    }
+    if (tid < SPT) {
+      const int64_t smp = tl * SPT + tid;
+      pf_t = smp < A.B ? (A.t ? A.t[smp] : A.t_scalar) : 0.f;
+      if (MODE == MODE_TRAIN) pf_c = (smp < A.B && A.u && A.cst) ? A.cst[smp] : 0.f;
+    }
+  };
+  auto raw_commit = [&](float* R) {
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int e = tid + NT * k;
+      if (e < SPT * LO::DMAX) {
+        R[LO::RY + e] = pf_y[k];
+        if (MODE == MODE_TRAIN) { R[LO::RV + e] = pf_v[k]; R[LO::RU + e] = pf_u[k]; }
+      }
+    }
+    if (tid < SPT) { R[LO::RT + tid] = pf_t; if (MODE == MODE_TRAIN) R[LO::RC + tid] = pf_c; }
+  };
+  // h0 (and its tangent) of tile tl from its raw buffer; run by SPT threads, one per sample row l.
+  // premodule none: h0 = [y, t], h0dot = [v, 0]                     NN.py:113-119
+  // NormalizeLogRadius: h0 = [y/r, log r, t], r = |y| + 1e-6          NN.py:56-70
+  auto build_h0 = [&](float* H0b, const float* R, int64_t tl, int l) {   // l = row (sample) of the tile
+    const int64_t smp = tl * SPT + l;
+    const bool live = smp < A.B;
+    float* hp = H0b + l * SM_P;
+    float* ht = H0b + (16 + l) * SM_P;   // tangent row (train only)
+    float tt = 0.f;
+    if (live) {
+      tt = R[LO::RT + l];
+      if (MODE == MODE_EM) tt = A.T - tt;                                 // s = T - t  SDEs.py:556-557
+    }
+    const float* yr = R + LO::RY + l * d;
+    const float* vr = R + LO::RV + l * d;
+    if (A.P.premodule == 0) {
+      for (int i = 0; i < d; ++i) {
+        hp[i] = yr[i];
+        if (MODE == MODE_TRAIN) ht[i] = vr[i];
+      }
+      hp[d] = tt;
+      if (MODE == MODE_TRAIN) ht[d] = 0.f;
+    } else {
+      float ss = 0.f, yv = 0.f;
+      for (int i = 0; i < d; ++i) {
+        const float yi = live ? yr[i] : 1.0f;
+        ss += yi * yi;
+        if (MODE == MODE_TRAIN) yv += yi * vr[i];
+      }
+      const float nr = sqrtf(ss);
+      const float r = nr + 1e-6f;
+      const float rdot = yv / nr;                                          // d|y| along v
+      for (int i = 0; i < d; ++i) {
+        const float yi = live ? yr[i] : 1.0f;
+        hp[i] = yi / r;
+        if (MODE == MODE_TRAIN) ht[i] = vr[i] / r - yi * rdot / (r * r);
+      }
+      hp[d] = logf(r);
+      hp[d + 1] = tt;
+      if (MODE == MODE_TRAIN) { ht[d] = rdot / r; ht[d + 1] = 0.f; }
+    }
+  };
+
+  const wrsrc_t R2 = make_wrsrc(A.P.W2), R3 = make_wrsrc(A.P.W3);
   WPre pre;
-  prefetch_w<false>(A.P.W2, w, il, q, pre);
+  prefetch_w<false>(R2, fb, il, q, pre);
+  raw_issue(blockIdx.x);
+  raw_commit(RAW0);
+  __syncthreads();
+  if (tid < SPT) build_h0(H0, RAW0, blockIdx.x, tid);
+  __syncthreads();
+
+  // layer 1 (K = in_dim, weights from LDS) of the tile whose h0 sits in H0b: z1 stays in registers (train: needed
+  // again by the Swish backward), h1 goes to `dst`.  It runs one tile AHEAD — in the prologue for the first tile, then
+  // at the tail of every tile for the next one, into the activation buffer that tile no longer needs — so the tile
+  // loop starts directly with the layer-2 gemm and has no layer-1 phase / barrier of its own.
+  constexpr bool TRN = MODE == MODE_TRAIN;
+  f32x4 z1[IT][2];
+  auto layer1 = [&](const float* H0b, float* dst) {
+    f32x4 h1[IT][2];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) { z1[it][0] = f32x4{0, 0, 0, 0}; z1[it][1] = f32x4{0, 0, 0, 0}; }
+    for (int s = 0; s < A.in4; ++s) {
+      const float bP = H0b[il * SM_P + 4 * s + q];
+      const float bT = H0b[(16 + il) * SM_P + 4 * s + q];
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const float a = W1s[(fb + 16 * it + il) * SM_P + 4 * s + q];
+        z1[it][0] = mfma16(a, bP, z1[it][0]); z1[it][1] = mfma16(a, bT, z1[it][1]);
+      }
+    }
+    bias_swish<TRN, IT>(z1, h1, B1s, fb, q, 0);
+    store_act<IT>(dst, fb, il, q, h1);
+  };
+  layer1(H0, X);
   __syncthreads();
 
   STAMP_DECL
   const int64_t n_tiles = (A.B + SPT - 1) / SPT;
   const float ca = 1.0f - 0.5f * A.lmbd;
+  int cur = 0;      // parity of the tile: selects the h0 / raw buffers and which of X / Y holds h1
 
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t s_base = tile * SPT;
-    // ---- phase 0: h0 (and its tangent) -----------------------------------
-    // premodule none: h0 = [y, t], h0dot = [v, 0]                     NN.py:113-119
-    // NormalizeLogRadius: h0 = [y/r, log r, t], r = |y| + 1e-6          NN.py:56-70
-    if (tid < 32 && (MODE != MODE_TRAIN || tid < 16)) {
-      const int64_t smp = s_base + tid;
-      const bool live = smp < A.B;
-      float* hp = H0 + tid * SM_P;
-      float* ht = H0 + (16 + tid) * SM_P;   // tangent row (train only)
-      float tt = 0.f;
-      if (live) {
-        tt = A.t ? A.t[smp] : A.t_scalar;
-        if (MODE == MODE_EM) tt = A.T - tt;                               // s = T - t  SDEs.py:556-557
-      }
-      const float* yr = A.y + smp * d;
-      const float* vr = (MODE == MODE_TRAIN) ? A.v + smp * d : nullptr;
-      if (A.P.premodule == 0) {
-        for (int i = 0; i < d; ++i) {
-          hp[i] = live ? yr[i] : 0.f;
-          if (MODE == MODE_TRAIN) ht[i] = live ? vr[i] : 0.f;
-        }
-        hp[d] = tt;
-        if (MODE == MODE_TRAIN) ht[d] = 0.f;
-      } else {
-        float ss = 0.f, yv = 0.f;
-        for (int i = 0; i < d; ++i) {
-          float yi = live ? yr[i] : 1.0f;
-          ss += yi * yi;
-          if (MODE == MODE_TRAIN) yv += yi * (live ? vr[i] : 0.f);
-        }
-        const float nr = sqrtf(ss);
-        const float r = nr + 1e-6f;
-        const float rdot = yv / nr;                                        // d|y| along v
-        for (int i = 0; i < d; ++i) {
-          float yi = live ? yr[i] : 1.0f;
-          hp[i] = yi / r;
-          if (MODE == MODE_TRAIN) ht[i] = (live ? vr[i] : 0.f) / r - yi * rdot / (r * r);
-        }
-        hp[d] = logf(r);
-        hp[d + 1] = tt;
-        if (MODE == MODE_TRAIN) { ht[d] = rdot / r; ht[d + 1] = 0.f; }
-      }
-    }
-    __syncthreads();
-    STAMP(0);
-
-    // ---- phase 1: layer 1 (K = in_dim, weights from LDS) ------------------
-    f32x4 z1[2][2], z2[2][2], z3[2][2], h[2][2];
-#pragma unroll
-    for (int it = 0; it < 2; ++it) { z1[it][0] = f32x4{0, 0, 0, 0}; z1[it][1] = f32x4{0, 0, 0, 0}; }
-    for (int s = 0; s < A.in4; ++s) {
-      const float a0 = W1s[(32 * w + il) * SM_P + 4 * s + q];
-      const float a1 = W1s[(32 * w + 16 + il) * SM_P + 4 * s + q];
-      const float bP = H0[il * SM_P + 4 * s + q];
-      const float bT = H0[(16 + il) * SM_P + 4 * s + q];
-      z1[0][0] = mfma16(a0, bP, z1[0][0]); z1[0][1] = mfma16(a0, bT, z1[0][1]);
-      z1[1][0] = mfma16(a1, bP, z1[1][0]); z1[1][1] = mfma16(a1, bT, z1[1][1]);
-    }
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const f32x4 bb = *reinterpret_cast<const f32x4*>(B1s + 32 * w + 16 * it + 4 * q);
-      z1[it][0] += bb;
-      if (MODE != MODE_TRAIN) z1[it][1] += bb;          // second primal half
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (MODE == MODE_TRAIN) {
-          float s0, s1, s2; swish012(z1[it][0][r], s0, s1, s2);
-          h[it][0][r] = s0; h[it][1][r] = s1 * z1[it][1][r];
-        } else { h[it][0][r] = swish0(z1[it][0][r]); h[it][1][r] = swish0(z1[it][1][r]); }
-      }
-    }
-    store_act(X, w, il, q, h);
-    __syncthreads();
-    STAMP(1);
+    const float* H0c = H0 + cur * 32 * SM_P;
+    float* H0n = H0 + (cur ^ 1) * 32 * SM_P;
+    const float* Rc = RAW0 + cur * LO::RAWN;
+    float* Rn = RAW0 + (cur ^ 1) * LO::RAWN;
+    float* Xc = cur ? Y : X;          // h1 of this tile (written one tile ahead)
+    float* Yc = cur ? X : Y;          // h2 of this tile; after phase 6 (train) / 3 (inference): h1 of the next tile
+    f32x4 z2[IT][2], z3[IT][2], h[IT][2];
+    cur ^= 1;
 
     // ---- phase 2: layer 2 --------------------------------------------------
 #pragma unroll
-    for (int it = 0; it < 2; ++it) { z2[it][0] = f32x4{0, 0, 0, 0}; z2[it][1] = f32x4{0, 0, 0, 0}; }
-    gemm128<false, (MODE == MODE_TRAIN ? 1 : 2)>(A.P.W2, pre, X, w, il, q, z2, B2s, h);
-    prefetch_w<false>(A.P.W3, w, il, q, pre);          // head of the next gemm's weights
-    {
-      const f32x4 bb = *reinterpret_cast<const f32x4*>(B2s + 32 * w + 16 + 4 * q);
-      z2[1][0] += bb;
-      if (MODE != MODE_TRAIN) z2[1][1] += bb;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (MODE == MODE_TRAIN) {
-          float s0, s1, s2; swish012(z2[1][0][r], s0, s1, s2);
-          h[1][0][r] = s0; h[1][1][r] = s1 * z2[1][1][r];
-        } else { h[1][0][r] = swish0(z2[1][0][r]); h[1][1][r] = swish0(z2[1][1][r]); }
-      }
-    }
-    store_act(Y, w, il, q, h);
-    __syncthreads();
+    for (int it = 0; it < IT; ++it) { z2[it][0] = f32x4{0, 0, 0, 0}; z2[it][1] = f32x4{0, 0, 0, 0}; }
+    if (MODE != MODE_TRAIN) raw_issue(tile + gridDim.x);
+    gemm128<false, (TRN ? 1 : 2), IT>(R2, pre, Xc, fb, il, q, z2, B2s, h);
+    prefetch_w<false>(R3, fb, il, q, pre);         // head of the next gemm's weights
+    bias_swish<TRN, IT>(z2, h, B2s, fb, q, GemmTail<IT>::FIRST);
+    store_act<IT>(Yc, fb, il, q, h);
+    if (MODE != MODE_TRAIN) raw_commit(Rn);
+    lds_barrier();
     STAMP(2);
 
     // ---- phase 3: layer 3, then this wave's K-slice of layer 4 -------------
 #pragma unroll
-    for (int it = 0; it < 2; ++it) { z3[it][0] = f32x4{0, 0, 0, 0}; z3[it][1] = f32x4{0, 0, 0, 0}; }
-    gemm128<false, (MODE == MODE_TRAIN ? 1 : 2)>(A.P.W3, pre, Y, w, il, q, z3, B3s, h);
-    if (MODE == MODE_TRAIN) prefetch_w<true>(A.P.W3, w, il, q, pre);   // W3^T for dgrad
-    else prefetch_w<false>(A.P.W2, w, il, q, pre);                     // next tile's layer 2
+    for (int it = 0; it < IT; ++it) { z3[it][0] = f32x4{0, 0, 0, 0}; z3[it][1] = f32x4{0, 0, 0, 0}; }
+    if (MODE != MODE_TRAIN) { if (tid < SPT) build_h0(H0n, Rn, tile + gridDim.x, tid); }   // next tile's layer-1 operand
+    else raw_issue(tile + gridDim.x);                        // train: next tile's inputs, in flight during the gemm
+    gemm128<false, (TRN ? 1 : 2), IT>(R3, pre, Yc, fb, il, q, z3, B3s, h);
+    if (MODE == MODE_TRAIN) prefetch_w<true>(R3, fb, il, q, pre);  // W3^T for dgrad
+    else prefetch_w<false>(R2, fb, il, q, pre);                    // next tile's layer 2
+    bias_swish<TRN, IT>(z3, h, B3s, fb, q, GemmTail<IT>::FIRST);
+    if (MODE == MODE_TRAIN) store_act<IT>(Z, fb, il, q, h);   // h3 is the dW4 operand later
     {
-      const f32x4 bb = *reinterpret_cast<const f32x4*>(B3s + 32 * w + 16 + 4 * q);
-      z3[1][0] += bb;
-      if (MODE != MODE_TRAIN) z3[1][1] += bb;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (MODE == MODE_TRAIN) {
-          float s0, s1, s2; swish012(z3[1][0][r], s0, s1, s2);
-          h[1][0][r] = s0; h[1][1][r] = s1 * z3[1][1][r];
-        } else { h[1][0][r] = swish0(z3[1][0][r]); h[1][1][r] = swish0(z3[1][1][r]); }
-      }
-    }
-    if (MODE == MODE_TRAIN) store_act(Z, w, il, q, h);   // h3 is the dW4 operand later
-    {
-      // partial[o][col] = sum_{k in this wave's 32 features} W4[o][k] h3[k][col]; B operand = registers
+      // partial[o][col] = sum_{k in this wave's FW features} W4[o][k] h3[k][col]; B operand = registers
 #pragma unroll
       for (int ot = 0; ot < OT; ++ot) {
         f32x4 p0 = {0, 0, 0, 0}, p1 = {0, 0, 0, 0};
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          const f32x4 a4 = *reinterpret_cast<const f32x4*>(W4s + (16 * ot + il) * ACT_P + 32 * w + 16 * it + 4 * q);
+        for (int it = 0; it < IT; ++it) {
+          const f32x4 a4 = *reinterpret_cast<const f32x4*>(W4s + (16 * ot + il) * ACT_P + fb + 16 * it + 4 * q);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             p0 = mfma16(a4[r], h[it][0][r], p0);
@@ -510,19 +554,21 @@ __global__ void __launch_bounds__(256, 1) k_mlp(MlpArgs A) {
         *reinterpret_cast<f32x4*>(PART + (w * 32 + 16 + il) * SM_P + 16 * ot + 4 * q) = p1;
       }
     }
-    __syncthreads();
+    if (MODE == MODE_TRAIN) raw_commit(Rn);
+    lds_barrier();
     STAMP(3);
 
     // ---- phase 4: reduce layer-4 partials; outputs / loss ------------------
     if (MODE == MODE_FWD || MODE == MODE_EM) {
+      layer1(H0n, Yc);                                         // next tile's h1 (h2 is dead)
       // 32 samples x d outputs
-      for (int idx = tid; idx < 32 * d; idx += 256) {
+      for (int idx = tid; idx < 32 * d; idx += NT) {
         const int c = idx / d, o = idx - c * d;
         const int64_t smp = s_base + c;
         if (smp < A.B) {
           float a = B4s[o];
 #pragma unroll
-          for (int ww = 0; ww < 4; ++ww) a += PART[(ww * 32 + c) * SM_P + o];
+          for (int ww = 0; ww < NW; ++ww) a += PART[(ww * 32 + c) * SM_P + o];
           const int64_t e = smp * d + o;
           if (MODE == MODE_FWD) {
             A.out[e] = a;
@@ -532,95 +578,110 @@ __global__ void __launch_bounds__(256, 1) k_mlp(MlpArgs A) {
             const float s = A.T - A.t_scalar;
             const float beta = sde_beta(A.b0, A.b1, s);
             const float sb = sqrtf(beta);
-            const float x = A.y[e];
+            const float x = Rc[LO::RY + idx];
             const float zz = A.z ? A.z[e] : philox_normal1(A.rng, A.rng_step, RNG_STREAM_DW, (uint64_t)e);
             const float mu = ca * (sb * a) - (-0.5f * beta * x);
             A.out[e] = x + (mu * A.delta + (sqrtf(1.0f - A.lmbd) * sb) * (A.sqrt_delta * zz));
           }
         }
       }
-      __syncthreads();   // PART / H0 are rewritten by the next tile
+      lds_barrier();   // PART / H0 are rewritten by the next tile
       continue;
     }
 
     if (MODE == MODE_TRAIN) {
-      if (tid < 16) {
-        const int64_t smp = s_base + tid;
+      if (tid < 256) {
+        // thread (c = sample, ol = output): a, adot from the K-slices; the sample's loss terms meet by shuffle
+        const int c = tid >> 4, ol = tid & 15;
+        const int64_t smp = s_base + c;
         const bool live = smp < A.B;
         const float wgt = live ? A.inv_batch : 0.f;
         float beta = 0.f, sb = 0.f;
-        if (live && !A.u) { beta = sde_beta(A.b0, A.b1, A.t[smp]); sb = sqrtf(beta); }
+        if (!A.u) { beta = sde_beta(A.b0, A.b1, Rc[LO::RT + c]); sb = sqrtf(beta); }
         float lj = 0.f;
-        for (int o = 0; o < d; ++o) {
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) {
+          const int o = 16 * ot + ol;
+          const bool oo = o < d;
           float a = B4s[o], ad = 0.f;
 #pragma unroll
-          for (int ww = 0; ww < 4; ++ww) { a += PART[(ww * 32 + tid) * SM_P + o]; ad += PART[(ww * 32 + 16 + tid) * SM_P + o]; }
+          for (int ww = 0; ww < NW; ++ww) { a += PART[(ww * 32 + c) * SM_P + o]; ad += PART[(ww * 32 + 16 + c) * SM_P + o]; }
           float adb;
           if (A.u) {
             // general form: loss_b = sum_o adot_o u_o + cst_b + 1/2 a_o^2, u = (d mu/d a)^T v  (MSGM: G(y)^T v)
-            const float uo = live ? A.u[smp * d + o] : 0.f;
+            const float uo = oo ? Rc[LO::RU + c * d + o] : 0.f;
             lj += ad * uo + 0.5f * a * a;
             adb = uo * wgt;
           } else {
-            const float vo = live ? A.v[smp * d + o] : 0.f;
+            const float vo = oo ? Rc[LO::RV + c * d + o] : 0.f;
             // SGM: loss_b = sum_o v_o (sqrt(beta) adot_o + 1/2 beta v_o) + 1/2 a_o^2     SDEs.py:631-646
             lj += vo * (sb * ad + 0.5f * beta * vo) + 0.5f * a * a;
             adb = sb * vo * wgt;
           }
           const float ab = a * wgt;
-          ABAR[tid * SM_P + o] = ab;
-          ABAR[(16 + tid) * SM_P + o] = adb;
-          DB4[tid * DPAD + o] += ab;
+          ABAR[c * SM_P + o] = ab;
+          ABAR[(16 + c) * SM_P + o] = adb;
+          DB4[c * DPAD + o] += ab;
         }
-        if (live && A.u && A.cst) lj += A.cst[smp];
-        if (live) { loss_acc += lj; if (A.loss_per) A.loss_per[smp] = lj; }
+#pragma unroll
+        for (int m = 8; m > 0; m >>= 1) lj += __shfl_xor(lj, m, 64);
+        if (ol == 0 && live) {
+          if (A.u && A.cst) lj += Rc[LO::RC + c];
+          loss_acc += lj;
+          if (A.loss_per) A.loss_per[smp] = lj;
+        }
       }
-      __syncthreads();
+      // next tile's layer-1 operand, by a wave that has no part in the loss when there are eight
+      if (tid >= NT - 64 && tid < NT - 64 + 16) build_h0(H0n, Rn, tile + gridDim.x, tid - (NT - 64));
+      lds_barrier();
       STAMP(4);
 
       // ---- phase 5: layer-4 backward, dW4, Swish' on layer 3 --------------
-      f32x4 g[2][2];
+      f32x4 g[IT][2];
 #pragma unroll
-      for (int it = 0; it < 2; ++it) { g[it][0] = f32x4{0, 0, 0, 0}; g[it][1] = f32x4{0, 0, 0, 0}; }
+      for (int it = 0; it < IT; ++it) { g[it][0] = f32x4{0, 0, 0, 0}; g[it][1] = f32x4{0, 0, 0, 0}; }
       for (int s = 0; s < A.d4; ++s) {
-        const float a0 = W4s[(4 * s + q) * ACT_P + 32 * w + il];
-        const float a1 = W4s[(4 * s + q) * ACT_P + 32 * w + 16 + il];
         const float bP = ABAR[il * SM_P + 4 * s + q];
         const float bT = ABAR[(16 + il) * SM_P + 4 * s + q];
-        g[0][0] = mfma16(a0, bP, g[0][0]); g[0][1] = mfma16(a0, bT, g[0][1]);
-        g[1][0] = mfma16(a1, bP, g[1][0]); g[1][1] = mfma16(a1, bT, g[1][1]);
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+          const float a = W4s[(4 * s + q) * ACT_P + fb + 16 * it + il];
+          g[it][0] = mfma16(a, bP, g[it][0]); g[it][1] = mfma16(a, bT, g[it][1]);
+        }
       }
-      wgrad_swish<OT>(Z, ABAR, SM_P, w, il, q, dW4, z3, g);       // dW4^T[feat][o] += h3 . abar, Swish' hidden
-      db3[0] += g[0][0]; db3[1] += g[1][0];
-      store_act(U, w, il, q, g);
-      __syncthreads();
+      wgrad_swish<OT, IT>(Z, ABAR, SM_P, fb, il, q, dW4, z3, g);  // dW4^T[feat][o] += h3 . abar, Swish' hidden
+#pragma unroll
+      for (int it = 0; it < IT; ++it) db3[it] += g[it][0];
+      store_act<IT>(U, fb, il, q, g);
+      lds_barrier();
       STAMP(5);
 
       // ---- phase 6: dgrad layer 3 (W3^T), dW3, Swish' on layer 2 -----------
 #pragma unroll
-      for (int it = 0; it < 2; ++it) { g[it][0] = f32x4{0, 0, 0, 0}; g[it][1] = f32x4{0, 0, 0, 0}; }
-      gemm128<true, 0>(A.P.W3, pre, U, w, il, q, g, nullptr, h);
-      prefetch_w<true>(A.P.W2, w, il, q, pre);           // W2^T for the next dgrad
-      wgrad_swish<8>(U, Y, ACT_P, w, il, q, dW3, z2, g);
-      db2[0] += g[0][0]; db2[1] += g[1][0];
-      store_act(Z, w, il, q, g);                           // h3 is dead after phase 5
-      __syncthreads();
+      for (int it = 0; it < IT; ++it) { g[it][0] = f32x4{0, 0, 0, 0}; g[it][1] = f32x4{0, 0, 0, 0}; }
+      gemm128<true, 0, IT>(R3, pre, U, fb, il, q, g, nullptr, h);
+      prefetch_w<true>(R2, fb, il, q, pre);          // W2^T for the next dgrad
+      wgrad_swish<8, IT>(U, Yc, ACT_P, fb, il, q, dW3, z2, g);
+#pragma unroll
+      for (int it = 0; it < IT; ++it) db2[it] += g[it][0];
+      store_act<IT>(Z, fb, il, q, g);                      // h3 is dead after phase 5
+      lds_barrier();
       STAMP(6);
 
       // ---- phase 7: dgrad layer 2 (W2^T), dW2, Swish' on layer 1 -----------
 #pragma unroll
-      for (int it = 0; it < 2; ++it) { g[it][0] = f32x4{0, 0, 0, 0}; g[it][1] = f32x4{0, 0, 0, 0}; }
-      gemm128<true, 0>(A.P.W2, pre, Z, w, il, q, g, nullptr, h);
-      prefetch_w<false>(A.P.W2, w, il, q, pre);          // next tile's layer 2
-      wgrad_swish<8>(Z, X, ACT_P, w, il, q, dW2, z1, g);
-      db1[0] += g[0][0]; db1[1] += g[1][0];
-      store_act(U, w, il, q, g);                           // zbar3 is dead after phase 6
-      __syncthreads();
+      for (int it = 0; it < IT; ++it) { g[it][0] = f32x4{0, 0, 0, 0}; g[it][1] = f32x4{0, 0, 0, 0}; }
+      gemm128<true, 0, IT>(R2, pre, Z, fb, il, q, g, nullptr, h);
+      prefetch_w<false>(R2, fb, il, q, pre);         // next tile's layer 2
+      wgrad_swish<8, IT>(Z, Xc, ACT_P, fb, il, q, dW2, z1, g);
+#pragma unroll
+      for (int it = 0; it < IT; ++it) db1[it] += g[it][0];
+      store_act<IT>(U, fb, il, q, g);                      // zbar3 is dead after phase 6
       STAMP(7);
-
-      // ---- phase 8: dW1 ------------------------------------------------------
-      wgrad<KT1>(U, H0, SM_P, w, il, q, dW1);
-      __syncthreads();   // H0/ABAR/PART/X.. are rewritten by the next tile
+      // dW1 reads only THIS wave's columns of zbar1 (just written by this wave) and h0: no barrier in between
+      wgrad<KT1, IT>(U, H0c, SM_P, fb, il, q, dW1);
+      layer1(H0n, Yc);                                     // next tile's h1 (h2 is dead since phase 6)
+      lds_barrier();     // ABAR/PART/.. are rewritten by the next tile
       STAMP(8);
     }
   }
@@ -634,44 +695,44 @@ __global__ void __launch_bounds__(256, 1) k_mlp(MlpArgs A) {
                   oW3 = ob2 + HID, ob3 = oW3 + HID * HID, oW4 = ob3 + HID, ob4 = oW4 + (int64_t)d * HID;
     // dW2 / dW3: lane (k = 16kt+il, q), reg r -> row 32w+16it+4q+r
 #pragma unroll
-    for (int it = 0; it < 2; ++it)
+    for (int it = 0; it < IT; ++it)
 #pragma unroll
       for (int kt = 0; kt < 8; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = 32 * w + 16 * it + 4 * q + r, col = 16 * kt + il;
+          const int row = fb + 16 * it + 4 * q + r, col = 16 * kt + il;
           slab[oW2 + row * HID + col] = dW2[it][kt][r];
           slab[oW3 + row * HID + col] = dW3[it][kt][r];
         }
 #pragma unroll
-    for (int it = 0; it < 2; ++it)
+    for (int it = 0; it < IT; ++it)
 #pragma unroll
       for (int kt = 0; kt < KT1; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = 32 * w + 16 * it + 4 * q + r, col = 16 * kt + il;
+          const int row = fb + 16 * it + 4 * q + r, col = 16 * kt + il;
           if (col < in_dim) slab[oW1 + (int64_t)row * in_dim + col] = dW1[it][kt][r];
         }
     // dW4 held transposed: lane (o = 16ot+il, q), reg r -> feature 32w+16it+4q+r
 #pragma unroll
-    for (int it = 0; it < 2; ++it)
+    for (int it = 0; it < IT; ++it)
 #pragma unroll
       for (int ot = 0; ot < OT; ++ot)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int feat = 32 * w + 16 * it + 4 * q + r, o = 16 * ot + il;
+          const int feat = fb + 16 * it + 4 * q + r, o = 16 * ot + il;
           if (o < d) slab[oW4 + (int64_t)o * HID + feat] = dW4[it][ot][r];
         }
     // biases: sum the primal cotangents over the 16 sample lanes
 #pragma unroll
-    for (int it = 0; it < 2; ++it)
+    for (int it = 0; it < IT; ++it)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float s1 = db1[it][r], s2 = db2[it][r], s3 = db3[it][r];
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); s3 += __shfl_xor(s3, o, 64); }
         if (il == 0) {
-          const int feat = 32 * w + 16 * it + 4 * q + r;
+          const int feat = fb + 16 * it + 4 * q + r;
           slab[ob1 + feat] = s1; slab[ob2 + feat] = s2; slab[ob3 + feat] = s3;
         }
       }
@@ -681,7 +742,7 @@ __global__ void __launch_bounds__(256, 1) k_mlp(MlpArgs A) {
       for (int j = 0; j < 16; ++j) s += DB4[j * DPAD + tid];
       slab[ob4 + tid] = s;
     }
-    if (tid < 16) RED[tid] = loss_acc;
+    if (tid < 256 && (tid & 15) == 0) RED[tid >> 4] = loss_acc;
     __syncthreads();
     if (tid == 0) {
       float s = 0.f;
@@ -737,11 +798,24 @@ __global__ void __launch_bounds__(256) k_slab_reduce(const float* __restrict__ s
 static inline hipStream_t S(msgm_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 static const int MLP_MAX_GRID = 256;
 
+// Waves per workgroup.  Training at narrow width runs 8 waves x 16 features: two waves per SIMD, so one wave's
+// Swish / LDS / barrier latencies are covered by the other's MFMAs (each holds half of the dW accumulators).  The
+// wide carve (d > 15) has no LDS left for eight layer-4 K-slices and stays at 4 waves x 32 features.
+#ifndef MLP_NW_TRAIN
+#define MLP_NW_TRAIN 8
+#endif
+#ifndef MLP_NW_FWD
+#define MLP_NW_FWD 4
+#endif
+template <int MODE, bool WIDE>
+struct MlpCfg { static constexpr int NW = WIDE ? 4 : (MODE == MODE_TRAIN ? MLP_NW_TRAIN : MLP_NW_FWD); };
+
 template <int MODE, bool WIDE>
 static void set_lds_attr() {
   static const int once = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp<MODE, WIDE>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, MlpLds<MODE, WIDE>::BYTES);
+    constexpr int NW = MlpCfg<MODE, WIDE>::NW;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp<MODE, WIDE, NW>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, MlpLds<MODE, WIDE, NW>::BYTES);
     return 0;
   }();
   (void)once;
@@ -750,9 +824,10 @@ static void set_lds_attr() {
 template <int MODE>
 static int launch_mlp(const MlpArgs& A, int grid, hipStream_t st) {
   const bool wide = A.in_dim > 16 || A.P.d > 16;
-  constexpr size_t lds_wide = MlpLds<MODE, true>::BYTES, lds_narrow = MlpLds<MODE, false>::BYTES;
-  if (wide) { set_lds_attr<MODE, true>(); hipLaunchKernelGGL((k_mlp<MODE, true>), dim3(grid), dim3(256), lds_wide, st, A); }
-  else { set_lds_attr<MODE, false>(); hipLaunchKernelGGL((k_mlp<MODE, false>), dim3(grid), dim3(256), lds_narrow, st, A); }
+  constexpr int nw_w = MlpCfg<MODE, true>::NW, nw_n = MlpCfg<MODE, false>::NW;
+  constexpr size_t lds_wide = MlpLds<MODE, true, nw_w>::BYTES, lds_narrow = MlpLds<MODE, false, nw_n>::BYTES;
+  if (wide) { set_lds_attr<MODE, true>(); hipLaunchKernelGGL((k_mlp<MODE, true, nw_w>), dim3(grid), dim3(64 * nw_w), lds_wide, st, A); }
+  else { set_lds_attr<MODE, false>(); hipLaunchKernelGGL((k_mlp<MODE, false, nw_n>), dim3(grid), dim3(64 * nw_n), lds_narrow, st, A); }
   return msgm_check_launch();
 }
 

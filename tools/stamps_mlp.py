@@ -43,6 +43,19 @@ for vi, flags in enumerate(variants):
             e1.record(); torch.cuda.synchronize()
             us = e0.elapsed_time(e1) / 50 * 1e3
             print(f"variant[{flags or 'default'}]: k_mlp<TRAIN> {us:.1f} us  -> {400896 * B / us / 1e6:.1f} TFLOP/s")
+            x = y.clone()
+            rng = torch.tensor([1234, 0], dtype=torch.int64, device=dev)
+            em = lambda i: L.msgm_mlp_em_step(P, x.data_ptr(), B, st, 0.5, 1e-3, 0.0, None, rng.data_ptr(), i,
+                                              torch.cuda.current_stream().cuda_stream)
+            for i in range(5):
+                assert em(i) == 0
+            torch.cuda.synchronize()
+            e0.record()
+            for i in range(100):
+                em(i)
+            e1.record(); torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / 100 * 1e3
+            print(f"variant[{flags or 'default'}]: k_mlp<EM> {us:.1f} us  -> {66816 * B / us / 1e6:.1f} TFLOP/s")
         else:
             L.msgm_debug_stamps.restype = C.c_int; L.msgm_debug_stamps.argtypes = [C.c_void_p]
             buf = (C.c_ulonglong * 12)()
