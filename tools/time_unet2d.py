@@ -21,18 +21,19 @@ from oracle.det_params import load_det_
 load_det_(net.core)          # non-zero "zero-init" layers so every kernel does real work
 T = torch.nn.Parameter(torch.FloatTensor([1.0]), requires_grad=False)
 gen = PluginReverseSDE(SGMsde(T=T, num_steps_forward=16, device=dev), net, T, deviceReverseSDE=dev).to(dev)
-tr = UNetScoreTrainer(gen, B, d, lr=1e-4)
-tr.set_data(random_images(B, Cc, S_, S_, device=dev))
-for _ in range(2):
-    l = tr.step()
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(steps):
-    l = tr.step()
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / steps
-print(f"B={B} train step {dt*1e3:.1f} ms  loss {float(l):.4f} -> {6*5.974e9*B/dt/1e12:.1f} TFLOP/s (algorithmic) "
-      f"mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
+if not os.environ.get("EM_ONLY"):
+    tr = UNetScoreTrainer(gen, B, d, lr=1e-4)
+    tr.set_data(random_images(B, Cc, S_, S_, device=dev))
+    for _ in range(2):
+        l = tr.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        l = tr.step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    print(f"B={B} train step {dt*1e3:.1f} ms  loss {float(l):.4f} -> {6*5.974e9*B/dt/1e12:.1f} TFLOP/s (algorithmic) "
+          f"mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
 x = torch.randn(B, d, device=dev)
 st = gen.base_sde.struct()
 rng = gen.base_sde.philox(dev)
