@@ -344,6 +344,16 @@ int msgm_softmax_dual_forward(float* S, const float* Wd, float* Pd, int64_t rows
 int msgm_softmax_dual_backward(const float* P, const float* Wd, float* Pb, float* Pdb, int64_t rows, int32_t T,
                                msgm_stream_t stream);
 
+/* Fused single-head self-attention FORWARD without tangent (the sampler's use of
+ * QKVAttention.forward, model/unet.py:236-250): out[n][t][:] = softmax_s(scale q_t.k_s) v_s with
+ * qkv [N][T][3C] channels-last (q | k | v slices) and out [N][T][C]; scale = ch^-1/2 (the two ch^-1/4
+ * factors of unet.py:245-248).  The (T,T) probabilities are never written to memory (online softmax).
+ * msgm_attention_supported(T, C) != 0 iff the shape is built (C in {32,64,128}, T a multiple of 64);
+ * otherwise msgm_attention_forward returns MSGM_E_UNSUPPORTED and the caller composes msgm_bmm +
+ * msgm_softmax_dual_forward + msgm_bmm (what the training path always does: its backward needs P). */
+int msgm_attention_supported(int32_t T, int32_t C);
+int msgm_attention_forward(const float* qkv, float* out, int64_t N, int32_t T, int32_t C, float scale, msgm_stream_t stream);
+
 /* [cos(t f_j), sin(t f_j)], f_j = exp(-ln(max_period) j/half) (model/nn_utils.py:130-148). */
 int msgm_timestep_embedding(const float* t, float* emb, int32_t B, int32_t dim, float max_period, msgm_stream_t stream);
 

@@ -243,6 +243,11 @@ class VorticityUNet(nn.Module, FlatParamMixin):
         hn, st = self._gn(a.m.norm, x, Bp, T, C, dual, False, tape)
         qkv, _, _ = a.qkv.forward([hn], N, 1, T, Bp)                     # [N][T][3C]: q | k | v channel slices
         s2 = 1.0 / math.sqrt(C)                                          # (ch^-1/4)^2           model/unet.py:245-248
+        if not dual and tape is None and ops.attention_supported(T, C):  # sampler: nothing to keep, no tangent
+            att = ops.attention_forward(qkv, torch.empty(N * T * C, device=dev), N, T, C, s2)
+            out, _, _ = a.proj.forward([att], N, 1, T, Bp)
+            ops.lincomb(out, out, 1.0, x, 1.0)
+            return out
         ld = 3 * C
         half = Bp * T * ld                                               # offset of the tangent rows
         S = torch.empty(Bp * T * T, device=dev)

@@ -89,33 +89,75 @@ __device__ __forceinline__ void gn_stats(const double* a8, double cnt, float eps
   a = (float)(iv * (a8[3] / cnt - m * d));
 }
 
-__global__ void __launch_bounds__(256) k_gn_fwd_apply(GnArgs A) {
+// {mean, inv_std, mean(xdot), a} per (sample, group), once — not per element (the double-precision divide and
+// square root used to sit in the elementwise pass).  Written to the workspace tail and, if asked, to `stats`.
+__global__ void __launch_bounds__(256) k_gn_finalize(GnArgs A, float* __restrict__ wstats) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= A.Bp * A.G) return;
+  const double cnt = (double)A.P * (A.C / A.G);
+  float mu, inv, md, a;
+  gn_stats(A.acc + (size_t)i * 8, cnt, A.eps, mu, inv, md, a);
+  *reinterpret_cast<f32x4*>(wstats + (size_t)i * 4) = f32x4{mu, inv, md, a};
+  if (A.stats) *reinterpret_cast<f32x4*>(A.stats + (size_t)i * 4) = f32x4{mu, inv, md, a};
+}
+
+// Elementwise pass.  VEC: grid (pixel chunk, sample); a thread owns 4 consecutive channels (its statistics and
+// affine parameters are loaded once) and walks over pixels — 16-B loads/stores, consecutive threads on consecutive
+// addresses.  !VEC (C % 4 != 0): one thread per channel, same walk.
+template <bool VEC>
+__global__ void __launch_bounds__(256) k_gn_fwd_apply(GnArgs A, const float* __restrict__ wstats) {
+  constexpr int V = VEC ? 4 : 1;
   const int C = A.C, P = A.P, G = A.G, cpg = C / G;
-  const long per = (long)P * C, tot = (long)A.Bp * per;
-  const double cnt = (double)P * cpg;
-  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.x * blockDim.x) {
-    const int b = (int)(e / per);
-    const int c = (int)(e % C);
-    const int g = c / cpg;
-    float mu, inv, md, a;
-    gn_stats(A.acc + ((size_t)b * G + g) * 8, cnt, A.eps, mu, inv, md, a);
-    if (A.stats && (e - (long)b * per) == (long)g * cpg) {
-      float* st = A.stats + ((size_t)b * G + g) * 4;
-      st[0] = mu; st[1] = inv; st[2] = md; st[3] = a;
-    }
-    const float ga = A.gamma[c], be = A.beta[c];
-    const float xh = (A.x[e] - mu) * inv;
-    const float y = ga * xh + be;
-    float yd = 0.f;
-    if (A.dual) yd = ga * (inv * ((A.x[e + tot] - md) - xh * a));
-    if (A.silu) {
-      float z0, z1, z2;
-      silu012u(y, z0, z1, z2);
-      A.out[e] = z0;
-      if (A.dual) A.out[e + tot] = z1 * yd;
+  const int CV = C / V, PL = 256 / CV;
+  const int tid = threadIdx.x, b = blockIdx.y;
+  if (tid >= CV * PL) return;
+  const int cv = tid % CV, pl = tid / CV;
+  const long tot = (long)A.Bp * P * C;
+  float mu[V], inv[V], md[V], a[V], ga[V], be[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) {
+    const int c = V * cv + k;
+    const f32x4 st = *reinterpret_cast<const f32x4*>(wstats + ((size_t)b * G + c / cpg) * 4);
+    mu[k] = st[0]; inv[k] = st[1]; md[k] = st[2]; a[k] = st[3];
+    ga[k] = A.gamma[c]; be[k] = A.beta[c];
+  }
+  const int p0 = blockIdx.x * A.chunk, p1 = min(p0 + A.chunk, P);
+  for (int p = p0 + pl; p < p1; p += PL) {
+    const long e = ((long)b * P + p) * C + V * cv;
+    float x[V], xd[V], y[V], yd[V];
+    if (VEC) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(A.x + e);
+#pragma unroll
+      for (int k = 0; k < V; ++k) x[k] = xv[k];
+      if (A.dual) {
+        const f32x4 dv = *reinterpret_cast<const f32x4*>(A.x + e + tot);
+#pragma unroll
+        for (int k = 0; k < V; ++k) xd[k] = dv[k];
+      }
     } else {
-      A.out[e] = y;
-      if (A.dual) A.out[e + tot] = yd;
+      x[0] = A.x[e];
+      if (A.dual) xd[0] = A.x[e + tot];
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      const float xh = (x[k] - mu[k]) * inv[k];
+      y[k] = ga[k] * xh + be[k];
+      yd[k] = A.dual ? ga[k] * (inv[k] * ((xd[k] - md[k]) - xh * a[k])) : 0.f;
+      if (A.silu) {
+        float z0, z1, z2;
+        silu012u(y[k], z0, z1, z2);
+        y[k] = z0; yd[k] = z1 * yd[k];
+      }
+    }
+    if (VEC) {
+      f32x4 o, od;
+#pragma unroll
+      for (int k = 0; k < V; ++k) { o[k] = y[k]; od[k] = yd[k]; }
+      *reinterpret_cast<f32x4*>(A.out + e) = o;
+      if (A.dual) *reinterpret_cast<f32x4*>(A.out + e + tot) = od;
+    } else {
+      A.out[e] = y[0];
+      if (A.dual) A.out[e + tot] = yd[0];
     }
   }
 }
@@ -178,27 +220,66 @@ __global__ void __launch_bounds__(256) k_gn_bwd_reduce(GnArgs A) {
   if (tid < cl) { float s = 0.f; for (int p = 0; p < pl; ++p) s += red[p * cl + tid]; atomicAdd(A.dbeta + tid, s); }
 }
 
+template <bool VEC>
 __global__ void __launch_bounds__(256) k_gn_bwd_apply(GnArgs A) {
+  constexpr int V = VEC ? 4 : 1;
   const int C = A.C, P = A.P, G = A.G, cpg = C / G;
-  const long per = (long)P * C, tot = (long)A.Bp * per;
+  const int CV = C / V, PL = 256 / CV;
+  const int tid = threadIdx.x, b = blockIdx.y;
+  if (tid >= CV * PL) return;
+  const int cv = tid % CV, pl = tid / CV;
+  const long tot = (long)A.Bp * P * C;
   const float rc = 1.0f / ((float)P * (float)cpg);
-  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.x * blockDim.x) {
-    const int b = (int)(e / per);
-    const int c = (int)(e % C);
-    const int g = c / cpg;
-    const float* st = A.stats + ((size_t)b * G + g) * 4;
-    const float mu = st[0], inv = st[1], md = st[2], a = st[3];
+  float mu[V], inv[V], md[V], a[V], ga[V], be[V], mX[V], mXx[V], mW[V], pp[V], cc[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) {
+    const int c = V * cv + k, g = c / cpg;
+    const f32x4 st = *reinterpret_cast<const f32x4*>(A.stats + ((size_t)b * G + g) * 4);
+    mu[k] = st[0]; inv[k] = st[1]; md[k] = st[2]; a[k] = st[3];
     const double* a8 = A.acc + ((size_t)b * G + g) * 8;
-    const float mX = (float)a8[0] * rc, mXx = (float)a8[1] * rc, mW = (float)a8[2] * rc, pp = (float)a8[3] * rc,
-                cc = (float)a8[4] * rc;
-    const float ga = A.gamma[c], be = A.beta[c];
-    float xh, wh, zb, zdb;
-    gn_bwd_elem(A, e, tot, mu, inv, md, a, ga, be, xh, wh, zb, zdb);
-    const float X = ga * zb, W = ga * zdb;
-    const float xdb = inv * (W - mW - xh * pp);
-    const float xb = inv * (X - mX - xh * mXx) - inv * (cc * xh + a * xdb + pp * wh);
-    A.gx[e] = xb;
-    A.gx[e + tot] = xdb;
+    mX[k] = (float)a8[0] * rc; mXx[k] = (float)a8[1] * rc; mW[k] = (float)a8[2] * rc; pp[k] = (float)a8[3] * rc;
+    cc[k] = (float)a8[4] * rc;
+    ga[k] = A.gamma[c]; be[k] = A.beta[c];
+  }
+  const int p0 = blockIdx.x * A.chunk, p1 = min(p0 + A.chunk, P);
+  for (int p = p0 + pl; p < p1; p += PL) {
+    const long e = ((long)b * P + p) * C + V * cv;
+    float x[V], xd[V], zb[V], zdb[V], xb[V], xdb[V];
+    if (VEC) {
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(A.x + e), v1 = *reinterpret_cast<const f32x4*>(A.x + e + tot);
+      const f32x4 v2 = *reinterpret_cast<const f32x4*>(A.gout + e), v3 = *reinterpret_cast<const f32x4*>(A.gout + e + tot);
+#pragma unroll
+      for (int k = 0; k < V; ++k) { x[k] = v0[k]; xd[k] = v1[k]; zb[k] = v2[k]; zdb[k] = v3[k]; }
+    } else {
+      x[0] = A.x[e]; xd[0] = A.x[e + tot]; zb[0] = A.gout[e]; zdb[0] = A.gout[e + tot];
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      const float xh = (x[k] - mu[k]) * inv[k];
+      const float wh = inv[k] * ((xd[k] - md[k]) - xh * a[k]);
+      float zbk = zb[k], zdbk = zdb[k];
+      if (A.silu) {
+        float z0, z1, z2;
+        silu012u(ga[k] * xh + be[k], z0, z1, z2);
+        const float yd = ga[k] * wh;
+        const float nzb = zbk * z1 + zdbk * (z2 * yd);
+        zdbk = zdbk * z1;
+        zbk = nzb;
+      }
+      const float X = ga[k] * zbk, W = ga[k] * zdbk;
+      xdb[k] = inv[k] * (W - mW[k] - xh * pp[k]);
+      xb[k] = inv[k] * (X - mX[k] - xh * mXx[k]) - inv[k] * (cc[k] * xh + a[k] * xdb[k] + pp[k] * wh);
+    }
+    if (VEC) {
+      f32x4 o, od;
+#pragma unroll
+      for (int k = 0; k < V; ++k) { o[k] = xb[k]; od[k] = xdb[k]; }
+      *reinterpret_cast<f32x4*>(A.gx + e) = o;
+      *reinterpret_cast<f32x4*>(A.gx + e + tot) = od;
+    } else {
+      A.gx[e] = xb[0];
+      A.gx[e + tot] = xdb[0];
+    }
   }
 }
 
@@ -507,7 +588,9 @@ static int gn_chunks(int Bp, int P, int* chunk) {
   return (P + c - 1) / c;
 }
 
-size_t msgm_groupnorm_workspace(int32_t Bp, int32_t G) { return (size_t)Bp * (size_t)G * 8 * sizeof(double); }
+// acc[Bp][G][8] doubles (moment atomics) followed by [Bp][G][4] floats (finalised forward statistics)
+static inline size_t gn_acc_bytes(int32_t Bp, int32_t G) { return (size_t)Bp * (size_t)G * 8 * sizeof(double); }
+size_t msgm_groupnorm_workspace(int32_t Bp, int32_t G) { return gn_acc_bytes(Bp, G) + (size_t)Bp * (size_t)G * 4 * sizeof(float); }
 
 int msgm_groupnorm_dual_forward(const float* x, const float* gamma, const float* beta, float* out, float* stats, int32_t Bp,
                                 int32_t P, int32_t C, int32_t G, int32_t dual, int32_t silu, float eps, void* workspace,
@@ -517,10 +600,13 @@ int msgm_groupnorm_dual_forward(const float* x, const float* gamma, const float*
   if (workspace_bytes < msgm_groupnorm_workspace(Bp, G)) return MSGM_E_WORKSPACE;
   GnArgs A{x, gamma, beta, out, reinterpret_cast<double*>(workspace), stats, P, C, G, Bp, dual, silu, 0, eps,
            nullptr, nullptr, nullptr, nullptr};
-  if (hipMemsetAsync(workspace, 0, msgm_groupnorm_workspace(Bp, G), S(stream)) != hipSuccess) return MSGM_E_LAUNCH;
+  if (hipMemsetAsync(workspace, 0, gn_acc_bytes(Bp, G), S(stream)) != hipSuccess) return MSGM_E_LAUNCH;
+  float* wstats = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + gn_acc_bytes(Bp, G));
   const int nch = gn_chunks(Bp, P, &A.chunk);
   hipLaunchKernelGGL(k_gn_fwd_reduce, dim3(Bp, nch), dim3(256), 0, S(stream), A);
-  hipLaunchKernelGGL(k_gn_fwd_apply, dim3(grid_for((int64_t)Bp * P * C, 256)), dim3(256), 0, S(stream), A);
+  hipLaunchKernelGGL(k_gn_finalize, dim3((Bp * G + 255) / 256), dim3(256), 0, S(stream), A, wstats);
+  if (C % 4 == 0) hipLaunchKernelGGL(k_gn_fwd_apply<true>, dim3(nch, Bp), dim3(256), 0, S(stream), A, (const float*)wstats);
+  else hipLaunchKernelGGL(k_gn_fwd_apply<false>, dim3(nch, Bp), dim3(256), 0, S(stream), A, (const float*)wstats);
   return msgm_check_launch();
 }
 
@@ -533,10 +619,11 @@ int msgm_groupnorm_dual_backward(const float* x, const float* gamma, const float
   if (workspace_bytes < msgm_groupnorm_workspace(Bp, G)) return MSGM_E_WORKSPACE;
   GnArgs A{x, gamma, beta, nullptr, reinterpret_cast<double*>(workspace), const_cast<float*>(stats), P, C, G, Bp, 1, silu, 0,
            eps, gout, gx, dgamma, dbeta};
-  if (hipMemsetAsync(workspace, 0, msgm_groupnorm_workspace(Bp, G), S(stream)) != hipSuccess) return MSGM_E_LAUNCH;
+  if (hipMemsetAsync(workspace, 0, gn_acc_bytes(Bp, G), S(stream)) != hipSuccess) return MSGM_E_LAUNCH;
   const int nch = gn_chunks(Bp, P, &A.chunk);
   hipLaunchKernelGGL(k_gn_bwd_reduce, dim3(Bp, nch), dim3(256), 0, S(stream), A);
-  hipLaunchKernelGGL(k_gn_bwd_apply, dim3(grid_for((int64_t)Bp * P * C, 256)), dim3(256), 0, S(stream), A);
+  if (C % 4 == 0) hipLaunchKernelGGL(k_gn_bwd_apply<true>, dim3(nch, Bp), dim3(256), 0, S(stream), A);
+  else hipLaunchKernelGGL(k_gn_bwd_apply<false>, dim3(nch, Bp), dim3(256), 0, S(stream), A);
   return msgm_check_launch();
 }
 

@@ -419,6 +419,18 @@ def softmax_dual_forward(S, T, Wd=None, Pd=None):
     check(lib().msgm_softmax_dual_forward(ptr(f32(S)), ptr(Wd), ptr(Pd), rows, T, int(dual), stream()), "msgm_softmax_dual_forward")
 
 
+def attention_supported(T, C) -> bool:
+    return bool(lib().msgm_attention_supported(int(T), int(C)))
+
+
+def attention_forward(qkv, out, N, T, C, scale):
+    """Fused softmax(scale q k^T) v on channels-last qkv [N][T][3C] -> out [N][T][C] (no tangent)."""
+    if qkv.numel() < N * T * 3 * C or out.numel() < N * T * C:
+        raise MsgmError("attention: buffer too small")
+    check(lib().msgm_attention_forward(ptr(f32(qkv)), ptr(f32(out)), N, T, C, float(scale), stream()), "msgm_attention_forward")
+    return out
+
+
 def softmax_dual_backward(Pm, Wd, Pb, Pdb, T):
     rows = Pm.numel() // T
     if not (Wd.numel() == Pb.numel() == Pdb.numel() == Pm.numel()):

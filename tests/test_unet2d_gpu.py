@@ -84,6 +84,54 @@ def test_bmm_strided_and_softmax_dual():
     assert rel_l2(pb.cpu(), Wg.grad) <= 2e-5 and rel_l2(pdb.cpu(), Wdg.grad) <= 2e-5
 
 
+@pytest.mark.parametrize("Bn,T,C", [(3, 64, 32), (2, 128, 64), (2, 320, 64), (5, 256, 128), (1, 1024, 64), (2, 192, 128)])
+def test_fused_attention_forward(Bn, T, C):
+    """K8b (sampler path): softmax(scale q k^T) v without the (T,T) matrix, vs plain PyTorch fp32 of
+    QKVAttention.forward (model/unet.py:236-250).  Tolerance 2e-5 rel-L2 (online softmax re-association, __expf)."""
+    from sdeflow_light_amd import ops
+    torch.manual_seed(T + C)
+    qkv = torch.randn(Bn, T, 3 * C) * 1.5
+    qkv[0, : T // 2, :C] *= 4.0                        # a few peaked rows: exercises the running-max rescale
+    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    s = C ** -0.25
+    ref = torch.einsum("bts,bsc->btc", torch.softmax(torch.einsum("btc,bsc->bts", q * s, k * s), -1), v)
+    assert ops.attention_supported(T, C)
+    out = torch.full((Bn * T * C,), float("nan"), device=DEV)
+    ops.attention_forward(qkv.to(DEV).contiguous().view(-1), out, Bn, T, C, 1.0 / math.sqrt(C))
+    assert rel_l2(out.view(Bn, T, C).cpu(), ref) <= 2e-5
+
+
+def test_fused_attention_unsupported_shapes_fail_loudly():
+    from sdeflow_light_amd import ops
+    from sdeflow_light_amd._lib import MsgmError
+    assert not ops.attention_supported(80, 32) and not ops.attention_supported(64, 48) and not ops.attention_supported(16, 64)
+    qkv = torch.zeros(2 * 80 * 96, device=DEV)
+    with pytest.raises(MsgmError):
+        ops.attention_forward(qkv, torch.zeros(2 * 80 * 32, device=DEV), 2, 80, 32, 1.0)
+
+
+def test_unet2d_sampler_forward_fused_equals_composed(monkeypatch):
+    """The no-tangent forward (sampler) takes the fused attention where the shape allows; it must agree with the
+    composed bmm/softmax/bmm path the training step uses (same net, same input)."""
+    from sdeflow_light_amd import ops
+    from sdeflow_light_amd.NNUnet import VorticityUNet
+    from oracle.det_params import load_det_
+    torch.manual_seed(3)
+    net = VorticityUNet(base_channels=32, channel_mults=(1, 2), num_res_blocks=1, in_space=16, attention_resolutions=(1, 2),
+                        flatten_order="F").to(DEV)
+    load_det_(net.core)
+    x = torch.randn(4, 256, device=DEV)
+    t = torch.rand(4, device=DEV)
+    calls = []
+    real = ops.attention_forward
+    monkeypatch.setattr(ops, "attention_forward", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    fused = net(x, t).clone()
+    assert calls, "fused attention was not taken for T=256/64, C=32/64"
+    monkeypatch.setattr(ops, "attention_supported", lambda T, C: False)
+    composed = net(x, t)
+    assert rel_l2(fused.cpu(), composed.cpu()) <= 2e-4      # whole-network amplification of the 2e-5 kernel-level bound
+
+
 def test_glue_kernels():
     from sdeflow_light_amd import ops
     from oracle import nets_ref as N
