@@ -292,6 +292,16 @@ int msgm_unpack_weight(float* dW, const float* dWp, int32_t rows, int32_t ncols,
                        int64_t sr, int64_t sc, int64_t st, int32_t rowsP, int32_t Ktot, int32_t kp_off,
                        int32_t accumulate, msgm_stream_t stream);
 
+/* One launch for every (un)pack job of a network.  `jobs` is a DEVICE array; job j copies
+ * Wp[t][r][kp_off+c] <- W[r*sr + (col_off+c)*sc + t*st] (unpack != 0: the other way, overwriting W).  The
+ * table is static as long as the parameter buckets and packed images do not move. */
+typedef struct {
+  float* W; float* Wp;
+  int64_t sr, sc, st;
+  int32_t rows, ncols, col_off, taps, rowsP, Ktot, kp_off, reserved;
+} msgm_pack_job_t;
+int msgm_pack_weights_batched(const msgm_pack_job_t* jobs, int32_t n_jobs, int32_t unpack, msgm_stream_t stream);
+
 /* Dual-number activations on a (primal | tangent) stacked tensor of 2*half
  * elements: act 0 = exact-erf GELU (NNUnet1D.py:18), 1 = SiLU (nn_utils.py:44-46).
  * forward: hP = f(zP), hT = f'(zP) zT (dual = 0: primal only, `half` elements).
@@ -315,8 +325,11 @@ int msgm_add_row(float* x, const float* E, int32_t N, int32_t P, int32_t C, int3
  * stats [Bp][G][4] = {mean, 1/sigma, mean(xdot), mean(xhat xdot)} is written by
  * forward (may be NULL when no backward follows) and read by backward, which
  * recomputes xhat / SiLU from x, adds to dgamma / dbeta (float atomics) and
- * writes the input cotangents (primal | tangent) to gx (may alias gout). */
-size_t msgm_groupnorm_workspace(int32_t Bp, int32_t G);   /* bytes: per-(sample, group) double moment accumulators */
+ * writes the input cotangents (primal | tangent) to gx (may alias gout).
+ * Workspace contract: the caller hands in a buffer that is ZERO the first time; every call leaves its
+ * accumulator part zero again (forward clears it in its finalise kernel, backward with a trailing memset), so
+ * consecutive calls on one stream share one buffer without a memset per call. */
+size_t msgm_groupnorm_workspace(int32_t Bp, int32_t G);   /* bytes: double moment accumulators + float statistics */
 int msgm_groupnorm_dual_forward(const float* x, const float* gamma, const float* beta, float* out, float* stats,
                                 int32_t Bp, int32_t P, int32_t C, int32_t G, int32_t dual, int32_t silu, float eps,
                                 void* workspace, size_t workspace_bytes, msgm_stream_t stream);

@@ -27,7 +27,7 @@ import torch.nn as nn
 from . import ops
 from ._lib import MsgmError
 from .NN import FlatParamMixin
-from .convnet import ConvOp
+from .convnet import ConvOp, ConvOpSet
 
 SILU = ops.ACT_SILU
 scale_image = 5          # NNUnet.py:19
@@ -211,6 +211,7 @@ class VorticityUNet(nn.Module, FlatParamMixin):
             for kind, o in blk:
                 allops += o.ops if kind in ("res", "attn") else [o]
         x["all"] = allops
+        x["set"] = ConvOpSet(allops)
         self._x = x
         return x
 
@@ -275,8 +276,7 @@ class VorticityUNet(nn.Module, FlatParamMixin):
         """img: channels-last [N][H][W][Cin].  Returns channels-last [N][H][W][Cout].
         logr: [log r ; rdot/r] (N,) with NormalizeLogRadius conditioning."""
         x = self._build()
-        for op in x["all"]:
-            op.pack()
+        x["set"].pack()
         core = self.core
         mc = core.model_channels
         H = W = self.in_space
@@ -378,11 +378,9 @@ class VorticityUNet(nn.Module, FlatParamMixin):
                 self._flatten_parameters()
                 break
         x = self._build()
-        for op in x["all"]:
-            op.zero_grad_images()
+        x["set"].zero_grad_images()
         flat, gflat = self.flat_parameters()
-        for gn in self._groupnorms():
-            gn.weight.grad.zero_(); gn.bias.grad.zero_()
+        gflat.zero_()                    # GroupNorm parameter gradients are accumulated with atomics; one memset for all
         forder = self.flatten_order == "F"
         stacked = torch.cat([y.contiguous().float(), v.contiguous().float()], 0)
         logr = None
@@ -396,8 +394,7 @@ class VorticityUNet(nn.Module, FlatParamMixin):
         per, g = ops.ssm_loss(a_flat.view(-1), u, cst, inv_batch)
         gimg = ops.flat_to_image(g.view(N, d), N, Cc, S_, S_, forder, float(scale_image))   # adjoint of (x5, unflatten)
         self._backward(tape, gimg, N, B)
-        for op in x["all"]:
-            op.unpack_grads()
+        x["set"].unpack_grads()
         return per
 
     def _groupnorms(self):

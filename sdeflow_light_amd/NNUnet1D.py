@@ -22,7 +22,7 @@ import torch.nn as nn
 from . import ops
 from ._lib import MsgmError
 from .NN import FlatParamMixin, NormalizeLogRadius
-from .convnet import ConvOp
+from .convnet import ConvOp, ConvOpSet
 
 GELU = ops.ACT_GELU
 
@@ -97,14 +97,14 @@ class UNet1D(nn.Module, FlatParamMixin):
             cin = c
         o["fin"] = ConvOp(self.final.weight, self.final.bias, "conv", (1,), 1, 0, [cin])
         self._ops = o
+        self._opset = ConvOpSet(list(o.values()))
         return o
 
     # ------------------------------------------------------------------ pipeline
     def _run(self, h0: torch.Tensor, t: torch.Tensor, N: int, Bp: int, L: int, dual: bool, tape: Optional[list]):
         """h0: [N][L][1] (primal rows then tangent rows).  Returns [N][L] output."""
         o = self._build()
-        for op in o.values():
-            op.pack()
+        self._opset.pack()
         dev = h0.device
         nl = len(self.chs)
         act = lambda z: ops.act_dual_forward(GELU, z, torch.empty_like(z), dual)
@@ -187,15 +187,13 @@ class UNet1D(nn.Module, FlatParamMixin):
                 self._flatten_parameters()
                 break
         o = self._build()
-        for op in o.values():
-            op.zero_grad_images()
+        self._opset.zero_grad_images()
         tape = []
         h0 = torch.cat([y.contiguous().float(), v.contiguous().float()], 0).reshape(-1)
         out = self._run(h0, t.reshape(-1).contiguous().float(), N, B, L, True, tape)
         per, g = ops.ssm_loss(out, u, cst, inv_batch)
         self._backward(tape, g, N, B)
-        for op in o.values():
-            op.unpack_grads()
+        self._opset.unpack_grads()
         return per
 
     def _backward(self, tape, g, N, Bp):

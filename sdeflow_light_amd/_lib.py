@@ -30,6 +30,13 @@ class SdeT(C.Structure):
                 ("t_epsilon", C.c_float), ("G", C.c_void_p), ("L_G", C.c_void_p)]
 
 
+class PackJobT(C.Structure):
+    """msgm_pack_job_t (include/msgm_hip.h)."""
+    _fields_ = [("W", C.c_void_p), ("Wp", C.c_void_p), ("sr", C.c_int64), ("sc", C.c_int64), ("st", C.c_int64),
+                ("rows", C.c_int32), ("ncols", C.c_int32), ("col_off", C.c_int32), ("taps", C.c_int32),
+                ("rowsP", C.c_int32), ("Ktot", C.c_int32), ("kp_off", C.c_int32), ("reserved", C.c_int32)]
+
+
 class ConvGeomT(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("N", "Hi", "Wi", "Ho", "Wo", "KH", "KW", "strideH", "padH", "strideW", "padW", "mode", "ups")]
 
@@ -79,6 +86,7 @@ SIGNATURES = {
     "msgm_bmm": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, _I32, _P]),
     "msgm_softmax_dual_forward": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P]),
     "msgm_softmax_dual_backward": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P]),
+    "msgm_pack_weights_batched": (C.c_int, [_P, _I32, _I32, _P]),
     "msgm_attention_supported": (C.c_int, [_I32, _I32]),
     "msgm_attention_forward": (C.c_int, [_P, _P, _I64, _I32, _I32, _F, _P]),
     "msgm_timestep_embedding": (C.c_int, [_P, _P, _I32, _I32, _F, _P]),

@@ -31,6 +31,45 @@ from ._lib import MsgmError
 pad16 = ops.pad16
 
 
+class ConvOpSet:
+    """All ConvOps of one network: their gradient images live in ONE flat buffer (one memset per step) and their
+    weight (un)packing runs as ONE launch each (ops.PackTable) instead of ~4 tiny launches per op."""
+
+    def __init__(self, ops_list: List["ConvOp"]):
+        self.ops = list(ops_list)
+        dev = self.ops[0].weight.device
+        sizes = []
+        for o in self.ops:
+            sizes.append(o.dWp.numel())
+            if o.embC:
+                sizes.append(o.dWpE.numel())
+        self.gimg = torch.zeros(sum(sizes), device=dev)
+        off = 0
+        for o in self.ops:
+            n = o.dWp.numel(); o.dWp = self.gimg[off:off + n]; off += n
+            if o.embC:
+                n = o.dWpE.numel(); o.dWpE = self.gimg[off:off + n]; off += n
+        self._pack = self._unpack = None
+        self._pack_sig = self._unpack_sig = None
+
+    def pack(self):
+        sig = tuple(o.weight.data_ptr() for o in self.ops)          # the parameter bucket may have been rebuilt
+        if self._pack is None or sig != self._pack_sig:
+            self._pack = ops.PackTable([j for o in self.ops for j in o.pack_jobs()], self.gimg.device)
+            self._pack_sig = sig
+        self._pack.run(False)
+
+    def zero_grad_images(self):
+        self.gimg.zero_()
+
+    def unpack_grads(self):
+        sig = tuple(o.weight.grad.data_ptr() for o in self.ops)
+        if self._unpack is None or sig != self._unpack_sig:
+            self._unpack = ops.PackTable([j for o in self.ops for j in o.unpack_jobs()], self.gimg.device)
+            self._unpack_sig = sig
+        self._unpack.run(True)
+
+
 class ConvOp:
     def __init__(self, weight: torch.nn.Parameter, bias: Optional[torch.nn.Parameter], kind: str, ksize: Sequence[int],
                  stride: int, pad: int, src_channels: Sequence[int], emb_channels: int = 0, ups: bool = False):
@@ -86,6 +125,32 @@ class ConvOp:
             ops.pack_weight(W, 0, self.WpE, self.Cout, E, off, 3, self.s_row, self.s_col, 1, self.Cout, pad16(E), 0)
             ops.pack_weight(W, off * self.s_col, self.WdE, E, self.Cout, 0, 3, self.s_col, self.s_row, 1, pad16(E),
                             pad16(self.Cout), 0)
+
+    def pack_jobs(self):
+        """The jobs of pack() as tuples for ops.PackTable."""
+        W = self.weight.detach()
+        jobs, off = [], 0
+        for s, C in enumerate(self.srcC):
+            jobs.append((W, 0, self.Wp, self.Cout, C, off, self.taps, self.s_row, self.s_col, 1, self.CoutP, self.Ktot, self.koff[s]))
+            jobs.append((W, off * self.s_col, self.Wd[s], C, self.Cout, 0, self.taps, self.s_col, self.s_row, 1, pad16(C),
+                         pad16(self.Cout), 0))
+            off += C
+        if self.embC:
+            E = self.embC
+            jobs.append((W, 0, self.WpE, self.Cout, E, off, 3, self.s_row, self.s_col, 1, self.Cout, pad16(E), 0))
+            jobs.append((W, off * self.s_col, self.WdE, E, self.Cout, 0, 3, self.s_col, self.s_row, 1, pad16(E), pad16(self.Cout), 0))
+        return jobs
+
+    def unpack_jobs(self):
+        """The jobs of unpack_grads() (weight.grad must exist)."""
+        gW = self.weight.grad
+        jobs, off = [], 0
+        for s, C in enumerate(self.srcC):
+            jobs.append((gW, 0, self.dWp, self.Cout, C, off, self.taps, self.s_row, self.s_col, 1, self.CoutP, self.Ktot, self.koff[s]))
+            off += C
+        if self.embC:
+            jobs.append((gW, 0, self.dWpE, self.Cout, self.embC, off, 3, self.s_row, self.s_col, 1, self.Cout, pad16(self.embC), 0))
+        return jobs
 
     def zero_grad_images(self):
         self.dWp.zero_()
@@ -165,7 +230,10 @@ class ConvOp:
             ops.conv_wgrad(geom, gy, srcs[s], C, self.koff[s], self.dWp, self.Cout, self.CoutP, self.Ktot)
         S = None
         er = n_bias if emb_rows is None else emb_rows
-        if self.bias is not None or self.embC or dsamp_bias is not None:
+        if self.bias is not None and not self.embC and dsamp_bias is None:
+            # bias only: the primal rows are one contiguous [n_bias * P][Cout] block — one reduction, no per-sample stage
+            ops.colsum(gy, 1, n_bias * P, self.Cout, out=self.bias.grad.view(1, -1))
+        elif self.bias is not None or self.embC or dsamp_bias is not None:
             S = dsamp_bias if dsamp_bias is not None else torch.empty(er * self.Cout, device=dev)
             ops.colsum(gy, er, P, self.Cout, out=S)                           # rows that carry a bias / embedding
             if self.bias is not None:                                         # the bias itself: primal rows only
@@ -208,9 +276,7 @@ class ConvOp:
         dev, C = gy.device, self.srcC[0]
         ops.conv_wgrad(geom, gy, src, C, 0, self.dWp, self.Cout, self.CoutP, self.Ktot)
         if self.bias is not None:
-            S = torch.empty(n_bias * self.Cout, device=dev)
-            ops.colsum(gy, n_bias, Ho * Wo, self.Cout, out=S)
-            ops.colsum(S, 1, n_bias, self.Cout, out=self.bias.grad.view(1, -1))
+            ops.colsum(gy, 1, n_bias * Ho * Wo, self.Cout, out=self.bias.grad.view(1, -1))
         gd = ops.conv_geom(N, Ho, Wo, 2 * Hi, 2 * Wi, self.KH, self.KW, self.stride, self.pad, 1 - self.mode, 0)
         gup = torch.empty(N * 4 * Hi * Wi * C, device=dev)
         ops.conv_forward(gd, gy, self.Cout, self.Wd[0], C, gup, CoutP=pad16(C))

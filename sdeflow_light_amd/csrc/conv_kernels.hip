@@ -898,6 +898,27 @@ int msgm_pack_weight(const float* W, float* Wp, int32_t rows, int32_t ncols, int
   return msgm_check_launch();
 }
 
+// All (un)pack jobs of a network in ONE launch: blockIdx.y = job, blockIdx.x strides over its elements.  The job
+// table is static (parameter buckets and packed images do not move), so the host uploads it once.
+__global__ void __launch_bounds__(256) k_pack_batched(const msgm_pack_job_t* __restrict__ jobs, int unpack) {
+  const msgm_pack_job_t J = jobs[blockIdx.y];
+  const int64_t tot = (int64_t)J.taps * J.rows * J.ncols;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < tot; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % J.ncols);
+    const int r = (int)((e / J.ncols) % J.rows);
+    const int t = (int)(e / ((int64_t)J.ncols * J.rows));
+    float* w = J.W + r * J.sr + (J.col_off + c) * J.sc + t * J.st;
+    float* p = J.Wp + ((int64_t)t * J.rowsP + r) * J.Ktot + J.kp_off + c;
+    if (unpack) *w = *p; else *p = *w;
+  }
+}
+
+int msgm_pack_weights_batched(const msgm_pack_job_t* jobs, int32_t n_jobs, int32_t unpack, msgm_stream_t stream) {
+  if (!jobs || n_jobs <= 0) return MSGM_E_BADARG;
+  hipLaunchKernelGGL(k_pack_batched, dim3(8, (unsigned)n_jobs), dim3(256), 0, S(stream), jobs, unpack);
+  return msgm_check_launch();
+}
+
 int msgm_unpack_weight(float* dW, const float* dWp, int32_t rows, int32_t ncols, int32_t col_off, int32_t taps, int64_t sr,
                        int64_t sc, int64_t st, int32_t rowsP, int32_t Ktot, int32_t kp_off, int32_t accumulate,
                        msgm_stream_t stream) {

@@ -53,29 +53,69 @@ __device__ __forceinline__ void gn_group_atomic(float* red, float v, int tid, in
   __syncthreads();
 }
 
+// V values per thread (channels V*cv .. V*cv+V-1 of pixel lane pl): LDS image [pl][C], then one thread per group sums
+// its channels over the pixel lanes and issues ONE double atomic.
+template <int V>
+__device__ __forceinline__ void gn_group_atomic_v(float* red, const float (&v)[V], bool live, int cv, int pl, int C, int PL,
+                                                  int G, int cpg, double* dst, int stride) {
+  if (live) {
+#pragma unroll
+    for (int k = 0; k < V; ++k) red[pl * C + V * cv + k] = v[k];
+  }
+  __syncthreads();
+  const int tid = threadIdx.x;
+  if (tid < G) {
+    float s = 0.f;
+    for (int p = 0; p < PL; ++p)
+      for (int cc = 0; cc < cpg; ++cc) s += red[p * C + tid * cpg + cc];
+    atomicAdd(dst + (size_t)tid * stride, (double)s);
+  }
+  __syncthreads();
+}
+
+template <bool VEC>
 __global__ void __launch_bounds__(256) k_gn_fwd_reduce(GnArgs A) {
-  __shared__ float red[256];
+  constexpr int V = VEC ? 4 : 1;
+  __shared__ float red[1024];
   const int tid = threadIdx.x, b = blockIdx.x;
   const int C = A.C, P = A.P, G = A.G, cpg = C / G;
-  const int cl = C, pl = 256 / C > 0 ? 256 / C : 1;
-  const bool live = tid < cl * pl;
-  const int c = live ? tid % cl : 0, pr = live ? tid / cl : 0;
+  const int CV = C / V, PL = 256 / CV;
+  const bool live = tid < CV * PL;
+  const int cv = live ? tid % CV : 0, pl = live ? tid / CV : 0;
   const float* xp = A.x + (size_t)b * P * C;
   const float* xt = A.x + (size_t)(b + A.Bp) * P * C;
   const int p0 = blockIdx.y * A.chunk, p1 = min(p0 + A.chunk, P);
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  float s0[V], s1[V], s2[V], s3[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) { s0[k] = 0.f; s1[k] = 0.f; s2[k] = 0.f; s3[k] = 0.f; }
   if (live)
-    for (int p = p0 + pr; p < p1; p += pl) {
-      const float xv = xp[(size_t)p * C + c];
-      s0 += xv; s1 += xv * xv;
-      if (A.dual) { const float dv = xt[(size_t)p * C + c]; s2 += dv; s3 += xv * dv; }
+    for (int p = p0 + pl; p < p1; p += PL) {
+      float xv[V], dv[V];
+      if (VEC) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(xp + (size_t)p * C + 4 * cv);
+#pragma unroll
+        for (int k = 0; k < V; ++k) xv[k] = t[k];
+        if (A.dual) {
+          const f32x4 u = *reinterpret_cast<const f32x4*>(xt + (size_t)p * C + 4 * cv);
+#pragma unroll
+          for (int k = 0; k < V; ++k) dv[k] = u[k];
+        }
+      } else {
+        xv[0] = xp[(size_t)p * C + cv];
+        if (A.dual) dv[0] = xt[(size_t)p * C + cv];
+      }
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        s0[k] += xv[k]; s1[k] += xv[k] * xv[k];
+        if (A.dual) { s2[k] += dv[k]; s3[k] += xv[k] * dv[k]; }
+      }
     }
   double* dst = A.acc + (size_t)b * G * 8;
-  gn_group_atomic(red, live ? s0 : 0.f, tid, cl, pl, G, cpg, dst + 0, 8);
-  gn_group_atomic(red, live ? s1 : 0.f, tid, cl, pl, G, cpg, dst + 1, 8);
+  gn_group_atomic_v<V>(red, s0, live, cv, pl, C, PL, G, cpg, dst + 0, 8);
+  gn_group_atomic_v<V>(red, s1, live, cv, pl, C, PL, G, cpg, dst + 1, 8);
   if (A.dual) {
-    gn_group_atomic(red, live ? s2 : 0.f, tid, cl, pl, G, cpg, dst + 2, 8);
-    gn_group_atomic(red, live ? s3 : 0.f, tid, cl, pl, G, cpg, dst + 3, 8);
+    gn_group_atomic_v<V>(red, s2, live, cv, pl, C, PL, G, cpg, dst + 2, 8);
+    gn_group_atomic_v<V>(red, s3, live, cv, pl, C, PL, G, cpg, dst + 3, 8);
   }
 }
 
@@ -96,7 +136,9 @@ __global__ void __launch_bounds__(256) k_gn_finalize(GnArgs A, float* __restrict
   if (i >= A.Bp * A.G) return;
   const double cnt = (double)A.P * (A.C / A.G);
   float mu, inv, md, a;
-  gn_stats(A.acc + (size_t)i * 8, cnt, A.eps, mu, inv, md, a);
+  double* acc = A.acc + (size_t)i * 8;
+  gn_stats(acc, cnt, A.eps, mu, inv, md, a);
+  acc[0] = 0.0; acc[1] = 0.0; acc[2] = 0.0; acc[3] = 0.0;      // leave the accumulators zero for the next call
   *reinterpret_cast<f32x4*>(wstats + (size_t)i * 4) = f32x4{mu, inv, md, a};
   if (A.stats) *reinterpret_cast<f32x4*>(A.stats + (size_t)i * 4) = f32x4{mu, inv, md, a};
 }
@@ -600,10 +642,10 @@ int msgm_groupnorm_dual_forward(const float* x, const float* gamma, const float*
   if (workspace_bytes < msgm_groupnorm_workspace(Bp, G)) return MSGM_E_WORKSPACE;
   GnArgs A{x, gamma, beta, out, reinterpret_cast<double*>(workspace), stats, P, C, G, Bp, dual, silu, 0, eps,
            nullptr, nullptr, nullptr, nullptr};
-  if (hipMemsetAsync(workspace, 0, gn_acc_bytes(Bp, G), S(stream)) != hipSuccess) return MSGM_E_LAUNCH;
   float* wstats = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + gn_acc_bytes(Bp, G));
   const int nch = gn_chunks(Bp, P, &A.chunk);
-  hipLaunchKernelGGL(k_gn_fwd_reduce, dim3(Bp, nch), dim3(256), 0, S(stream), A);
+  if (C % 4 == 0) hipLaunchKernelGGL(k_gn_fwd_reduce<true>, dim3(Bp, nch), dim3(256), 0, S(stream), A);
+  else hipLaunchKernelGGL(k_gn_fwd_reduce<false>, dim3(Bp, nch), dim3(256), 0, S(stream), A);
   hipLaunchKernelGGL(k_gn_finalize, dim3((Bp * G + 255) / 256), dim3(256), 0, S(stream), A, wstats);
   if (C % 4 == 0) hipLaunchKernelGGL(k_gn_fwd_apply<true>, dim3(nch, Bp), dim3(256), 0, S(stream), A, (const float*)wstats);
   else hipLaunchKernelGGL(k_gn_fwd_apply<false>, dim3(nch, Bp), dim3(256), 0, S(stream), A, (const float*)wstats);
@@ -619,11 +661,11 @@ int msgm_groupnorm_dual_backward(const float* x, const float* gamma, const float
   if (workspace_bytes < msgm_groupnorm_workspace(Bp, G)) return MSGM_E_WORKSPACE;
   GnArgs A{x, gamma, beta, nullptr, reinterpret_cast<double*>(workspace), const_cast<float*>(stats), P, C, G, Bp, 1, silu, 0,
            eps, gout, gx, dgamma, dbeta};
-  if (hipMemsetAsync(workspace, 0, gn_acc_bytes(Bp, G), S(stream)) != hipSuccess) return MSGM_E_LAUNCH;
   const int nch = gn_chunks(Bp, P, &A.chunk);
   hipLaunchKernelGGL(k_gn_bwd_reduce, dim3(Bp, nch), dim3(256), 0, S(stream), A);
   if (C % 4 == 0) hipLaunchKernelGGL(k_gn_bwd_apply<true>, dim3(nch, Bp), dim3(256), 0, S(stream), A);
   else hipLaunchKernelGGL(k_gn_bwd_apply<false>, dim3(nch, Bp), dim3(256), 0, S(stream), A);
+  if (hipMemsetAsync(workspace, 0, gn_acc_bytes(Bp, G), S(stream)) != hipSuccess) return MSGM_E_LAUNCH;   // zero on exit
   return msgm_check_launch();
 }
 

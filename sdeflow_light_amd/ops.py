@@ -301,6 +301,29 @@ def pack_weight(W: torch.Tensor, w_off: int, Wp: torch.Tensor, rows, ncols, col_
                                  kp_off, stream()), "msgm_pack_weight")
 
 
+class PackTable:
+    """Device-resident table of (un)pack jobs — every weight image of a network in one launch.
+    job = (W, w_off, Wp, rows, ncols, col_off, taps, sr, sc, st, rowsP, Ktot, kp_off), as pack_weight's arguments."""
+
+    def __init__(self, jobs, device):
+        import ctypes as C
+        arr = (L.PackJobT * len(jobs))()
+        self.keep = []
+        for i, (W, w_off, Wp, rows, ncols, col_off, taps, sr, sc, st, rowsP, Ktot, kp_off) in enumerate(jobs):
+            need = w_off + (rows - 1) * sr + (col_off + ncols - 1) * sc + (taps - 1) * st + 1
+            if need > W.numel() or Wp.numel() < taps * rowsP * Ktot or kp_off + ncols > Ktot or rowsP < rows:
+                raise MsgmError("pack table: job out of range")
+            arr[i] = L.PackJobT(ptr(f32(W)) + 4 * w_off, ptr(f32(Wp)), sr, sc, st, rows, ncols, col_off, taps, rowsP, Ktot,
+                                kp_off, 0)
+            self.keep.append((W, Wp))
+        raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        self.table = raw.to(device)
+        self.n = len(jobs)
+
+    def run(self, unpack: bool = False):
+        check(lib().msgm_pack_weights_batched(ptr(self.table), self.n, int(bool(unpack)), stream()), "msgm_pack_weights_batched")
+
+
 def unpack_weight(dW: torch.Tensor, w_off: int, dWp: torch.Tensor, rows, ncols, col_off, taps, sr, sc, st, rowsP, Ktot,
                   kp_off, accumulate=False):
     need = w_off + (rows - 1) * sr + (col_off + ncols - 1) * sc + (taps - 1) * st + 1
@@ -360,7 +383,7 @@ def _gn_ws(Bp: int, G: int, device) -> torch.Tensor:
     n = int(lib().msgm_groupnorm_workspace(Bp, G)) // 8
     key = (torch.device(device), n)
     if key not in _GN_WS:
-        _GN_WS[key] = torch.empty(n, dtype=torch.float64, device=device)
+        _GN_WS[key] = torch.zeros(n, dtype=torch.float64, device=device)     # contract: zero on entry, left zero
     return _GN_WS[key]
 
 

@@ -103,9 +103,15 @@ class MLPScoreTrainer:
 class UNetScoreTrainer:
     """SGM + a U-Net score net exposing ``ssm_grad`` (configs C3/C4): prep kernel
     (K1 + probe) -> dual-number forward / hand-written backward -> [RCCL all-reduce
-    of the flat gradient bucket] -> fused Adam on the flat parameter bucket."""
+    of the flat gradient bucket] -> fused Adam on the flat parameter bucket.
 
-    def __init__(self, gen_sde, batch_local: int, dim: int, lr: float = 1e-4, world: int = 1, seed: int = 0):
+    The step enqueues ~2000 small launches for the 2-D U-Net; at the C4 shard size
+    (32 samples per GPU) the launch gaps cost as much as the kernels, so everything
+    before the collective is captured ONCE as a hipGraph and replayed (``use_graph``);
+    with one rank the Adam update and the Philox advance are inside the graph too."""
+
+    def __init__(self, gen_sde, batch_local: int, dim: int, lr: float = 1e-4, world: int = 1, seed: int = 0,
+                 use_graph: bool = True):
         net, base = gen_sde.a, gen_sde.base_sde
         if not hasattr(net, "ssm_grad") or base.kind != L.SDE_SGM:
             raise MsgmError("UNetScoreTrainer needs a HIP U-Net score net and an SGMsde")
@@ -113,8 +119,10 @@ class UNetScoreTrainer:
         self.dev = next(net.parameters()).device
         self.B, self.d, self.world, self.lr = batch_local, dim, world, lr
         self.flat, self.gflat = net.flat_parameters()
+        self.n = self.flat.numel()
         self.m, self.v = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
-        self.gbuf = torch.zeros(self.flat.numel() + 1, dtype=torch.float32, device=self.dev)   # [grads | loss] for N>1
+        self.gbuf = torch.zeros(self.n + 1, dtype=torch.float32, device=self.dev)   # ONE bucket: [grads | mean loss]
+        self.loss = self.gbuf[self.n:]
         self.step_dev = torch.zeros(1, dtype=torch.int64, device=self.dev)
         self.rng = L.PhiloxState(seed * 1000003 + 29, self.dev)
         self.x = torch.zeros(batch_local, dim, dtype=torch.float32, device=self.dev)
@@ -122,25 +130,61 @@ class UNetScoreTrainer:
         self.t = torch.empty(batch_local, dtype=torch.float32, device=self.dev)
         self.st = base.struct()
         self.inv_batch = 1.0 / (batch_local * world)
-        self.loss = torch.zeros(1, dtype=torch.float32, device=self.dev)
+        self.use_graph = use_graph
+        self.graph = None
 
     def set_data(self, x):
         self.x.copy_(x)
 
-    def step(self):
+    def _fwd_bwd(self):
+        """Everything before the collective; leaves [grads | loss] (already x 1/global_batch) in ``gbuf``."""
         lib, s = ops.lib(), ops.stream()
         ops.check(lib.msgm_ssm_prep(self.x.data_ptr(), self.y.data_ptr(), self.t.data_ptr(), self.vp.data_ptr(), self.B,
                                     self.d, self.st, self.rng.ptr(), self.step_dev.data_ptr(), s), "msgm_ssm_prep")
         u, cst = ops.ssm_terms(self.y, self.vp, self.t, self.st)
         per = self.net.ssm_grad(self.y, self.t, self.vp, u, cst, self.inv_batch)
-        self.flat, self.gflat = self.net.flat_parameters()
-        self.loss = per.sum() * self.inv_batch
-        g = self.gflat
-        if self.world > 1:                       # ONE collective: flat gradient bucket + the loss scalar
-            n = self.gflat.numel()
-            self.gbuf[:n].copy_(self.gflat); self.gbuf[n:].copy_(self.loss.reshape(1))
-            parallel.allreduce_sum_(self.gbuf)
-            g, self.loss = self.gbuf[:n], self.gbuf[n]
-        ops.adam_step(self.flat, g, self.m, self.v, step=0, lr=self.lr, step_dev=self.step_dev)
+        flat, gflat = self.net.flat_parameters()
+        if flat.data_ptr() != self.flat.data_ptr() or gflat.data_ptr() != self.gflat.data_ptr():
+            raise MsgmError("the flat parameter bucket moved; rebuild the trainer")
+        self.gbuf[: self.n].copy_(gflat)
+        self.gbuf[self.n:].copy_((per.sum() * self.inv_batch).reshape(1))
+
+    def _update(self):
+        ops.adam_step(self.flat, self.gbuf[: self.n], self.m, self.v, step=0, lr=self.lr, step_dev=self.step_dev)
         self.rng.advance(1)
+
+    def _collective_update(self):
+        if self.world > 1:
+            parallel.allreduce_sum_(self.gbuf)       # ONE collective: flat gradient bucket + the loss scalar
+        self._update()
+
+    def capture(self):
+        """One ordinary eager step with the pre-collective part on a side stream (allocations, packed-weight
+        images, one-time kernel attributes), then the capture.  Parameters, Adam state, Philox offset and step
+        counter all live on the device, so the warm-up is a real training step and every replay is the next one.
+        With one rank the graph holds the whole step; with N ranks it ends before the RCCL all-reduce."""
+        side = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side):
+            self._fwd_bwd()
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        self._collective_update()
+        torch.cuda.synchronize(self.dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._fwd_bwd()
+            if self.world == 1:
+                self._update()
+
+    def step(self):
+        if not self.use_graph:
+            self._fwd_bwd()
+            self._collective_update()
+            return self.loss
+        if self.graph is None:
+            self.capture()                           # performs this call's step eagerly
+            return self.loss
+        self.graph.replay()
+        if self.world > 1:
+            self._collective_update()
         return self.loss
