@@ -853,7 +853,8 @@ int msgm_conv_wgrad(const msgm_conv_geom_t* geom, const float* gy, const float* 
     int wgs = 1024 / yblocks;                              // ~4 workgroups per CU overall
     if (wgs < 1) wgs = 1;
     int per = (n_tiles + wgs - 1) / wgs;
-    if (per < 4) per = n_tiles < 4 ? n_tiles : 4;
+    static const int min_per = getenv("MSGM_WGRAD_PER") ? atoi(getenv("MSGM_WGRAD_PER")) : 8;   // >= 8 tiles per workgroup amortise the cross-wave sum + atomics
+    if (per < min_per) per = n_tiles < min_per ? n_tiles : min_per;
     wgs = (n_tiles + per - 1) / per;
     const int halo = (TH + geom->KH - 1) * (TW + geom->KW - 1);
     const int IP = ((halo + 7) & ~7) + 3;

@@ -111,7 +111,7 @@ class UNetScoreTrainer:
     with one rank the Adam update and the Philox advance are inside the graph too."""
 
     def __init__(self, gen_sde, batch_local: int, dim: int, lr: float = 1e-4, world: int = 1, seed: int = 0,
-                 use_graph: bool = True):
+                 use_graph: Optional[bool] = None):
         net, base = gen_sde.a, gen_sde.base_sde
         if not hasattr(net, "ssm_grad") or base.kind != L.SDE_SGM:
             raise MsgmError("UNetScoreTrainer needs a HIP U-Net score net and an SGMsde")
@@ -130,7 +130,9 @@ class UNetScoreTrainer:
         self.t = torch.empty(batch_local, dtype=torch.float32, device=self.dev)
         self.st = base.struct()
         self.inv_batch = 1.0 / (batch_local * world)
-        self.use_graph = use_graph
+        # default: graph on one rank only — the step is GPU-bound either way (the host runs ahead of ~2000 launches),
+        # and capturing next to a live RCCL communicator is not something a 1-GPU box can rehearse
+        self.use_graph = (world == 1) if use_graph is None else bool(use_graph)
         self.graph = None
 
     def set_data(self, x):
@@ -171,7 +173,8 @@ class UNetScoreTrainer:
         self._collective_update()
         torch.cuda.synchronize(self.dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        mode = "global" if self.world == 1 else "thread_local"      # a collective backend's watchdog thread must not
+        with torch.cuda.graph(self.graph, capture_error_mode=mode):  # invalidate the capture
             self._fwd_bwd()
             if self.world == 1:
                 self._update()
