@@ -233,32 +233,27 @@ __global__ void __launch_bounds__(256) k_conv_gemm(ConvArgs A) {
 #define CT_KC 32
 #define CT_P 36
 template <int TH, int TW, int NCO>
-__global__ void __launch_bounds__(256) k_conv_tile(ConvArgs A, int flip, int tiles_x, int tiles_y) {
+__global__ void __launch_bounds__(256) k_conv_tile(ConvArgs A, int flip, int tiles_x, int tiles_y, int tiles_per_wg, int n_tiles) {
   extern __shared__ __attribute__((aligned(16))) float ct_lds[];
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, il = lane & 15, q = lane >> 4;
   const ConvGeom g = A.g;
   const int KH = g.KH, KW = g.KW, taps = KH * KW;
   const int HH = TH + KH - 1, HW = TW + KW - 1, halo = HH * HW;
-  float* buf0 = ct_lds;
-  float* buf1 = ct_lds + halo * CT_P;
-  int bx = blockIdx.x;
-  const int tx_i = bx % tiles_x; bx /= tiles_x;
-  const int ty_i = bx % tiles_y;
-  const int n = bx / tiles_y;
-  const int y0 = ty_i * TH, x0 = tx_i * TW;
+  float* cur = ct_lds;
+  float* nxt = ct_lds + halo * CT_P;
   const int co0 = blockIdx.y * (NCO * 16);
-  // this lane's two output pixels
+  // A workgroup walks over tiles_per_wg consecutive spatial tiles; the pipeline unit is a (tile, channel chunk)
+  // item, so the halo of the NEXT tile is in flight during the MFMAs of this one even when Cin fits one chunk.
+  const int t_beg = blockIdx.x * tiles_per_wg, t_end = min(t_beg + tiles_per_wg, n_tiles);
+  if (t_beg >= t_end) return;
+  // this lane's two output pixels inside a tile
   int pty[2], ptx[2];
-  bool pin[2];
 #pragma unroll
   for (int pt = 0; pt < 2; ++pt) {
     const int p = 32 * w + 16 * pt + il;
     pty[pt] = p / TW; ptx[pt] = p - pty[pt] * TW;
-    pin[pt] = (y0 + pty[pt] < g.Ho) && (x0 + ptx[pt] < g.Wo);
   }
   f32x4 acc[NCO][2];
-#pragma unroll
-  for (int c = 0; c < NCO; ++c) { acc[c][0] = f32x4{0, 0, 0, 0}; acc[c][1] = f32x4{0, 0, 0, 0}; }
 
   // chunk list: (source, channel offset), flattened
   int nch[CONV_MAX_SRC];
@@ -271,7 +266,14 @@ __global__ void __launch_bounds__(256) k_conv_tile(ConvArgs A, int flip, int til
   f32x4 st[MAXST];
   const int n_items = halo * (CT_KC / 4);
   const int padH = g.padH, padW = g.padW;
-  auto stage_load = [&](int s, int c0) {
+  auto tile_origin = [&](int t, int& n, int& y0, int& x0) {
+    const int tx_i = t % tiles_x; t /= tiles_x;
+    const int ty_i = t % tiles_y;
+    n = t / tiles_y; y0 = ty_i * TH; x0 = tx_i * TW;
+  };
+  auto stage_load = [&](int t, int s, int c0) {
+    int n, y0, x0;
+    tile_origin(t, n, y0, x0);
     const int C = A.C[s];
     const float* base = A.src[s] + (size_t)n * g.Hi * g.Wi * C;
 #pragma unroll
@@ -297,19 +299,23 @@ __global__ void __launch_bounds__(256) k_conv_tile(ConvArgs A, int flip, int til
     }
   };
 
-  int cs = 0, cc = 0;                    // current chunk: source cs, chunk index cc within it
-  stage_load(0, 0);
-  stage_store(buf0);
+  int tile = t_beg, cs = 0, cc = 0;      // current item: tile, source cs, chunk index cc within it
+  stage_load(tile, 0, 0);
+  stage_store(cur);
   __syncthreads();
-  float* cur = buf0;
-  float* nxt = buf1;
   const size_t a_co_stride = (size_t)16 * A.Ktot;
-  for (int ch = 0; ch < total_chunks; ++ch) {
-    // next chunk coordinates
-    int ns = cs, nc = cc + 1;
+  for (;;) {
+    // next item
+    int ntile = tile, ns = cs, nc = cc + 1;
     if (nc == nch[cs]) { ns = cs + 1; nc = 0; }
-    const bool more = ch + 1 < total_chunks;
-    if (more) stage_load(ns, nc * CT_KC);
+    const bool last_chunk = ns >= A.nsrc || nch[ns] == 0;
+    if (last_chunk) { ntile = tile + 1; ns = 0; nc = 0; }
+    const bool more = ntile < t_end;
+    if (more) stage_load(ntile, ns, nc * CT_KC);
+    if (cs == 0 && cc == 0) {
+#pragma unroll
+      for (int c = 0; c < NCO; ++c) { acc[c][0] = f32x4{0, 0, 0, 0}; acc[c][1] = f32x4{0, 0, 0, 0}; }
+    }
     // ---- MFMAs of this chunk: (tap, 16-channel group) pairs, weight fragments one pair ahead
     const int C = A.C[cs];
     const int c0 = cc * CT_KC;
@@ -346,42 +352,47 @@ __global__ void __launch_bounds__(256) k_conv_tile(ConvArgs A, int flip, int til
         }
       tap = ntap; grp = ngr;
     }
-    if (more) stage_store(nxt);
-    __syncthreads();
-    float* t = cur; cur = nxt; nxt = t;
-    cs = ns; cc = nc;
-  }
 
-  // ---- epilogue (same contract as k_conv_gemm)
+    // ---- epilogue of a finished tile (same contract as k_conv_gemm)
+    if (last_chunk) {
+      int n, y0, x0;
+      tile_origin(tile, n, y0, x0);
 #pragma unroll
-  for (int pt = 0; pt < 2; ++pt) {
-    if (!pin[pt]) continue;
-    const size_t m = ((size_t)n * g.Ho + y0 + pty[pt]) * g.Wo + x0 + ptx[pt];
-    const bool primal = n < A.n_bias;
+      for (int pt = 0; pt < 2; ++pt) {
+        if (!((y0 + pty[pt] < g.Ho) && (x0 + ptx[pt] < g.Wo))) continue;
+        const size_t m = ((size_t)n * g.Ho + y0 + pty[pt]) * g.Wo + x0 + ptx[pt];
+        const bool primal = n < A.n_bias;
 #pragma unroll
-    for (int c = 0; c < NCO; ++c) {
-      const int co = co0 + 16 * c + 4 * q;
-      if (co >= A.Cout) continue;
-      f32x4 v = acc[c][pt];
-      float* op = A.out + m * A.Cout + co;
-      const bool full = (co + 3 < A.Cout) && ((A.Cout & 3) == 0);
-      if (primal && A.bias) {
+        for (int c = 0; c < NCO; ++c) {
+          const int co = co0 + 16 * c + 4 * q;
+          if (co >= A.Cout) continue;
+          f32x4 v = acc[c][pt];
+          float* op = A.out + m * A.Cout + co;
+          const bool full = (co + 3 < A.Cout) && ((A.Cout & 3) == 0);
+          if (primal && A.bias) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) if (co + r < A.Cout) v[r] += A.bias[co + r];
-      }
-      if (A.samp_bias && n < A.n_samp) {
+            for (int r = 0; r < 4; ++r) if (co + r < A.Cout) v[r] += A.bias[co + r];
+          }
+          if (A.samp_bias && n < A.n_samp) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) if (co + r < A.Cout) v[r] += A.samp_bias[(size_t)n * A.Cout + co + r];
-      }
-      if (full) {
-        if (A.accumulate) v += *reinterpret_cast<const f32x4*>(op);
-        *reinterpret_cast<f32x4*>(op) = v;
-      } else {
+            for (int r = 0; r < 4; ++r) if (co + r < A.Cout) v[r] += A.samp_bias[(size_t)n * A.Cout + co + r];
+          }
+          if (full) {
+            if (A.accumulate) v += *reinterpret_cast<const f32x4*>(op);
+            *reinterpret_cast<f32x4*>(op) = v;
+          } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (co + r < A.Cout) op[r] = A.accumulate ? op[r] + v[r] : v[r];
+            for (int r = 0; r < 4; ++r)
+              if (co + r < A.Cout) op[r] = A.accumulate ? op[r] + v[r] : v[r];
+          }
+        }
       }
     }
+    if (!more) break;
+    stage_store(nxt);
+    __syncthreads();
+    float* t = cur; cur = nxt; nxt = t;
+    tile = ntile; cs = ns; cc = nc;
   }
 }
 
@@ -805,14 +816,22 @@ int msgm_conv_forward(const msgm_conv_geom_t* geom, const float* src0, int32_t C
     const int halo = (TH + geom->KH - 1) * (TW + geom->KW - 1);
     const size_t lds = (size_t)2 * halo * CT_P * sizeof(float);
     const int nco = (CoutP % 64 == 0) ? 4 : 2;
-    dim3 grid((unsigned)(tiles_x * tiles_y * geom->N), (unsigned)(CoutP / (16 * nco)));
+    const int n_tiles = tiles_x * tiles_y * geom->N, gy = CoutP / (16 * nco);
+    // several consecutive tiles per workgroup (the next tile's halo loads overlap this tile's MFMAs) — but only
+    // while >= 8 rounds of resident workgroups (3 per CU) remain: below that the tail of the last round costs more
+    // than the hidden prologues gain (measured, tools/bench_conv.py)
+    static const int max_per = getenv("MSGM_CONV_TILES") ? atoi(getenv("MSGM_CONV_TILES")) : 4;
+    int per = (int)(((int64_t)n_tiles * gy) / 6144);
+    if (per > max_per) per = max_per;
+    if (per < 1) per = 1;
+    dim3 grid((unsigned)((n_tiles + per - 1) / per), (unsigned)gy);
     const int flip = geom->mode;
     if (two_d) {
-      if (nco == 4) hipLaunchKernelGGL((k_conv_tile<8, 16, 4>), grid, dim3(256), lds, S(stream), A, flip, tiles_x, tiles_y);
-      else hipLaunchKernelGGL((k_conv_tile<8, 16, 2>), grid, dim3(256), lds, S(stream), A, flip, tiles_x, tiles_y);
+      if (nco == 4) hipLaunchKernelGGL((k_conv_tile<8, 16, 4>), grid, dim3(256), lds, S(stream), A, flip, tiles_x, tiles_y, per, n_tiles);
+      else hipLaunchKernelGGL((k_conv_tile<8, 16, 2>), grid, dim3(256), lds, S(stream), A, flip, tiles_x, tiles_y, per, n_tiles);
     } else {
-      if (nco == 4) hipLaunchKernelGGL((k_conv_tile<1, 128, 4>), grid, dim3(256), lds, S(stream), A, flip, tiles_x, tiles_y);
-      else hipLaunchKernelGGL((k_conv_tile<1, 128, 2>), grid, dim3(256), lds, S(stream), A, flip, tiles_x, tiles_y);
+      if (nco == 4) hipLaunchKernelGGL((k_conv_tile<1, 128, 4>), grid, dim3(256), lds, S(stream), A, flip, tiles_x, tiles_y, per, n_tiles);
+      else hipLaunchKernelGGL((k_conv_tile<1, 128, 2>), grid, dim3(256), lds, S(stream), A, flip, tiles_x, tiles_y, per, n_tiles);
     }
     return msgm_check_launch();
   }
