@@ -278,9 +278,12 @@ int msgm_conv_forward(const msgm_conv_geom_t* geom, const float* src0, int32_t C
                       msgm_stream_t stream);
 
 /* dWp[tap][co][koff + c] += sum_m gy[m][co] in[src(m,tap)][c] (float atomics across
- * position chunks; zero dWp first).  One call per concatenated source. */
+ * position chunks; zero dWp first).  One call per concatenated source.
+ * dbias (may be NULL): dbias[co] += sum over the primal rows n < n_bias and all pixels of gy — the bias gradient
+ * (torch: conv backward's grad_bias) as a by-product of the tiles the kernel stages anyway; zero it first. */
 int msgm_conv_wgrad(const msgm_conv_geom_t* geom, const float* gy, const float* src, int32_t C, int32_t koff,
-                    float* dWp, int32_t Cout, int32_t CoutP, int32_t Ktot, msgm_stream_t stream);
+                    float* dWp, int32_t Cout, int32_t CoutP, int32_t Ktot, float* dbias, int32_t n_bias,
+                    msgm_stream_t stream);
 
 /* Wp[t][r][kp_off + c] = W[r*sr + (col_off + c)*sc + t*st] for r < rows, c < ncols
  * (strides in elements: any of the PyTorch layouts (Cout,Cin,k), (Cin,Cout,k) and

@@ -378,7 +378,7 @@ class VorticityUNet(nn.Module, FlatParamMixin):
                 self._flatten_parameters()
                 break
         x = self._build()
-        x["set"].zero_grad_images()
+        x["set"].zero_grad_images(bias_grads_zeroed=True)
         flat, gflat = self.flat_parameters()
         gflat.zero_()                    # GroupNorm parameter gradients are accumulated with atomics; one memset for all
         forder = self.flatten_order == "F"

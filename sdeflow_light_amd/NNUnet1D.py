@@ -187,7 +187,8 @@ class UNet1D(nn.Module, FlatParamMixin):
                 self._flatten_parameters()
                 break
         o = self._build()
-        self._opset.zero_grad_images()
+        self._opset.zero_grad_images(bias_grads_zeroed=True)
+        self.flat_parameters()[1].zero_()          # bias gradients are accumulated as a by-product of wgrad
         tape = []
         h0 = torch.cat([y.contiguous().float(), v.contiguous().float()], 0).reshape(-1)
         out = self._run(h0, t.reshape(-1).contiguous().float(), N, B, L, True, tape)

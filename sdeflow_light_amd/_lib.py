@@ -72,7 +72,7 @@ SIGNATURES = {
     "msgm_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _D, _D, _D, _D, _F, _I64, _P, _P]),
     "msgm_counter_inc": (C.c_int, [_P, _P]),
     "msgm_conv_forward": (C.c_int, [C.POINTER(ConvGeomT), _P, _I32, _P, _I32, _P, _I32, _I32, _I32, _P, _P, _I32, _I32, _P, _I32, _P]),
-    "msgm_conv_wgrad": (C.c_int, [C.POINTER(ConvGeomT), _P, _P, _I32, _I32, _P, _I32, _I32, _I32, _P]),
+    "msgm_conv_wgrad": (C.c_int, [C.POINTER(ConvGeomT), _P, _P, _I32, _I32, _P, _I32, _I32, _I32, _P, _I32, _P]),
     "msgm_pack_weight": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I32, _I32, _I32, _P]),
     "msgm_unpack_weight": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I32, _I32, _I32, _I32, _P]),
     "msgm_act_dual_forward": (C.c_int, [_I32, _P, _P, _I64, _I32, _P]),

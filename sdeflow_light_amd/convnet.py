@@ -59,8 +59,12 @@ class ConvOpSet:
             self._pack_sig = sig
         self._pack.run(False)
 
-    def zero_grad_images(self):
+    def zero_grad_images(self, bias_grads_zeroed: bool = False):
+        """bias_grads_zeroed: the caller has zeroed the flat gradient bucket for this step, so each op's next
+        backward() may accumulate its bias gradient without a memset of its own."""
         self.gimg.zero_()
+        for o in self.ops:
+            o._bias_zeroed = bool(bias_grads_zeroed)
 
     def unpack_grads(self):
         sig = tuple(o.weight.grad.data_ptr() for o in self.ops)
@@ -108,6 +112,7 @@ class ConvOp:
             self.dWpE = torch.zeros_like(self.WpE)
             self.WdE = torch.zeros(3 * pad16(emb_channels) * pad16(self.Cout), device=dev)
         self._E = None
+        self._bias_zeroed = False      # set per step by ConvOpSet.zero_grad_images, consumed by the next backward
 
     # -------------------------------------------------------------- packing
     def pack(self):
@@ -219,20 +224,26 @@ class ConvOp:
                  emb: Optional[torch.Tensor] = None, demb: Optional[torch.Tensor] = None,
                  need: Optional[Sequence[bool]] = None, dsrc: Optional[List[Optional[torch.Tensor]]] = None,
                  dacc: Optional[Sequence[bool]] = None, dsamp_bias: Optional[torch.Tensor] = None,
-                 emb_rows: Optional[int] = None):
+                 emb_rows: Optional[int] = None, bias_grad_zeroed: bool = False):
         """gy: cotangent of the output [N][Ho][Wo][Cout].  Accumulates the packed
         weight gradient, writes bias.grad, adds to ``demb`` / writes ``dsamp_bias``
         (per-sample bias cotangent, primal rows) and returns d(src_s)."""
         geom, Ho, Wo = self._geom(N, Hi, Wi)
         dev = gy.device
         P = Ho * Wo
+        # bias only (no per-sample bias / embedding): the gradient is a by-product of the first source's wgrad
+        fuse_bias = self.bias is not None and not self.embC and dsamp_bias is None
+        bias_grad_zeroed = bias_grad_zeroed or self._bias_zeroed
+        self._bias_zeroed = False
+        if fuse_bias and not bias_grad_zeroed:
+            self.bias.grad.zero_()
         for s, C in enumerate(self.srcC):
-            ops.conv_wgrad(geom, gy, srcs[s], C, self.koff[s], self.dWp, self.Cout, self.CoutP, self.Ktot)
+            ops.conv_wgrad(geom, gy, srcs[s], C, self.koff[s], self.dWp, self.Cout, self.CoutP, self.Ktot,
+                           dbias=self.bias.grad.view(-1) if (fuse_bias and s == 0) else None, n_bias=n_bias)
         S = None
         er = n_bias if emb_rows is None else emb_rows
-        if self.bias is not None and not self.embC and dsamp_bias is None:
-            # bias only: the primal rows are one contiguous [n_bias * P][Cout] block — one reduction, no per-sample stage
-            ops.colsum(gy, 1, n_bias * P, self.Cout, out=self.bias.grad.view(1, -1))
+        if fuse_bias:
+            pass
         elif self.bias is not None or self.embC or dsamp_bias is not None:
             S = dsamp_bias if dsamp_bias is not None else torch.empty(er * self.Cout, device=dev)
             ops.colsum(gy, er, P, self.Cout, out=S)                           # rows that carry a bias / embedding
@@ -267,16 +278,20 @@ class ConvOp:
             outs.append(d)
         return outs
 
-    def backward_ups(self, gy: torch.Tensor, src: torch.Tensor, N: int, Hi: int, Wi: int, n_bias: int) -> torch.Tensor:
+    def backward_ups(self, gy: torch.Tensor, src: torch.Tensor, N: int, Hi: int, Wi: int, n_bias: int,
+                     bias_grad_zeroed: bool = False) -> torch.Tensor:
         """Backward of a conv whose input is nearest-upsampled 2x on the fly (Upsample, model/unet.py:60-73):
         wgrad through the folded gather, dgrad on the 2x grid, then the 2x2 block sum (adjoint of the upsample)."""
         if not self.ups or len(self.srcC) != 1:
             raise MsgmError("backward_ups is for a single-source folded-upsample conv")
         geom, Ho, Wo = self._geom(N, Hi, Wi)
         dev, C = gy.device, self.srcC[0]
-        ops.conv_wgrad(geom, gy, src, C, 0, self.dWp, self.Cout, self.CoutP, self.Ktot)
-        if self.bias is not None:
-            ops.colsum(gy, 1, n_bias * Ho * Wo, self.Cout, out=self.bias.grad.view(1, -1))
+        bias_grad_zeroed = bias_grad_zeroed or self._bias_zeroed
+        self._bias_zeroed = False
+        if self.bias is not None and not bias_grad_zeroed:
+            self.bias.grad.zero_()
+        ops.conv_wgrad(geom, gy, src, C, 0, self.dWp, self.Cout, self.CoutP, self.Ktot,
+                       dbias=self.bias.grad.view(-1) if self.bias is not None else None, n_bias=n_bias)
         gd = ops.conv_geom(N, Ho, Wo, 2 * Hi, 2 * Wi, self.KH, self.KW, self.stride, self.pad, 1 - self.mode, 0)
         gup = torch.empty(N * 4 * Hi * Wi * C, device=dev)
         ops.conv_forward(gd, gy, self.Cout, self.Wd[0], C, gup, CoutP=pad16(C))

@@ -405,6 +405,8 @@ struct WgradArgs {
   float* dWp;                 // [taps][CoutP][Ktot], accumulated with float atomics
   int Cout, CoutP, Ktot;
   int chunk;                  // output positions per workgroup
+  float* dbias;               // optional: dbias[co] += sum over primal rows (n < n_bias) and pixels of gy (tile kernel)
+  int n_bias;
 };
 
 // One workgroup = one (position chunk, tap, co block of 16*MT, c block of 16*KT).
@@ -573,6 +575,9 @@ __global__ void __launch_bounds__(256) k_wgrad_tile(WgradArgs A, int tiles_x, in
     }
   };
 
+  const bool do_bias = A.dbias != nullptr && cblk == 0;
+  const int tiles_per_sample = tiles_x * tiles_y;
+  float bsum = 0.f;                                        // thread (co = tid>>3, 16-pixel part = tid&7)
   stage_load(t_beg);
   stage_store(0);
   __syncthreads();
@@ -582,6 +587,14 @@ __global__ void __launch_bounds__(256) k_wgrad_tile(WgradArgs A, int tiles_x, in
     if (more) stage_load(tile + 1);
     const float* gT = gyT[cur];
     const float* iT = inT[cur];
+    if (do_bias && tile / tiles_per_sample < A.n_bias) {   // bias gradient as a by-product of the staged gy tile
+      const float* gr = gT + (tid >> 3) * WT_GP + 16 * (tid & 7);
+      f32x4 t4 = *reinterpret_cast<const f32x4*>(gr);
+      t4 += *reinterpret_cast<const f32x4*>(gr + 4);
+      t4 += *reinterpret_cast<const f32x4*>(gr + 8);
+      t4 += *reinterpret_cast<const f32x4*>(gr + 12);
+      bsum += (t4[0] + t4[1]) + (t4[2] + t4[3]);
+    }
 #pragma unroll
     for (int pg2 = 0; pg2 < 2; ++pg2) {
       const int pg = 2 * w + pg2;                           // this wave's 16-pixel group
@@ -611,6 +624,13 @@ __global__ void __launch_bounds__(256) k_wgrad_tile(WgradArgs A, int tiles_x, in
     if (more) stage_store(cur ^ 1);
     __syncthreads();
     cur ^= 1;
+  }
+  if (do_bias) {
+    bsum += __shfl_xor(bsum, 1, 64);
+    bsum += __shfl_xor(bsum, 2, 64);
+    bsum += __shfl_xor(bsum, 4, 64);
+    const int co = co0 + (tid >> 3);
+    if ((tid & 7) == 0 && co < A.Cout) atomicAdd(A.dbias + co, bsum);
   }
   // cross-wave reduction through LDS (reuse the staging area), then atomics
   float* red = wt_lds;
@@ -727,7 +747,7 @@ __global__ void k_act_dual_bwd(const float* __restrict__ z, float* __restrict__ 
 // S[n][c] (+)= sum over positions of x[n][pos][c]  (bias / embedding gradients).  Grid (n, position
 // chunk): threads along channels, LDS across pixel lanes, one float atomic per (n, c) per block into a
 // zeroed S (a per-sample workgroup would leave the chip idle at small batch).
-__global__ void __launch_bounds__(256) k_colsum(const float* __restrict__ x, float* __restrict__ S, int P, int C, int chunk) {
+__global__ void __launch_bounds__(256) k_colsum(const float* __restrict__ x, float* __restrict__ S, int P, int C, int chunk, int acc) {
   __shared__ float red[256];
   const int n = blockIdx.x;
   const float* xn = x + (size_t)n * P * C;
@@ -744,7 +764,7 @@ __global__ void __launch_bounds__(256) k_colsum(const float* __restrict__ x, flo
     if (pr == 0) {
       float t = 0.f;
       for (int r = 0; r < rows; ++r) t += red[r * lanes_c + c];
-      if (gridDim.y == 1) S[(size_t)n * C + cb + c] = t;
+      if (gridDim.y == 1 && !acc) S[(size_t)n * C + cb + c] = t;
       else atomicAdd(S + (size_t)n * C + cb + c, t);
     }
     __syncthreads();
@@ -852,11 +872,11 @@ int msgm_conv_forward(const msgm_conv_geom_t* geom, const float* src0, int32_t C
 }
 
 int msgm_conv_wgrad(const msgm_conv_geom_t* geom, const float* gy, const float* src, int32_t C, int32_t koff,
-                    float* dWp, int32_t Cout, int32_t CoutP, int32_t Ktot, msgm_stream_t stream) {
+                    float* dWp, int32_t Cout, int32_t CoutP, int32_t Ktot, float* dbias, int32_t n_bias, msgm_stream_t stream) {
   int rc = check_geom(geom);
   if (rc) return rc;
-  if (!gy || !src || !dWp || C <= 0 || Cout <= 0 || koff < 0 || koff + C > Ktot) return MSGM_E_BADARG;
-  WgradArgs A{to_geom(geom), gy, src, C, koff, dWp, Cout, CoutP, Ktot, 0};
+  if (!gy || !src || !dWp || C <= 0 || Cout <= 0 || koff < 0 || koff + C > Ktot || (dbias && n_bias <= 0)) return MSGM_E_BADARG;
+  WgradArgs A{to_geom(geom), gy, src, C, koff, dWp, Cout, CoutP, Ktot, 0, dbias, n_bias};
   const int64_t Mtot = (int64_t)geom->N * geom->Ho * geom->Wo;
   const int taps = geom->KH * geom->KW;
   const bool same = geom->mode == 0 && geom->strideH == 1 && geom->strideW == 1 && !geom->ups && geom->Hi == geom->Ho &&
@@ -907,6 +927,13 @@ int msgm_conv_wgrad(const msgm_conv_geom_t* geom, const float* gy, const float* 
   A.chunk = (int)chunk;
   dim3 grid((unsigned)nchunks, (unsigned)(coblocks * cblocks), (unsigned)taps);
   hipLaunchKernelGGL((k_conv_wgrad<2, 4>), grid, dim3(256), 0, S(stream), A);
+  if (dbias) {                                             // no by-product in this kernel: a separate accumulating column sum
+    const int64_t Pb = (int64_t)n_bias * geom->Ho * geom->Wo;
+    int64_t cch = (Pb + 1023) / 1024;
+    if (cch < 64) cch = 64;
+    if (cch > Pb) cch = Pb;
+    hipLaunchKernelGGL(k_colsum, dim3(1, (unsigned)((Pb + cch - 1) / cch)), dim3(256), 0, S(stream), gy, dbias, (int)Pb, Cout, (int)cch, 1);
+  }
   return msgm_check_launch();
 }
 
@@ -972,7 +999,7 @@ int msgm_colsum(const float* x, float* Sout, int32_t N, int32_t P, int32_t C, ms
   if (chunk > P) chunk = P;
   nch = (P + chunk - 1) / chunk;
   if (nch > 1 && hipMemsetAsync(Sout, 0, (size_t)N * C * sizeof(float), S(stream)) != hipSuccess) return MSGM_E_LAUNCH;
-  hipLaunchKernelGGL(k_colsum, dim3(N, nch), dim3(256), 0, S(stream), x, Sout, P, C, chunk);
+  hipLaunchKernelGGL(k_colsum, dim3(N, nch), dim3(256), 0, S(stream), x, Sout, P, C, chunk, 0);
   return msgm_check_launch();
 }
 

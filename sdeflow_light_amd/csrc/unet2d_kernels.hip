@@ -40,19 +40,6 @@ struct GnArgs {
   const float* gout; float* gx; float* dgamma; float* dbeta;
 };
 
-__device__ __forceinline__ void gn_group_atomic(float* red, float v, int tid, int cl, int pl, int G, int cpg, double* dst,
-                                                int stride) {
-  red[tid] = v;
-  __syncthreads();
-  if (tid < G) {
-    float s = 0.f;
-    for (int p = 0; p < pl; ++p)
-      for (int cc = 0; cc < cpg; ++cc) s += red[p * cl + tid * cpg + cc];
-    atomicAdd(dst + (size_t)tid * stride, (double)s);
-  }
-  __syncthreads();
-}
-
 // V values per thread (channels V*cv .. V*cv+V-1 of pixel lane pl): LDS image [pl][C], then one thread per group sums
 // its channels over the pixel lanes and issues ONE double atomic.
 template <int V>
@@ -209,57 +196,78 @@ __global__ void __launch_bounds__(256) k_gn_fwd_apply(GnArgs A, const float* __r
 //   xdotbar = inv (W - mean W - xhat p),                      p = mean(xhat W)
 //   xbar    = inv (X - mean X - xhat mean(xhat X)) - inv (c xhat + a xdotbar + p what),  c = mean(W what)
 // (derived by hand, checked against autograd in tests/test_unet2d_gpu.py).
-__device__ __forceinline__ void gn_bwd_elem(const GnArgs& A, long e, long tot, float mu, float inv, float md, float a,
-                                            float ga, float be, float& xh, float& wh, float& zb, float& zdb) {
-  xh = (A.x[e] - mu) * inv;
-  wh = inv * ((A.x[e + tot] - md) - xh * a);
-  zb = A.gout[e]; zdb = A.gout[e + tot];
-  if (A.silu) {
-    float z0, z1, z2;
-    silu012u(ga * xh + be, z0, z1, z2);
-    const float yd = ga * wh;
-    const float nzb = zb * z1 + zdb * (z2 * yd);
-    zdb = zdb * z1;
-    zb = nzb;
-  }
-}
-
+template <bool VEC>
 __global__ void __launch_bounds__(256) k_gn_bwd_reduce(GnArgs A) {
-  __shared__ float red[256];
+  constexpr int V = VEC ? 4 : 1;
+  __shared__ float red[1024];
   const int tid = threadIdx.x, b = blockIdx.x;
   const int C = A.C, P = A.P, G = A.G, cpg = C / G;
-  const int cl = C, pl = 256 / C > 0 ? 256 / C : 1;
-  const bool live = tid < cl * pl;
-  const int c = live ? tid % cl : 0, pr = live ? tid / cl : 0;
+  const int CV = C / V, PL = 256 / CV;
+  const bool live = tid < CV * PL;
+  const int cv = live ? tid % CV : 0, pl = live ? tid / CV : 0;
   const long tot = (long)A.Bp * P * C;
-  const float* st = A.stats + ((size_t)b * G + c / cpg) * 4;
-  const float mu = st[0], inv = st[1], md = st[2], a = st[3];
-  const float ga = A.gamma[c], be = A.beta[c];
+  float mu[V], inv[V], md[V], a[V], ga[V], be[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) {
+    const int c = V * cv + k;
+    const f32x4 st = *reinterpret_cast<const f32x4*>(A.stats + ((size_t)b * G + c / cpg) * 4);
+    mu[k] = st[0]; inv[k] = st[1]; md[k] = st[2]; a[k] = st[3];
+    ga[k] = A.gamma[c]; be[k] = A.beta[c];
+  }
   const int p0 = blockIdx.y * A.chunk, p1 = min(p0 + A.chunk, P);
-  float sX = 0.f, sXx = 0.f, sW = 0.f, sWx = 0.f, sWw = 0.f, dga = 0.f, dbe = 0.f;
+  float sX[V], sXx[V], sW[V], sWx[V], sWw[V], dga[V], dbe[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) { sX[k] = sXx[k] = sW[k] = sWx[k] = sWw[k] = dga[k] = dbe[k] = 0.f; }
   if (live)
-    for (int p = p0 + pr; p < p1; p += pl) {
-      const long e = ((long)b * P + p) * C + c;
-      float xh, wh, zb, zdb;
-      gn_bwd_elem(A, e, tot, mu, inv, md, a, ga, be, xh, wh, zb, zdb);
-      const float X = ga * zb, W = ga * zdb;
-      sX += X; sXx += X * xh; sW += W; sWx += W * xh; sWw += W * wh;
-      dga += zb * xh + zdb * wh; dbe += zb;
+    for (int p = p0 + pl; p < p1; p += PL) {
+      const long e = ((long)b * P + p) * C + V * cv;
+      float x[V], xd[V], zb[V], zdb[V];
+      if (VEC) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(A.x + e), v1 = *reinterpret_cast<const f32x4*>(A.x + e + tot);
+        const f32x4 v2 = *reinterpret_cast<const f32x4*>(A.gout + e), v3 = *reinterpret_cast<const f32x4*>(A.gout + e + tot);
+#pragma unroll
+        for (int k = 0; k < V; ++k) { x[k] = v0[k]; xd[k] = v1[k]; zb[k] = v2[k]; zdb[k] = v3[k]; }
+      } else {
+        x[0] = A.x[e]; xd[0] = A.x[e + tot]; zb[0] = A.gout[e]; zdb[0] = A.gout[e + tot];
+      }
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        const float xh = (x[k] - mu[k]) * inv[k];
+        const float wh = inv[k] * ((xd[k] - md[k]) - xh * a[k]);
+        float zbk = zb[k], zdbk = zdb[k];
+        if (A.silu) {
+          float z0, z1, z2;
+          silu012u(ga[k] * xh + be[k], z0, z1, z2);
+          const float yd = ga[k] * wh;
+          const float nzb = zbk * z1 + zdbk * (z2 * yd);
+          zdbk = zdbk * z1;
+          zbk = nzb;
+        }
+        const float X = ga[k] * zbk, W = ga[k] * zdbk;
+        sX[k] += X; sXx[k] += X * xh; sW[k] += W; sWx[k] += W * xh; sWw[k] += W * wh;
+        dga[k] += zbk * xh + zdbk * wh; dbe[k] += zbk;
+      }
     }
   double* dst = A.acc + (size_t)b * G * 8;
-  gn_group_atomic(red, live ? sX : 0.f, tid, cl, pl, G, cpg, dst + 0, 8);
-  gn_group_atomic(red, live ? sXx : 0.f, tid, cl, pl, G, cpg, dst + 1, 8);
-  gn_group_atomic(red, live ? sW : 0.f, tid, cl, pl, G, cpg, dst + 2, 8);
-  gn_group_atomic(red, live ? sWx : 0.f, tid, cl, pl, G, cpg, dst + 3, 8);
-  gn_group_atomic(red, live ? sWw : 0.f, tid, cl, pl, G, cpg, dst + 4, 8);
+  gn_group_atomic_v<V>(red, sX, live, cv, pl, C, PL, G, cpg, dst + 0, 8);
+  gn_group_atomic_v<V>(red, sXx, live, cv, pl, C, PL, G, cpg, dst + 1, 8);
+  gn_group_atomic_v<V>(red, sW, live, cv, pl, C, PL, G, cpg, dst + 2, 8);
+  gn_group_atomic_v<V>(red, sWx, live, cv, pl, C, PL, G, cpg, dst + 3, 8);
+  gn_group_atomic_v<V>(red, sWw, live, cv, pl, C, PL, G, cpg, dst + 4, 8);
   // per-channel parameter gradients: sum the pixel lanes, one atomic per channel per block
-  red[tid] = live ? dga : 0.f;
+  if (live) {
+#pragma unroll
+    for (int k = 0; k < V; ++k) red[pl * C + V * cv + k] = dga[k];
+  }
   __syncthreads();
-  if (tid < cl) { float s = 0.f; for (int p = 0; p < pl; ++p) s += red[p * cl + tid]; atomicAdd(A.dgamma + tid, s); }
+  if (tid < C) { float t = 0.f; for (int p = 0; p < PL; ++p) t += red[p * C + tid]; atomicAdd(A.dgamma + tid, t); }
   __syncthreads();
-  red[tid] = live ? dbe : 0.f;
+  if (live) {
+#pragma unroll
+    for (int k = 0; k < V; ++k) red[pl * C + V * cv + k] = dbe[k];
+  }
   __syncthreads();
-  if (tid < cl) { float s = 0.f; for (int p = 0; p < pl; ++p) s += red[p * cl + tid]; atomicAdd(A.dbeta + tid, s); }
+  if (tid < C) { float t = 0.f; for (int p = 0; p < PL; ++p) t += red[p * C + tid]; atomicAdd(A.dbeta + tid, t); }
 }
 
 template <bool VEC>
@@ -662,7 +670,8 @@ int msgm_groupnorm_dual_backward(const float* x, const float* gamma, const float
   GnArgs A{x, gamma, beta, nullptr, reinterpret_cast<double*>(workspace), const_cast<float*>(stats), P, C, G, Bp, 1, silu, 0,
            eps, gout, gx, dgamma, dbeta};
   const int nch = gn_chunks(Bp, P, &A.chunk);
-  hipLaunchKernelGGL(k_gn_bwd_reduce, dim3(Bp, nch), dim3(256), 0, S(stream), A);
+  if (C % 4 == 0) hipLaunchKernelGGL(k_gn_bwd_reduce<true>, dim3(Bp, nch), dim3(256), 0, S(stream), A);
+  else hipLaunchKernelGGL(k_gn_bwd_reduce<false>, dim3(Bp, nch), dim3(256), 0, S(stream), A);
   if (C % 4 == 0) hipLaunchKernelGGL(k_gn_bwd_apply<true>, dim3(nch, Bp), dim3(256), 0, S(stream), A);
   else hipLaunchKernelGGL(k_gn_bwd_apply<false>, dim3(nch, Bp), dim3(256), 0, S(stream), A);
   if (hipMemsetAsync(workspace, 0, gn_acc_bytes(Bp, G), S(stream)) != hipSuccess) return MSGM_E_LAUNCH;   // zero on exit

@@ -283,14 +283,17 @@ def conv_forward(geom: L.ConvGeomT, src0: torch.Tensor, C0: int, Wp: torch.Tenso
 
 
 def conv_wgrad(geom: L.ConvGeomT, gy: torch.Tensor, src: torch.Tensor, C: int, koff: int, dWp: torch.Tensor, Cout: int,
-               CoutP: int, Ktot: int):
+               CoutP: int, Ktot: int, dbias: Optional[torch.Tensor] = None, n_bias: int = 0):
+    """dbias (Cout floats, ACCUMULATED into): bias gradient over the primal rows n < n_bias, as a by-product."""
     taps = geom.KH * geom.KW
+    if dbias is not None and (dbias.numel() != Cout or n_bias <= 0 or n_bias > geom.N):
+        raise MsgmError("wgrad: bad bias-gradient arguments")
     if gy.numel() != geom.N * geom.Ho * geom.Wo * Cout or src.numel() != geom.N * geom.Hi * geom.Wi * C:
         raise MsgmError("wgrad operands do not match the geometry")
     if dWp.numel() < taps * CoutP * Ktot:
         raise MsgmError("packed gradient too small")
-    check(lib().msgm_conv_wgrad(geom, ptr(f32(gy)), ptr(f32(src)), C, koff, ptr(f32(dWp)), Cout, CoutP, Ktot, stream()),
-          "msgm_conv_wgrad")
+    check(lib().msgm_conv_wgrad(geom, ptr(f32(gy)), ptr(f32(src)), C, koff, ptr(f32(dWp)), Cout, CoutP, Ktot,
+                                ptr(dbias), int(n_bias), stream()), "msgm_conv_wgrad")
 
 
 def pack_weight(W: torch.Tensor, w_off: int, Wp: torch.Tensor, rows, ncols, col_off, taps, sr, sc, st, rowsP, Ktot, kp_off):
