@@ -266,6 +266,7 @@ __global__ void __launch_bounds__(256) k_conv_tile(ConvArgs A, int flip, int til
   f32x4 st[MAXST];
   const int n_items = halo * (CT_KC / 4);
   const int padH = g.padH, padW = g.padW;
+  const int up = g.ups ? 1 : 0;          // Upsample folded into the gather (model/unet.py:60-73)
   auto tile_origin = [&](int t, int& n, int& y0, int& x0) {
     const int tx_i = t % tiles_x; t /= tiles_x;
     const int ty_i = t % tiles_y;
@@ -283,10 +284,10 @@ __global__ void __launch_bounds__(256) k_conv_tile(ConvArgs A, int flip, int til
       if (idx < n_items) {
         const int hp = idx >> 3, c4 = idx & 7;
         const int hy = hp / HW, hx = hp - hy * HW;
-        const int iy = y0 + hy - padH, ix = x0 + hx - padW;
+        const int iy = y0 + hy - padH, ix = x0 + hx - padW;     // on the (2x nearest-upsampled, if ups) input grid
         const int c = c0 + 4 * c4;
-        if (iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi && c < C)
-          v = *reinterpret_cast<const f32x4*>(base + ((size_t)iy * g.Wi + ix) * C + c);
+        if (iy >= 0 && iy < (g.Hi << up) && ix >= 0 && ix < (g.Wi << up) && c < C)
+          v = *reinterpret_cast<const f32x4*>(base + ((size_t)(iy >> up) * g.Wi + (ix >> up)) * C + c);
       }
       st[k] = v;
     }
@@ -322,20 +323,36 @@ __global__ void __launch_bounds__(256) k_conv_tile(ConvArgs A, int flip, int til
     const int ngrp = (C - c0 >= CT_KC) ? 2 : ((C - c0 + 15) >> 4);
     const float* wbase = A.Wp + (size_t)(co0 + il) * A.Ktot + A.koff[cs] + c0 + 4 * q;
     const int npairs = taps * ngrp;
-    f32x4 an[NCO];
+    // weight fragments are fetched WD (tap, group) pairs ahead (one pair = 8*NCO MFMAs = 256*NCO cycles of matrix
+    // pipe).  WD = 2 for the narrow variant measured no gain (3-4 resident waves per SIMD already cover the L2 hit).
+    constexpr int WD = 1;
+    f32x4 an[WD][NCO];
+    int ftap = 0, fgrp = 0;                // next pair to fetch
 #pragma unroll
-    for (int c = 0; c < NCO; ++c) an[c] = *reinterpret_cast<const f32x4*>(wbase + c * a_co_stride);   // tap 0, group 0
+    for (int d = 0; d < WD; ++d) {
+      if (d < npairs) {
+        const float* wp = wbase + (size_t)ftap * A.CoutP * A.Ktot + 16 * fgrp;
+#pragma unroll
+        for (int c = 0; c < NCO; ++c) an[d][c] = *reinterpret_cast<const f32x4*>(wp + c * a_co_stride);
+        if (++fgrp == ngrp) { fgrp = 0; ++ftap; }
+      }
+    }
     int tap = 0, grp = 0;
     for (int pr = 0; pr < npairs; ++pr) {
       f32x4 a[NCO];
 #pragma unroll
-      for (int c = 0; c < NCO; ++c) a[c] = an[c];
+      for (int c = 0; c < NCO; ++c) a[c] = an[0][c];
+#pragma unroll
+      for (int d = 0; d + 1 < WD; ++d)
+#pragma unroll
+        for (int c = 0; c < NCO; ++c) an[d][c] = an[d + 1][c];
       int ntap = tap, ngr = grp + 1;
       if (ngr == ngrp) { ngr = 0; ++ntap; }
-      if (pr + 1 < npairs) {
-        const float* wp = wbase + (size_t)ntap * A.CoutP * A.Ktot + 16 * ngr;
+      if (pr + WD < npairs) {
+        const float* wp = wbase + (size_t)ftap * A.CoutP * A.Ktot + 16 * fgrp;
 #pragma unroll
-        for (int c = 0; c < NCO; ++c) an[c] = *reinterpret_cast<const f32x4*>(wp + c * a_co_stride);
+        for (int c = 0; c < NCO; ++c) an[WD - 1][c] = *reinterpret_cast<const f32x4*>(wp + c * a_co_stride);
+        if (++fgrp == ngrp) { fgrp = 0; ++ftap; }
       }
       const int kh = tap / KW, kw = tap - kh * KW;
       const int oy = flip ? (KH - 1 - kh) : kh, ox = flip ? (KW - 1 - kw) : kw;
@@ -524,6 +541,7 @@ __global__ void __launch_bounds__(256) k_wgrad_tile(WgradArgs A, int tiles_x, in
 
   constexpr int MAXIN = ((TH == 1 ? 1 : TH + 2) * (TW + 2) * 8 + 255) / 256;   // 1-D convolutions have no vertical halo
   f32x4 sg[4], si[MAXIN];
+  const int up = g.ups ? 1 : 0;          // input nearest-upsampled 2x on the fly (folded Upsample)
   const int n_in = halo * 8;
   auto stage_load = [&](int tile) {
     int bx = tile;
@@ -549,9 +567,9 @@ __global__ void __launch_bounds__(256) k_wgrad_tile(WgradArgs A, int tiles_x, in
       if (idx < n_in) {
         const int hp = idx >> 3, c4 = idx & 7;
         const int hy = hp / HW, hx = hp - hy * HW;
-        const int iy = y0 + hy - g.padH, ix = x0 + hx - g.padW, c = c0 + 4 * c4;
-        if (iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi && c < A.C)
-          v = *reinterpret_cast<const f32x4*>(A.src + (((size_t)n * g.Hi + iy) * g.Wi + ix) * A.C + c);
+        const int iy = y0 + hy - g.padH, ix = x0 + hx - g.padW, c = c0 + 4 * c4;   // on the 2x grid if ups
+        if (iy >= 0 && iy < (g.Hi << up) && ix >= 0 && ix < (g.Wi << up) && c < A.C)
+          v = *reinterpret_cast<const f32x4*>(A.src + (((size_t)n * g.Hi + (iy >> up)) * g.Wi + (ix >> up)) * A.C + c);
       }
       si[k] = v;
     }
@@ -825,7 +843,9 @@ int msgm_conv_forward(const msgm_conv_geom_t* geom, const float* src0, int32_t C
   const int64_t Mtot = (int64_t)geom->N * geom->Ho * geom->Wo;
   const bool fast = (C0 % 16 == 0) && (!src1 || C1 % 16 == 0);
   // stride-1 "same" convolution (or its dgrad) on a big enough image: halo-tile kernel
-  const bool same = geom->strideH == 1 && geom->strideW == 1 && !geom->ups && geom->Hi == geom->Ho && geom->Wi == geom->Wo &&
+  const int ups_sh = geom->ups ? 1 : 0;
+  const bool same = geom->strideH == 1 && geom->strideW == 1 && (!geom->ups || geom->mode == 0) &&
+                    (geom->Hi << ups_sh) == geom->Ho && (geom->Wi << ups_sh) == geom->Wo &&
                     (geom->KH & 1) && (geom->KW & 1) && geom->padH == (geom->KH - 1) / 2 && geom->padW == (geom->KW - 1) / 2 &&
                     geom->KH <= 3 && geom->KW <= 3;
   if (same && fast && CoutP % 32 == 0 && (int64_t)geom->Ho * geom->Wo >= 64 && (geom->Ho > 1 || geom->KH == 1) &&
@@ -879,8 +899,9 @@ int msgm_conv_wgrad(const msgm_conv_geom_t* geom, const float* gy, const float* 
   WgradArgs A{to_geom(geom), gy, src, C, koff, dWp, Cout, CoutP, Ktot, 0, dbias, n_bias};
   const int64_t Mtot = (int64_t)geom->N * geom->Ho * geom->Wo;
   const int taps = geom->KH * geom->KW;
-  const bool same = geom->mode == 0 && geom->strideH == 1 && geom->strideW == 1 && !geom->ups && geom->Hi == geom->Ho &&
-                    geom->Wi == geom->Wo && (geom->KH & 1) && (geom->KW & 1) && geom->padH == (geom->KH - 1) / 2 &&
+  const int ups_sh = geom->ups ? 1 : 0;
+  const bool same = geom->mode == 0 && geom->strideH == 1 && geom->strideW == 1 && (geom->Hi << ups_sh) == geom->Ho &&
+                    (geom->Wi << ups_sh) == geom->Wo && (geom->KH & 1) && (geom->KW & 1) && geom->padH == (geom->KH - 1) / 2 &&
                     geom->padW == (geom->KW - 1) / 2 && geom->KH <= 3 && geom->KW <= 3;
   if (same && C % 4 == 0 && Cout % 4 == 0 && (int64_t)geom->Ho * geom->Wo >= 64 && (taps == 1 || taps == 3 || (taps == 9 && geom->Ho > 1)) &&
       (geom->Ho > 1 || geom->KH == 1) && !getenv("MSGM_NO_WGRAD_TILE")) {
