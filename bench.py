@@ -321,7 +321,7 @@ def main():
                "config": {"workload": "C2: 2-D Gaussian mixture, MLP score net (d=2, hidden 128), SGM, batch 65536/GPU, "
                                       "SSM loss + Adam", "global_batch": B_C2 * world, "parallelism": f"dp{world}",
                           "graph": world == 1},
-               "sample_steps_per_s": sample_steps_per_s, "sample_config": f"EM, {a.sample_steps} steps, 65536 rows/GPU, hipGraph",
+               "sample_steps_per_s": sample_steps_per_s, "sample_config": f"EM, {a.sample_steps} steps, 65536 rows/GPU, whole loop = one launch (msgm_mlp_em_loop) replayed as a hipGraph",
                "final_loss": loss_end, "sampler_finite": finite, "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out))
 

@@ -216,6 +216,14 @@ int msgm_mlp_em_step(const msgm_mlp_params_t* P, float* x, int64_t B, const msgm
                      float t, float delta, float lmbd, const float* z, const uint64_t* rng,
                      uint64_t rng_step, msgm_stream_t stream);
 
+/* The WHOLE Euler-Maruyama loop of euler_maruyama_sampler (sde_scheme.py:43-99, keep_all_samples=False, SGM,
+ * no norm correction) in ONE launch: step i uses t = ts[i] (device array of n_steps+1 values,
+ * linspace(0,1,N+1)*T as upstream computes it, sde_scheme.py:59) and Philox step rng_step0 + i, i.e. exactly the
+ * numbers n_steps successive msgm_mlp_em_step calls draw.  Rows never interact, so each workgroup takes its rows
+ * through all steps; the small layers are staged once.  Needs B > 32 (MSGM_E_UNSUPPORTED otherwise). */
+int msgm_mlp_em_loop(const msgm_mlp_params_t* P, float* x, int64_t B, const msgm_sde_t* sde, const float* ts, int32_t n_steps,
+                     float delta, float lmbd, const uint64_t* rng, uint64_t rng_step0, msgm_stream_t stream);
+
 /* Fused SSM training pass for SGM + MLP (replaces SDEs.py:607-646 +
  * loss.mean().backward(), MSGM_higherDim.py:807-808):
  *   per sample: a = MLP(y,t), adot = J_a v (forward-mode), loss_b =

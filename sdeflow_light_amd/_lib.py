@@ -97,6 +97,7 @@ SIGNATURES = {
     "msgm_sum2x2": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P]),
     "msgm_mlp_forward": (C.c_int, [C.POINTER(MlpParamsT), _P, _P, _P, _I64, _P]),
     "msgm_mlp_em_step": (C.c_int, [C.POINTER(MlpParamsT), _P, _I64, C.POINTER(SdeT), _F, _F, _F, _P, _P, _U64, _P]),
+    "msgm_mlp_em_loop": (C.c_int, [C.POINTER(MlpParamsT), _P, _I64, C.POINTER(SdeT), _P, _I32, _F, _F, _P, _U64, _P]),
     "msgm_mlp_ssm_workspace": (_SZ, [_I32, _I32]),
     "msgm_mlp_num_params": (_I64, [_I32, _I32]),
     "msgm_mlp_ssm_partial": (C.c_int, [C.POINTER(MlpParamsT), _P, _P, _P, _P, _P, _I64, C.POINTER(SdeT), _F, _P, _P, _SZ,

@@ -105,6 +105,7 @@ struct MlpArgs {
   // EM step
   float delta, sqrt_delta, lmbd;
   const float* z; const uint64_t* rng; uint64_t rng_step;
+  int n_steps; const float* ts;   // EM loop: n_steps > 1 steps in ONE launch, time of step i = ts[i] (device array)
   // train
   float inv_batch;
   float* loss_per; float* slabs;   // slabs: [gridDim.x][n_params + 1] (last = loss sum)
@@ -351,23 +352,6 @@ __global__ void __launch_bounds__(64 * NW, 1) k_mlp(MlpArgs A) {
   float* B1s = lds + LO::B1; float* B2s = lds + LO::B2; float* B3s = lds + LO::B3; float* B4s = lds + LO::B4;
   float* DB4 = lds + LO::DB4; float* RED = lds + LO::RED;
 
-  // ---- one-time staging of the small layers and biases -------------------
-  for (int i = tid; i < HID * SM_P; i += NT) {
-    int r = i / SM_P, c = i - r * SM_P;
-    W1s[i] = (c < A.in_dim) ? A.P.W1[r * A.in_dim + c] : 0.f;
-  }
-  for (int i = tid; i < DPAD * ACT_P; i += NT) {
-    int r = i / ACT_P, c = i - r * ACT_P;
-    W4s[i] = (r < d && c < HID) ? A.P.W4[r * HID + c] : 0.f;
-  }
-  for (int i = tid; i < HID; i += NT) { B1s[i] = A.P.b1[i]; B2s[i] = A.P.b2[i]; B3s[i] = A.P.b3[i]; }
-  if (tid < 32) B4s[tid] = tid < d ? A.P.b4[tid] : 0.f;
-  if (MODE == MODE_TRAIN) {
-    for (int i = tid; i < 16 * DPAD; i += NT) DB4[i] = 0.f;
-    for (int i = tid; i < 32 * SM_P; i += NT) ABAR[i] = 0.f;
-  }
-  for (int i = tid; i < 2 * 32 * SM_P; i += NT) H0[i] = 0.f;
-
   // persistent accumulators (train)
   f32x4 dW2[IT][8], dW3[IT][8], dW1[IT][KT1], dW4[IT][OT], db1[IT], db2[IT], db3[IT];
   float loss_acc = 0.f;
@@ -391,14 +375,16 @@ __global__ void __launch_bounds__(64 * NW, 1) k_mlp(MlpArgs A) {
   float* RAW0 = lds + LO::RAW;
   float pf_y[NR], pf_v[NR], pf_u[NR], pf_t = 0.f, pf_c = 0.f;
   const int64_t etot = A.B * d;
-  auto raw_issue = [&](int64_t tl) {
+  auto raw_issue = [&](int64_t tl, int step = 0) {
     const int64_t e0 = tl * SPT * d;                 // tl past the last tile => e0 >= etot => zeros
     const int cnt = SPT * d;
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
       const int e = tid + NT * k;
       const bool ok = e < cnt && e0 + e < etot;
-      pf_y[k] = ok ? A.y[e0 + e] : 0.f;
+      // EM loop: x was rewritten by THIS workgroup a sweep ago — device-scope load so no stale L1 line is served
+      if (MODE == MODE_EM) pf_y[k] = ok ? __hip_atomic_load(A.y + e0 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+      else pf_y[k] = ok ? A.y[e0 + e] : 0.f;
       if (MODE == MODE_TRAIN) {
         pf_v[k] = ok ? A.v[e0 + e] : 0.f;
         pf_u[k] = (ok && A.u) ? A.u[e0 + e] : 0.f;
@@ -406,7 +392,7 @@ __global__ void __launch_bounds__(64 * NW, 1) k_mlp(MlpArgs A) {
     }
     if (tid < SPT) {
       const int64_t smp = tl * SPT + tid;
-      pf_t = smp < A.B ? (A.t ? A.t[smp] : A.t_scalar) : 0.f;
+      pf_t = smp < A.B ? (A.t ? A.t[smp] : ((MODE == MODE_EM && A.ts) ? A.ts[step] : A.t_scalar)) : 0.f;
       if (MODE == MODE_TRAIN) pf_c = (smp < A.B && A.u && A.cst) ? A.cst[smp] : 0.f;
     }
   };
@@ -464,10 +450,41 @@ __global__ void __launch_bounds__(64 * NW, 1) k_mlp(MlpArgs A) {
     }
   };
 
+  // ---- prologue.  The first tile's inputs and the first weight fragments go out first; the one-time staging of
+  // the small layers and biases is written as fixed-trip loops with all global loads ahead of the LDS stores, so its
+  // latency is ONE L2 round trip, not one per element (at the C2 sampler size a workgroup only has 4 tiles to
+  // amortise this over).
+  raw_issue(blockIdx.x);
   const wrsrc_t R2 = make_wrsrc(A.P.W2), R3 = make_wrsrc(A.P.W3);
   WPre pre;
   prefetch_w<false>(R2, fb, il, q, pre);
-  raw_issue(blockIdx.x);
+  {
+    constexpr int N1 = (HID * SM_P + NT - 1) / NT, N4 = (DPAD * ACT_P + NT - 1) / NT;
+    float v1[N1], v4[N4], vb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < N1; ++k) {
+      const int i = tid + NT * k, r = i / SM_P, c = i - r * SM_P;
+      v1[k] = (i < HID * SM_P && c < A.in_dim) ? A.P.W1[r * A.in_dim + c] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < N4; ++k) {
+      const int i = tid + NT * k, r = i / ACT_P, c = i - r * ACT_P;
+      v4[k] = (i < DPAD * ACT_P && r < d && c < HID) ? A.P.W4[r * HID + c] : 0.f;
+    }
+    if (tid < HID) { vb[0] = A.P.b1[tid]; vb[1] = A.P.b2[tid]; vb[2] = A.P.b3[tid]; }
+    if (tid < d) vb[3] = A.P.b4[tid];
+#pragma unroll
+    for (int k = 0; k < N1; ++k) { const int i = tid + NT * k; if (i < HID * SM_P) W1s[i] = v1[k]; }
+#pragma unroll
+    for (int k = 0; k < N4; ++k) { const int i = tid + NT * k; if (i < DPAD * ACT_P) W4s[i] = v4[k]; }
+    if (tid < HID) { B1s[tid] = vb[0]; B2s[tid] = vb[1]; B3s[tid] = vb[2]; }
+    if (tid < 32) B4s[tid] = vb[3];
+    if (MODE == MODE_TRAIN) {
+      for (int i = tid; i < 16 * DPAD; i += NT) DB4[i] = 0.f;
+      for (int i = tid; i < 32 * SM_P; i += NT) ABAR[i] = 0.f;
+    }
+    for (int i = tid; i < 2 * 32 * SM_P; i += NT) H0[i] = 0.f;
+  }
   raw_commit(RAW0);
   __syncthreads();
   if (tid < SPT) build_h0(H0, RAW0, blockIdx.x, tid);
@@ -503,8 +520,17 @@ __global__ void __launch_bounds__(64 * NW, 1) k_mlp(MlpArgs A) {
   const float ca = 1.0f - 0.5f * A.lmbd;
   int cur = 0;      // parity of the tile: selects the h0 / raw buffers and which of X / Y holds h1
 
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  // Work items are (step, tile) with the tile index fastest; training / forward / single-step EM have one step.
+  // EM loop (n_steps > 1): rows never interact (sde_scheme.py:82-86), so a workgroup takes its tiles through ALL
+  // steps in one launch — weights and biases are staged once, x only travels to L2 and back.  The host guarantees
+  // >= 2 tiles per workgroup, so the item prefetched one ahead is always a tile whose previous step is complete.
+  const int n_steps = (MODE == MODE_EM && A.n_steps > 1) ? A.n_steps : 1;
+  int step = 0;
+  for (int64_t tile = blockIdx.x; tile < n_tiles;) {
     const int64_t s_base = tile * SPT;
+    int64_t ntile = tile + gridDim.x;           // the next item
+    int nstep = step;
+    if (ntile >= n_tiles) { ++nstep; ntile = nstep < n_steps ? (int64_t)blockIdx.x : n_tiles; }
     const float* H0c = H0 + cur * 32 * SM_P;
     float* H0n = H0 + (cur ^ 1) * 32 * SM_P;
     const float* Rc = RAW0 + cur * LO::RAWN;
@@ -517,7 +543,7 @@ __global__ void __launch_bounds__(64 * NW, 1) k_mlp(MlpArgs A) {
     // ---- phase 2: layer 2 --------------------------------------------------
 #pragma unroll
     for (int it = 0; it < IT; ++it) { z2[it][0] = f32x4{0, 0, 0, 0}; z2[it][1] = f32x4{0, 0, 0, 0}; }
-    if (MODE != MODE_TRAIN) raw_issue(tile + gridDim.x);
+    if (MODE != MODE_TRAIN) raw_issue(ntile, nstep);
     gemm128<false, (TRN ? 1 : 2), IT>(R2, pre, Xc, fb, il, q, z2, B2s, h);
     prefetch_w<false>(R3, fb, il, q, pre);         // head of the next gemm's weights
     bias_swish<TRN, IT>(z2, h, B2s, fb, q, GemmTail<IT>::FIRST);
@@ -529,8 +555,8 @@ __global__ void __launch_bounds__(64 * NW, 1) k_mlp(MlpArgs A) {
     // ---- phase 3: layer 3, then this wave's K-slice of layer 4 -------------
 #pragma unroll
     for (int it = 0; it < IT; ++it) { z3[it][0] = f32x4{0, 0, 0, 0}; z3[it][1] = f32x4{0, 0, 0, 0}; }
-    if (MODE != MODE_TRAIN) { if (tid < SPT) build_h0(H0n, Rn, tile + gridDim.x, tid); }   // next tile's layer-1 operand
-    else raw_issue(tile + gridDim.x);                        // train: next tile's inputs, in flight during the gemm
+    if (MODE != MODE_TRAIN) { if (tid < SPT) build_h0(H0n, Rn, ntile, tid); }   // next item's layer-1 operand
+    else raw_issue(ntile);                                   // train: next tile's inputs, in flight during the gemm
     gemm128<false, (TRN ? 1 : 2), IT>(R3, pre, Yc, fb, il, q, z3, B3s, h);
     if (MODE == MODE_TRAIN) prefetch_w<true>(R3, fb, il, q, pre);  // W3^T for dgrad
     else prefetch_w<false>(R2, fb, il, q, pre);                    // next tile's layer 2
@@ -575,17 +601,19 @@ __global__ void __launch_bounds__(64 * NW, 1) k_mlp(MlpArgs A) {
           } else {
             // x += [(1-l/2) sqrt(beta) a + 1/2 beta x] delta + sqrt(1-l) sqrt(beta) dW
             // (SDEs.py:556-561,587-588; sde_scheme.py:82-84,38-40)
-            const float s = A.T - A.t_scalar;
+            const float s = A.T - Rc[LO::RT + c];               // this item's time (ts[step] in the EM loop)
             const float beta = sde_beta(A.b0, A.b1, s);
             const float sb = sqrtf(beta);
             const float x = Rc[LO::RY + idx];
-            const float zz = A.z ? A.z[e] : philox_normal1(A.rng, A.rng_step, RNG_STREAM_DW, (uint64_t)e);
+            const float zz = A.z ? A.z[e] : philox_normal1(A.rng, A.rng_step + (uint64_t)step, RNG_STREAM_DW, (uint64_t)e);
             const float mu = ca * (sb * a) - (-0.5f * beta * x);
             A.out[e] = x + (mu * A.delta + (sqrtf(1.0f - A.lmbd) * sb) * (A.sqrt_delta * zz));
           }
         }
       }
-      lds_barrier();   // PART / H0 are rewritten by the next tile
+      if (n_steps > 1) __syncthreads();   // + vmcnt(0): this tile's new x must have left the CU before it is re-read
+      else lds_barrier();                 // PART / H0 are rewritten by the next tile
+      tile = ntile; step = nstep;
       continue;
     }
 
@@ -632,7 +660,7 @@ __global__ void __launch_bounds__(64 * NW, 1) k_mlp(MlpArgs A) {
         }
       }
       // next tile's layer-1 operand, by a wave that has no part in the loss when there are eight
-      if (tid >= NT - 64 && tid < NT - 64 + 16) build_h0(H0n, Rn, tile + gridDim.x, tid - (NT - 64));
+      if (tid >= NT - 64 && tid < NT - 64 + 16) build_h0(H0n, Rn, ntile, tid - (NT - 64));
       lds_barrier();
       STAMP(4);
 
@@ -684,6 +712,7 @@ __global__ void __launch_bounds__(64 * NW, 1) k_mlp(MlpArgs A) {
       lds_barrier();     // ABAR/PART/.. are rewritten by the next tile
       STAMP(8);
     }
+    tile = ntile; step = nstep;
   }
 
   // ---- epilogue (train): write this workgroup's gradient slab -------------
@@ -877,6 +906,25 @@ int msgm_mlp_em_step(const msgm_mlp_params_t* P, float* x, int64_t B, const msgm
   const int64_t tiles = (B + 31) / 32;
   const int64_t cap = 2 * MLP_MAX_GRID;
   return launch_mlp<MODE_EM>(A, (int)(tiles < cap ? tiles : cap), S(stream));
+}
+
+int msgm_mlp_em_loop(const msgm_mlp_params_t* P, float* x, int64_t B, const msgm_sde_t* sde, const float* ts, int32_t n_steps,
+                     float delta, float lmbd, const uint64_t* rng, uint64_t rng_step0, msgm_stream_t stream) {
+  MlpArgs A{};
+  int rc = fill_common(A, P, B);
+  if (rc) return rc;
+  if (!x || !sde || !ts || !rng || n_steps < 1) return MSGM_E_BADARG;
+  if (sde->kind != MSGM_SDE_SGM) return MSGM_E_UNSUPPORTED;
+  const int64_t tiles = (B + 31) / 32;
+  if (tiles < 2) return MSGM_E_UNSUPPORTED;              // a workgroup needs two tiles to prefetch one ahead
+  A.y = x; A.out = x; A.t = nullptr; A.t_scalar = 0.f;
+  A.b0 = sde->beta_min; A.b1 = sde->beta_max; A.T = sde->T;
+  A.delta = delta; A.sqrt_delta = (float)sqrt((double)delta); A.lmbd = lmbd;
+  A.z = nullptr; A.rng = rng; A.rng_step = rng_step0;
+  A.n_steps = n_steps; A.ts = ts;
+  const int64_t cap = 2 * MLP_MAX_GRID;
+  const int64_t grid = tiles / 2 < cap ? tiles / 2 : cap;
+  return launch_mlp<MODE_EM>(A, (int)grid, S(stream));
 }
 
 int msgm_mlp_ssm_partial(const msgm_mlp_params_t* P, const float* y, const float* t, const float* v, const float* u,

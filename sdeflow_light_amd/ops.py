@@ -197,6 +197,19 @@ def mlp_em_step(P: L.MlpParamsT, x: torch.Tensor, sde: L.SdeT, t: float, delta: 
     return x
 
 
+def mlp_em_loop(P: L.MlpParamsT, x: torch.Tensor, sde: L.SdeT, ts: torch.Tensor, delta: float, lmbd: float,
+                rng: PhiloxState, rng_step0: int = 0):
+    """All len(ts)-1 Euler-Maruyama steps in ONE launch (final state only); ts = device fp32 time grid."""
+    B, d = x.shape
+    if d != P.d:
+        raise MsgmError(f"state has d={d}, the MLP was built for d={P.d}")
+    if ts.device != x.device or ts.dtype != torch.float32 or ts.numel() < 2:
+        raise MsgmError("em loop: ts must be a device fp32 grid of N+1 values")
+    check(lib().msgm_mlp_em_loop(P, ptr(f32(x)), B, sde, ptr(ts), ts.numel() - 1, float(delta), float(lmbd), _rng_ptr(rng),
+                                 int(rng_step0), stream()), "msgm_mlp_em_loop")
+    return x
+
+
 def mlp_ssm_workspace(d: int, premodule: bool, device) -> torch.Tensor:
     nbytes = int(lib().msgm_mlp_ssm_workspace(d, int(bool(premodule))))
     return torch.empty(nbytes // 4, dtype=torch.float32, device=device)

@@ -15,6 +15,8 @@ Extra keyword ``noise=`` (steps,B,n) injects the standard-normal draws
 """
 from __future__ import annotations
 
+import os
+
 from typing import Optional
 
 import torch
@@ -245,11 +247,18 @@ class GraphedEMSampler:
         st = base.struct()
         ts = torch.linspace(0, 1, num_steps + 1) * self.T_
         delta = self.T_ / num_steps
+        self.ts_dev = ts.to(dev)
         self._keep = (P, st)
+        # B > 32: the whole loop is ONE launch (msgm_mlp_em_loop — rows never interact, so a workgroup carries its rows
+        # through all steps); otherwise N single-step kernel nodes.  Same Philox numbers either way.
+        self.one_launch = B > 32 and not os.environ.get("MSGM_EM_PER_STEP")
 
         def body():
-            for i in range(num_steps):
-                ops.mlp_em_step(P, self.x, st, ts[i].item(), delta, lmbd, rng=self.rng, rng_step=i)
+            if self.one_launch:
+                ops.mlp_em_loop(P, self.x, st, self.ts_dev, delta, lmbd, self.rng, 0)
+            else:
+                for i in range(num_steps):
+                    ops.mlp_em_step(P, self.x, st, ts[i].item(), delta, lmbd, rng=self.rng, rng_step=i)
             self.rng.advance(num_steps)
 
         s = torch.cuda.Stream(device=dev)

@@ -210,6 +210,37 @@ def test_graphed_sampler_equals_eager():
     assert not torch.equal(a, c) and torch.isfinite(c).all()
 
 
+@pytest.mark.parametrize("B,d,pre,N", [(65, 2, None, 7), (1000, 2, None, 12), (4100, 6, "NormalizeLogRadius", 5),
+                                      (300, 20, None, 4), (32, 2, None, 3), (70000, 2, None, 3)])
+def test_em_loop_one_launch_equals_per_step_kernels(B, d, pre, N):
+    """msgm_mlp_em_loop (all N steps in one launch, each workgroup carrying its rows through every step) must give
+    the numbers of N successive msgm_mlp_em_step launches: same time grid, same Philox draws.  Ragged B, several
+    tiles per workgroup, wide and premodule variants; B <= 32 is refused and the sampler falls back."""
+    from sdeflow_light_amd.NN import MLP
+    from sdeflow_light_amd import ops
+    from sdeflow_light_amd._lib import MsgmError
+    torch.manual_seed(B + d)
+    gen = make_gen("sgm", MLP(d, premodule=pre))
+    base = gen.base_sde
+    P, st = gen.a.kernel_params(), base.struct()
+    T = base.T_float()
+    ts = torch.linspace(0, 1, N + 1) * T
+    delta = T / N
+    x0 = torch.randn(B, d, device=DEV)
+    rng = base.philox(DEV)
+    ref = x0.clone()
+    for i in range(N):
+        ops.mlp_em_step(P, ref, st, ts[i].item(), delta, 0.0, rng=rng, rng_step=i)
+    one = x0.clone()
+    if B <= 32:
+        with pytest.raises(MsgmError):
+            ops.mlp_em_loop(P, one, st, ts.to(DEV), delta, 0.0, rng, 0)
+        return
+    ops.mlp_em_loop(P, one, st, ts.to(DEV), delta, 0.0, rng, 0)
+    assert torch.isfinite(one).all()
+    assert rel_l2(one.cpu(), ref.cpu()) <= 1e-6
+
+
 def test_trainer_fused_launches_match_separate_kernels():
     """prep (K1+probe+tick) and reduce+Adam fused launches == the separate C-ABI kernels, two steps, ragged batch."""
     from sdeflow_light_amd.NN import MLP
