@@ -51,6 +51,9 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// row pitch of a gradient slab: n_params + 1 (loss) rounded up to 4 floats, so the reduction reads 16-B vectors
+__host__ __device__ static inline int64_t slab_stride(int64_t n_params) { return (n_params + 1 + 3) & ~(int64_t)3; }
+
 // ---- LDS carve (floats), per (mode, width) ------------------------------------
 // NARROW nets (in_dim <= 16 and d <= 16) use 20-float small rows and 16 padded outputs; the forward / sampler
 // modes drop the backward-only buffers — 67 KB instead of 134 KB, so TWO workgroups share a CU there and each
@@ -108,7 +111,7 @@ struct MlpArgs {
   int n_steps; const float* ts;   // EM loop: n_steps > 1 steps in ONE launch, time of step i = ts[i] (device array)
   // train
   float inv_batch;
-  float* loss_per; float* slabs;   // slabs: [gridDim.x][n_params + 1] (last = loss sum)
+  float* loss_per; float* slabs;   // slabs: [gridDim.x][slab_stride], element n_params = loss sum; stride = 4-aligned
   int64_t n_params;
 };
 
@@ -718,7 +721,7 @@ __global__ void __launch_bounds__(64 * NW, 1) k_mlp(MlpArgs A) {
   // ---- epilogue (train): write this workgroup's gradient slab -------------
   if (MODE == MODE_TRAIN) {
     STAMP(9);
-    float* slab = A.slabs + (int64_t)blockIdx.x * (A.n_params + 1);
+    float* slab = A.slabs + (int64_t)blockIdx.x * slab_stride(A.n_params);
     const int in_dim = A.in_dim;
     const int64_t oW1 = 0, ob1 = oW1 + (int64_t)HID * in_dim, oW2 = ob1 + HID, ob2 = oW2 + HID * HID,
                   oW3 = ob2 + HID, ob3 = oW3 + HID * HID, oW4 = ob3 + HID, ob4 = oW4 + (int64_t)d * HID;
@@ -784,9 +787,8 @@ __global__ void __launch_bounds__(64 * NW, 1) k_mlp(MlpArgs A) {
 }
 
 // grads[p] = sum_wg slab[wg][p]; element n_params = loss sum (x inv_batch -> mean).
-// 64 parameters x 4 slab-groups per block: each thread sums a quarter of the slabs
-// (coalesced along p), the four partials meet in LDS — deterministic order.
-// ADAM: the same thread then applies the fused Adam update to its parameter
+// 64 parameters (16 quads) x 16 slab groups per block, 16-B loads, fixed summation order (see the kernel).
+// ADAM: one thread per parameter then applies the fused Adam update
 // (single-GPU step: no all-reduce sits between the two), and thread 0 advances the
 // Philox offset (nothing after this kernel reads it within the step).
 template <bool ADAM>
@@ -796,29 +798,37 @@ __global__ void __launch_bounds__(256) k_slab_reduce(const float* __restrict__ s
                                                      float* __restrict__ prm, float* __restrict__ m, float* __restrict__ v,
                                                      double lr, double b1, double b2, double eps,
                                                      const int64_t* __restrict__ step_dev, uint64_t* rng_advance) {
-  __shared__ float part[4][64];
-  const int px = threadIdx.x & 63, gy = threadIdx.x >> 6;
-  const int64_t p = (int64_t)blockIdx.x * 64 + px;
-  float s = 0.f;
-  if (p <= n_params)
-    for (int g = gy; g < n_slabs; g += 4) s += slabs[(int64_t)g * stride + p];
-  part[gy][px] = s;
+  // 64 parameters per block = 16 quads x 16 slab groups: thread (quad, group) sums every 16th slab with 16-B loads
+  // (16 independent loads in flight), the 16 partial quads meet in LDS in a fixed order — deterministic.
+  __shared__ f32x4 part[16][16];
+  const int q4 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int64_t p0 = (int64_t)blockIdx.x * 64 + 4 * q4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (p0 <= n_params)
+    for (int g = grp; g < n_slabs; g += 16) acc += *reinterpret_cast<const f32x4*>(slabs + (int64_t)g * stride + p0);
+  part[grp][q4] = acc;
   __syncthreads();
-  if (gy == 0 && p <= n_params) {
-    s = (part[0][px] + part[1][px]) + (part[2][px] + part[3][px]);
-    if (p < n_params) {
-      if (grads) grads[p] = s;
-      if (ADAM) {
-        const int64_t st = step_dev[0];
-        const double bc1 = 1.0 - pow(b1, (double)st), bc2 = 1.0 - pow(b2, (double)st);
-        const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
-        const float w1 = (float)(1.0 - b1), b2f = (float)b2, w2 = (float)(1.0 - b2);
-        const float mm = m[p] + w1 * (s - m[p]);
-        const float vv = v[p] * b2f + w2 * (s * s);
-        prm[p] = prm[p] - step_size * (mm / (sqrtf(vv) / bc2_sqrt + (float)eps));
-        m[p] = mm; v[p] = vv;
-      }
-    } else if (loss_sum) loss_sum[0] = s * inv_batch;
+  if (threadIdx.x < 64) {
+    const int px = threadIdx.x;
+    const int64_t p = (int64_t)blockIdx.x * 64 + px;
+    if (p <= n_params) {
+      float s = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) s += part[g][px >> 2][px & 3];
+      if (p < n_params) {
+        if (grads) grads[p] = s;
+        if (ADAM) {
+          const int64_t st = step_dev[0];
+          const double bc1 = 1.0 - pow(b1, (double)st), bc2 = 1.0 - pow(b2, (double)st);
+          const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+          const float w1 = (float)(1.0 - b1), b2f = (float)b2, w2 = (float)(1.0 - b2);
+          const float mm = m[p] + w1 * (s - m[p]);
+          const float vv = v[p] * b2f + w2 * (s * s);
+          prm[p] = prm[p] - step_size * (mm / (sqrtf(vv) / bc2_sqrt + (float)eps));
+          m[p] = mm; v[p] = vv;
+        }
+      } else if (loss_sum) loss_sum[0] = s * inv_batch;
+    }
   }
   if (ADAM && rng_advance && blockIdx.x == 0 && threadIdx.x == 0) rng_advance[1] += 1;
 }
@@ -877,7 +887,7 @@ int64_t msgm_mlp_num_params(int32_t d, int32_t premodule) {
 }
 
 size_t msgm_mlp_ssm_workspace(int32_t d, int32_t premodule) {
-  return (size_t)MLP_MAX_GRID * (size_t)(msgm_mlp_num_params(d, premodule) + 1) * sizeof(float);
+  return (size_t)MLP_MAX_GRID * (size_t)slab_stride(msgm_mlp_num_params(d, premodule)) * sizeof(float);
 }
 
 int msgm_mlp_forward(const msgm_mlp_params_t* P, const float* y, const float* t, float* a, int64_t B,
@@ -951,7 +961,7 @@ int msgm_mlp_ssm_reduce(int32_t d, int32_t premodule, const void* workspace, int
   if (!workspace || !grads || n_slabs < 1 || n_slabs > MLP_MAX_GRID) return MSGM_E_BADARG;
   const int64_t n_params = msgm_mlp_num_params(d, premodule);
   hipLaunchKernelGGL(k_slab_reduce<false>, dim3((unsigned)((n_params + 1 + 63) / 64)), dim3(256), 0, S(stream),
-                     reinterpret_cast<const float*>(workspace), n_slabs, n_params + 1, grads, n_params, loss_sum, inv_batch,
+                     reinterpret_cast<const float*>(workspace), n_slabs, slab_stride(n_params), grads, n_params, loss_sum, inv_batch,
                      (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.0, 0.0, 0.0, 0.0, (const int64_t*)nullptr,
                      (uint64_t*)nullptr);
   return msgm_check_launch();
@@ -964,7 +974,7 @@ int msgm_mlp_ssm_reduce_adam(int32_t d, int32_t premodule, const void* workspace
   if (!workspace || !params || !m || !v || !step_dev || n_slabs < 1 || n_slabs > MLP_MAX_GRID) return MSGM_E_BADARG;
   const int64_t n_params = msgm_mlp_num_params(d, premodule);
   hipLaunchKernelGGL(k_slab_reduce<true>, dim3((unsigned)((n_params + 1 + 63) / 64)), dim3(256), 0, S(stream),
-                     reinterpret_cast<const float*>(workspace), n_slabs, n_params + 1, grads, n_params, loss_sum, inv_batch,
+                     reinterpret_cast<const float*>(workspace), n_slabs, slab_stride(n_params), grads, n_params, loss_sum, inv_batch,
                      params, m, v, lr, beta1, beta2, eps, step_dev, rng_advance);
   return msgm_check_launch();
 }
