@@ -378,6 +378,14 @@ int msgm_softmax_dual_backward(const float* P, const float* Wd, float* Pb, float
 int msgm_attention_supported(int32_t T, int32_t C);
 int msgm_attention_forward(const float* qkv, float* out, int64_t N, int32_t T, int32_t C, float scale, msgm_stream_t stream);
 
+/* ---- reporting metric next to the hot path -------------------- */
+/* RBF kernel of compute_kernel / compute_mmd (quantitative_comparison.py:22-46):
+ * k(x_i, y_j) = exp(-sum_d (x_i - y_j)^2 / d^2) for x [Nx][d], y [Ny][d].  K (may be NULL) receives the
+ * [Nx][Ny] matrix; sum (may be NULL; a device double, zeroed by this call) receives sum_ij k — the MMD is
+ * sxx/Nx^2 + syy/Ny^2 - 2 sxy/(Nx Ny) without the (Nx, Ny, d) broadcast tensor of the reference. */
+int msgm_rbf_kernel(const float* x, const float* y, int64_t Nx, int64_t Ny, int32_t d, float* K, double* sum,
+                    msgm_stream_t stream);
+
 /* [cos(t f_j), sin(t f_j)], f_j = exp(-ln(max_period) j/half) (model/nn_utils.py:130-148). */
 int msgm_timestep_embedding(const float* t, float* emb, int32_t B, int32_t dim, float max_period, msgm_stream_t stream);
 

@@ -135,3 +135,12 @@ def load_checkpoint(path, gen_sde, optim, device):
     np.random.set_state(ck["numpy_rng"])
     random.setstate(ck["python_rng"])
     return ck["iteration"]
+
+
+def evaluate(gen_sde, x_test):
+    """Mean and standard error of the ELBO slice estimate on a test batch (NN.py:123-129)."""
+    gen_sde.eval()
+    num_samples_ = x_test.size(0)
+    test_elbo = gen_sde.elbo_random_t_slice(x_test)
+    gen_sde.train()
+    return test_elbo.mean(), test_elbo.std() / num_samples_ ** 0.5

@@ -19,6 +19,8 @@ tests inject explicit noise instead.
 """
 from __future__ import annotations
 
+import math
+
 from typing import Optional
 
 import torch
@@ -149,8 +151,16 @@ class SGMsde(SDE):
         rng.advance(1)
         return x
 
-    def cond_latent_sample(self, t_, T, x):
-        return self.sample(torch.ones_like(t_) * T, x)
+    def cond_latent_sample(self, t_, T, x, eps=None):
+        return self.sample(torch.ones_like(t_) * T, x, eps=eps)
+
+    def log_normal(self, x, mean, log_var, eps=0.00001):
+        """SDEs.py:213-215."""
+        return -(x - mean) ** 2 / (2. * torch.exp(log_var) + eps) - log_var / 2. - 0.5 * math.log(2 * math.pi)
+
+    def log_latent_pdf(self, yT):
+        """Standard-normal latent log-density per element (SDEs.py:209-211), on the device."""
+        return self.log_normal(yT, torch.zeros_like(yT), torch.zeros_like(yT))
 
 
 class MSGMsde(SDE):
@@ -429,8 +439,21 @@ class PluginReverseSDE(nn.Module):
     def cond_latent_sample(self, t_, T, x):
         return self.base_sde.cond_latent_sample(t_, T, x)
 
-    def elbo_random_t_slice(self, x):
-        raise MsgmError("ELBO evaluation (KDE latent density) is outside the accelerated hot path")
+    def elbo_random_t_slice(self, x, u=None, eps=None, u_v=None, eps_T=None):
+        """ELBO slice estimate lp(y_T) - ssm(x) T (SDEs.py:708-721) for the additive SDE; the loss term runs on the
+        same fused kernels as training.  ``u``/``eps``/``u_v`` inject the draws of ``ssm`` and ``eps_T`` the noise
+        of ``cond_latent_sample`` (parity tests).  The multiplicative SDE's latent density is a sklearn KDE
+        (SDEs.py:503-509) and stays out of scope."""
+        if self.base_sde.kind != L.SDE_SGM:
+            raise MsgmError("ELBO evaluation of the multiplicative SDE needs its KDE latent density (out of scope)")
+        x = x.contiguous().float()
+        qt = 1.0 / self.base_sde.T_float()
+        with torch.no_grad():
+            loss_ssm = self.ssm(x, u=u, eps=eps, u_v=u_v).detach() / qt
+            t_ = torch.empty(x.shape[0], 1, device=x.device)
+            yT = self.base_sde.cond_latent_sample(t_, self.base_sde.T_float(), x, eps=eps_T)
+            lp = self.base_sde.log_latent_pdf(yT).view(x.size(0), -1).sum(1)
+        return lp - loss_ssm
 
 
 class _SSMGradBridge(torch.autograd.Function):

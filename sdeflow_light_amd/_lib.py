@@ -87,6 +87,7 @@ SIGNATURES = {
     "msgm_softmax_dual_forward": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P]),
     "msgm_softmax_dual_backward": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P]),
     "msgm_pack_weights_batched": (C.c_int, [_P, _I32, _I32, _P]),
+    "msgm_rbf_kernel": (C.c_int, [_P, _P, _I64, _I64, _I32, _P, _P, _P]),
     "msgm_attention_supported": (C.c_int, [_I32, _I32]),
     "msgm_attention_forward": (C.c_int, [_P, _P, _I64, _I32, _I32, _F, _P]),
     "msgm_timestep_embedding": (C.c_int, [_P, _P, _I32, _I32, _F, _P]),

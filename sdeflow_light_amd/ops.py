@@ -458,6 +458,18 @@ def softmax_dual_forward(S, T, Wd=None, Pd=None):
     check(lib().msgm_softmax_dual_forward(ptr(f32(S)), ptr(Wd), ptr(Pd), rows, T, int(dual), stream()), "msgm_softmax_dual_forward")
 
 
+def rbf_kernel(x: torch.Tensor, y: torch.Tensor, want_matrix: bool = False, want_sum: bool = True):
+    """exp(-mean_d((x_i - y_j)^2) / d) over all pairs: (K or None, sum as a 1-element float64 tensor or None)."""
+    if x.dim() != 2 or y.dim() != 2 or x.shape[1] != y.shape[1]:
+        raise MsgmError("rbf_kernel: x (Nx,d) and y (Ny,d) expected")
+    x, y = f32(x), f32(y)
+    Kmat = torch.empty(x.shape[0], y.shape[0], dtype=torch.float32, device=x.device) if want_matrix else None
+    ssum = torch.empty(1, dtype=torch.float64, device=x.device) if want_sum else None
+    check(lib().msgm_rbf_kernel(ptr(x), ptr(y), x.shape[0], y.shape[0], x.shape[1], ptr(Kmat), ptr(ssum), stream()),
+          "msgm_rbf_kernel")
+    return Kmat, ssum
+
+
 def attention_supported(T, C) -> bool:
     return bool(lib().msgm_attention_supported(int(T), int(C)))
 

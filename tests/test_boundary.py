@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     # pure-host queries are callable without a GPU
     assert L.msgm_mlp_num_params(2, 0) == 33794
     assert L.msgm_mlp_num_params(2, 1) == 33922
-    assert L.msgm_mlp_ssm_workspace(2, 0) == 256 * (33794 + 1) * 4
+    assert L.msgm_mlp_ssm_workspace(2, 0) == 256 * 33796 * 4    # 256 slabs of n_params + 1 (loss) floats, pitch rounded up to 4
 
 
 def test_product_never_imports_oracle_or_reference():

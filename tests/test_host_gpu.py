@@ -432,3 +432,43 @@ def test_checkpoint_roundtrip_and_torch_adam_compat(tmp_path):
     assert it == 1
     run(gen2, opt2, noise[2:])
     assert torch.equal(gen2.a.flat_parameters()[0], final)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_mmd_golden(tag):
+    """compute_kernel / compute_mmd (quantitative_comparison.py:22-46) on the device vs the reference's values
+    (g15, generated by importing the reference) — fp32, 1e-5."""
+    from sdeflow_light_amd.quantitative_comparison import compute_kernel, compute_mmd
+    g = load_golden("g15_metrics")
+    x, y = g[f"mmd_{tag}_x"], g[f"mmd_{tag}_y"]
+    K = compute_kernel(x.to(DEV), y.to(DEV))
+    assert K.shape == (x.shape[0], y.shape[0])
+    assert rel_l2(K.cpu(), g[f"mmd_{tag}_Kxy"]) <= 1e-5
+    assert abs(float(compute_mmd(x.to(DEV), y.to(DEV))) - float(g[f"mmd_{tag}"])) <= 1e-5
+    assert abs(float(compute_mmd(x, y)) - float(g[f"mmd_{tag}"])) <= 1e-5          # host tensors are moved over
+
+
+def test_mmd_large_matches_oracle_and_properties():
+    """Ragged sizes across several tiles; MMD(x, x) = 0 and symmetry (size-independent properties)."""
+    from oracle import metrics_ref as M
+    from sdeflow_light_amd.quantitative_comparison import compute_mmd
+    torch.manual_seed(3)
+    x, y = torch.randn(1000, 5), torch.randn(777, 5) * 0.7 + 0.3
+    a = float(compute_mmd(x.to(DEV), y.to(DEV)))
+    assert abs(a - float(M.mmd(x, y))) <= 1e-5
+    assert abs(a - float(compute_mmd(y.to(DEV), x.to(DEV)))) <= 1e-6
+    assert abs(float(compute_mmd(x.to(DEV), x.to(DEV)))) <= 1e-6
+
+
+def test_elbo_and_evaluate_golden():
+    """elbo_random_t_slice (SDEs.py:708-721) with the reference's recorded draws, and NN.evaluate's contract."""
+    from sdeflow_light_amd.NN import MLP, evaluate
+    g = load_golden("g15_metrics")
+    gen = make_gen("sgm", MLP(2), g, "elbo::")
+    assert rel_l2(gen.base_sde.log_latent_pdf(g["lp_y"].to(DEV)).cpu(), g["lp"]) <= 1e-6
+    elbo = gen.elbo_random_t_slice(g["elbo_x"].to(DEV), u=g["elbo_draw0_rand"].to(DEV), eps=g["elbo_draw1_randn_like"].to(DEV),
+                                   u_v=g["elbo_draw2_rand"].to(DEV), eps_T=g["elbo_draw5_randn_like"].to(DEV))
+    assert rel_l2(elbo.cpu(), g["elbo"]) <= 1e-4
+    mean, se = evaluate(gen, g["elbo_x"].to(DEV))
+    assert mean.dim() == 0 and se.dim() == 0 and torch.isfinite(mean) and float(se) > 0
+    assert gen.training

@@ -367,3 +367,25 @@ def test_g14_ssm_msgm(tag, kind, d, pre, form):
     close(per, g[tag + "_per"], 1e-5)
     for k, gr in grads.items():
         close(gr, g[f"{tag}_grad::a.{k}"], 5e-5)
+
+
+# ---- g15: reporting metrics next to the hot path -----------------------------------------------
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_g15_rbf_mmd(tag):
+    from oracle import metrics_ref as M
+    g = load_golden("g15_metrics")
+    x, y = g[f"mmd_{tag}_x"], g[f"mmd_{tag}_y"]
+    close(M.rbf_kernel(x, y), g[f"mmd_{tag}_Kxy"], 1e-6)
+    assert abs(float(M.mmd(x, y)) - float(g[f"mmd_{tag}"])) <= 1e-6
+
+
+def test_g15_log_latent_pdf_and_elbo():
+    from oracle import metrics_ref as M
+    g = load_golden("g15_metrics")
+    close(M.sgm_log_latent_pdf(g["lp_y"]), g["lp"], 1e-6)
+    sp = spec()
+    p = {k[2:]: v for k, v in g.sub("elbo::").items() if k.startswith("a.")}
+    score = lambda prm, yy, tt: N.mlp_forward(prm, yy, tt, None)
+    elbo = M.elbo_sgm(sp, score, p, g["elbo_x"], g["elbo_draw0_rand"], g["elbo_draw1_randn_like"], g["elbo_draw2_rand"],
+                      g["elbo_draw5_randn_like"])
+    close(elbo, g["elbo"], 1e-5)

@@ -425,6 +425,32 @@ def g14_ssm_msgm():
     save("g14_ssm_msgm", **out)
 
 
+def g15_metrics():
+    """Reporting metrics next to the hot path: RBF-kernel MMD (quantitative_comparison.py:22-46),
+    Gaussian latent log-density (SDEs.py:209-215) and the ELBO slice estimate (SDEs.py:708-721) with every draw
+    recorded in call order."""
+    from quantitative_comparison import compute_kernel, compute_mmd
+    torch.manual_seed(15)
+    out = {}
+    for tag, nx, ny, d in (("a", 37, 53, 2), ("b", 64, 40, 7), ("c", 20, 20, 300)):
+        x, y = torch.randn(nx, d) * 1.3, torch.randn(ny, d) * 0.9 + 0.4
+        out.update({f"mmd_{tag}_x": x, f"mmd_{tag}_y": y, f"mmd_{tag}_Kxy": compute_kernel(x, y),
+                    f"mmd_{tag}": compute_mmd(x, y).reshape(1)})
+    yT = torch.randn(19, 5) * 1.7
+    out.update(lp_y=yT, lp=sgm().log_latent_pdf(yT))
+    B, d = 96, 2
+    net = MLP(d)
+    rev = PluginReverseSDE(sgm(), net, Tparam())
+    x = torch.randn(B, d) * 1.5
+    with Recorder() as r:
+        elbo = rev.elbo_random_t_slice(x)
+    out.update({"elbo::" + k: v for k, v in sd_np(rev.state_dict()).items()})
+    out.update(elbo_x=x, elbo=elbo.detach())
+    for i, (kind, val) in enumerate(r.draws):
+        out[f"elbo_draw{i}_{kind}"] = val
+    save("g15_metrics", **out)
+
+
 def g11_train3():
     torch.manual_seed(11)
     B, d, steps = 128, 2, 3
