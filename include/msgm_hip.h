@@ -285,6 +285,27 @@ int msgm_conv_forward(const msgm_conv_geom_t* geom, const float* src0, int32_t C
                       const float* samp_bias, int32_t n_bias, int32_t n_samp, float* out, int32_t accumulate,
                       msgm_stream_t stream);
 
+/* The same convolution with optional work folded in:
+ *  - residual [N][Ho][Wo][Cout]: added in the epilogue (ResBlock `h + x`, attention `x + proj(...)`, model/unet.py:
+ *    187,232) — saves one read-modify-write pass over the output;
+ *  - in_scale / in_shift [N][C0+C1] (+ in_act = 1: SiLU): the convolution reads act(a x + b) instead of x, i.e.
+ *    GroupNorm(+SiLU) (model/unet.py:140-143,152-155,214) is applied while the input tile is staged and the
+ *    normalised tensor is never written.  Only the halo-tile kernel (stride-1 "same" shapes) can do this:
+ *    msgm_conv_input_transform_supported() tells; otherwise the call returns MSGM_E_UNSUPPORTED.
+ * fuse may be NULL (= msgm_conv_forward). */
+typedef struct {
+  const float* residual;
+  const float* in_scale;
+  const float* in_shift;
+  int32_t in_act;
+  int32_t reserved;
+} msgm_conv_fuse_t;
+int msgm_conv_input_transform_supported(const msgm_conv_geom_t* geom, int32_t C0, int32_t C1, int32_t CoutP);
+int msgm_conv_forward_fused(const msgm_conv_geom_t* geom, const float* src0, int32_t C0, const float* src1, int32_t C1,
+                            const float* Wp, int32_t Cout, int32_t CoutP, int32_t Ktot, const float* bias,
+                            const float* samp_bias, int32_t n_bias, int32_t n_samp, float* out, int32_t accumulate,
+                            const msgm_conv_fuse_t* fuse, msgm_stream_t stream);
+
 /* dWp[tap][co][koff + c] += sum_m gy[m][co] in[src(m,tap)][c] (float atomics across
  * position chunks; zero dWp first).  One call per concatenated source.
  * dbias (may be NULL): dbias[co] += sum over the primal rows n < n_bias and all pixels of gy — the bias gradient
@@ -348,6 +369,15 @@ int msgm_groupnorm_dual_backward(const float* x, const float* gamma, const float
                                  const float* gout, float* gx, float* dgamma, float* dbeta, int32_t Bp, int32_t P,
                                  int32_t C, int32_t G, int32_t silu, float eps, void* workspace, size_t workspace_bytes,
                                  msgm_stream_t stream);
+
+/* GroupNorm statistics only, returned as the per-(sample, channel) affine map y = scale x + shift
+ * (scale = gamma/sigma, shift = beta - mean scale; [Bp][C0+C1] each) for a consumer that applies it while reading
+ * x (msgm_conv_forward_fused) — the normalised tensor is never written.  x1 (may be NULL) is a second tensor whose
+ * C1 channels are concatenated after x0's C0 (decoder ResBlocks normalise cat([h, skip]), model/unet.py:514), so the
+ * concatenation need not be materialised either.  No tangent (sampler path).  Workspace as above. */
+int msgm_groupnorm_affine(const float* x0, int32_t C0, const float* x1, int32_t C1, const float* gamma, const float* beta,
+                          float* scale, float* shift, int32_t Bp, int32_t P, int32_t G, float eps, void* workspace,
+                          size_t workspace_bytes, msgm_stream_t stream);
 
 /* Batched fp32-MFMA GEMM with element strides:
  *   C[b](i,j) (+)= alpha ( sum_k A[b](i,k) B[b](k,j) + sum_k A2[b](i,k) B2[b](k,j) )

@@ -19,6 +19,7 @@ the core UNet upstream already supports any ``in_channels``.
 from __future__ import annotations
 
 import math
+import os
 from typing import Literal, Optional
 
 import torch
@@ -222,18 +223,35 @@ class VorticityUNet(nn.Module, FlatParamMixin):
         out = ops.groupnorm_dual_forward(h, gnm.weight.detach(), gnm.bias.detach(), Bp, P, C, G, dual, silu, stats=stats)
         return out, stats
 
+    def _gn_fold(self, gnm: nn.GroupNorm, x, Bp, P, C):
+        """GroupNorm as a per-(sample, channel) affine map for a conv that applies it while staging its input."""
+        return ops.groupnorm_affine(x, C, gnm.weight.detach(), gnm.bias.detach(), Bp, P, gnm.num_groups)
+
     def _res_fwd(self, r: _Res, x, N, Bp, H, W, semb, dual, tape, er):
         P = H * W
-        h1, st1 = self._gn(r.m.in_layers[0], x, Bp, P, r.ci, dual, True, tape)
         eo, _, _ = r.lin.forward([semb], er, 1, 1, Bp)           # er rows carry an embedding (N with log-radius conditioning)
+        fold = (not dual and tape is None and not os.environ.get("MSGM_NO_GN_FOLD")
+                and r.conv1.can_transform_input(N, H, W) and r.conv2.can_transform_input(N, H, W))
+        if fold:
+            # sampler path: GroupNorm+SiLU are applied by the consuming conv while it stages its input tile, the residual
+            # is added in conv2's epilogue — the two normalised tensors and the separate add pass never exist
+            h2, _, _ = r.conv1.forward([x], N, H, W, Bp, samp_bias=eo, emb_rows=er,
+                                       in_affine=self._gn_fold(r.m.in_layers[0], x, Bp, P, r.ci), in_act=1)
+            aff2 = self._gn_fold(r.m.out_layers[0], h2, Bp, P, r.co)
+            if r.skip is not None:
+                out, _, _ = r.skip.forward([x], N, H, W, Bp)
+                r.conv2.forward([h2], N, H, W, Bp, out=out, accumulate=True, in_affine=aff2, in_act=1)
+            else:
+                out, _, _ = r.conv2.forward([h2], N, H, W, Bp, residual=x, in_affine=aff2, in_act=1)
+            return out
+        h1, st1 = self._gn(r.m.in_layers[0], x, Bp, P, r.ci, dual, True, tape)
         h2, _, _ = r.conv1.forward([h1], N, H, W, Bp, samp_bias=eo, emb_rows=er)
         h3, st2 = self._gn(r.m.out_layers[0], h2, Bp, P, r.co, dual, True, tape)
         if r.skip is not None:
             out, _, _ = r.skip.forward([x], N, H, W, Bp)
             r.conv2.forward([h3], N, H, W, Bp, out=out, accumulate=True)
         else:
-            out, _, _ = r.conv2.forward([h3], N, H, W, Bp)
-            ops.lincomb(out, out, 1.0, x, 1.0)
+            out, _, _ = r.conv2.forward([h3], N, H, W, Bp, residual=x)          # h + x in the epilogue (unet.py:187)
         if tape is not None:
             tape.append(("res", r, x, H, W, h1, st1, h2, st2, h3))
         return out
@@ -241,14 +259,18 @@ class VorticityUNet(nn.Module, FlatParamMixin):
     def _attn_fwd(self, a: _Attn, x, N, Bp, H, W, dual, tape):
         T, C = H * W, a.c
         dev = x.device
-        hn, st = self._gn(a.m.norm, x, Bp, T, C, dual, False, tape)
-        qkv, _, _ = a.qkv.forward([hn], N, 1, T, Bp)                     # [N][T][3C]: q | k | v channel slices
         s2 = 1.0 / math.sqrt(C)                                          # (ch^-1/4)^2           model/unet.py:245-248
         if not dual and tape is None and ops.attention_supported(T, C):  # sampler: nothing to keep, no tangent
+            if a.qkv.can_transform_input(N, 1, T) and not os.environ.get("MSGM_NO_GN_FOLD"):
+                qkv, _, _ = a.qkv.forward([x], N, 1, T, Bp, in_affine=self._gn_fold(a.m.norm, x, Bp, T, C))   # GN folded in
+            else:
+                hn, _ = self._gn(a.m.norm, x, Bp, T, C, False, False, None)
+                qkv, _, _ = a.qkv.forward([hn], N, 1, T, Bp)
             att = ops.attention_forward(qkv, torch.empty(N * T * C, device=dev), N, T, C, s2)
-            out, _, _ = a.proj.forward([att], N, 1, T, Bp)
-            ops.lincomb(out, out, 1.0, x, 1.0)
+            out, _, _ = a.proj.forward([att], N, 1, T, Bp, residual=x)    # x + proj(.) in the epilogue (unet.py:232)
             return out
+        hn, st = self._gn(a.m.norm, x, Bp, T, C, dual, False, tape)
+        qkv, _, _ = a.qkv.forward([hn], N, 1, T, Bp)                     # [N][T][3C]: q | k | v channel slices
         ld = 3 * C
         half = Bp * T * ld                                               # offset of the tangent rows
         S = torch.empty(Bp * T * T, device=dev)
@@ -266,8 +288,7 @@ class VorticityUNet(nn.Module, FlatParamMixin):
         if dual:
             offa = Bp * T * C
             ops.bmm(Pd, 0, qkv, 2 * C, att, offa, T, C, T, Bp, sP, sv, sa, pair2=(S, 0, qkv, half + 2 * C))   # Pdot v + P vdot
-        out, _, _ = a.proj.forward([att], N, 1, T, Bp)
-        ops.lincomb(out, out, 1.0, x, 1.0)
+        out, _, _ = a.proj.forward([att], N, 1, T, Bp, residual=x)
         if tape is not None:
             tape.append(("attn", a, x, H, W, hn, st, qkv, S, Wd, Pd, att))
         return out

@@ -30,6 +30,12 @@ class SdeT(C.Structure):
                 ("t_epsilon", C.c_float), ("G", C.c_void_p), ("L_G", C.c_void_p)]
 
 
+class ConvFuseT(C.Structure):
+    """msgm_conv_fuse_t (include/msgm_hip.h)."""
+    _fields_ = [("residual", C.c_void_p), ("in_scale", C.c_void_p), ("in_shift", C.c_void_p), ("in_act", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
 class PackJobT(C.Structure):
     """msgm_pack_job_t (include/msgm_hip.h)."""
     _fields_ = [("W", C.c_void_p), ("Wp", C.c_void_p), ("sr", C.c_int64), ("sc", C.c_int64), ("st", C.c_int64),
@@ -72,6 +78,9 @@ SIGNATURES = {
     "msgm_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _D, _D, _D, _D, _F, _I64, _P, _P]),
     "msgm_counter_inc": (C.c_int, [_P, _P]),
     "msgm_conv_forward": (C.c_int, [C.POINTER(ConvGeomT), _P, _I32, _P, _I32, _P, _I32, _I32, _I32, _P, _P, _I32, _I32, _P, _I32, _P]),
+    "msgm_conv_forward_fused": (C.c_int, [C.POINTER(ConvGeomT), _P, _I32, _P, _I32, _P, _I32, _I32, _I32, _P, _P, _I32, _I32, _P, _I32, C.POINTER(ConvFuseT), _P]),
+    "msgm_conv_input_transform_supported": (C.c_int, [C.POINTER(ConvGeomT), _I32, _I32, _I32]),
+    "msgm_groupnorm_affine": (C.c_int, [_P, _I32, _P, _I32, _P, _P, _P, _P, _I32, _I32, _I32, _F, _P, C.c_size_t, _P]),
     "msgm_conv_wgrad": (C.c_int, [C.POINTER(ConvGeomT), _P, _P, _I32, _I32, _P, _I32, _I32, _I32, _P, _I32, _P]),
     "msgm_pack_weight": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I32, _I32, _I32, _P]),
     "msgm_unpack_weight": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I32, _I32, _I32, _I32, _P]),

@@ -187,10 +187,16 @@ class ConvOp:
         Ho, Wo = self.out_hw(Hi, Wi)
         return ops.conv_geom(N, Hi, Wi, Ho, Wo, self.KH, self.KW, self.stride, self.pad, self.mode, int(self.ups)), Ho, Wo
 
+    def can_transform_input(self, N: int, Hi: int, Wi: int) -> bool:
+        """True when forward() can apply a per-(sample, channel) affine (+SiLU) to its input on the fly."""
+        geom, _, _ = self._geom(N, Hi, Wi)
+        return ops.conv_input_transform_supported(geom, self.srcC[0], self.srcC[1] if len(self.srcC) > 1 else 0, self.CoutP)
+
     # -------------------------------------------------------------- forward
     def forward(self, srcs: List[torch.Tensor], N: int, Hi: int, Wi: int, n_bias: int, emb: Optional[torch.Tensor] = None,
                 samp_bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, accumulate=False,
-                emb_rows: Optional[int] = None):
+                emb_rows: Optional[int] = None, residual: Optional[torch.Tensor] = None,
+                in_affine: Optional[tuple] = None, in_act: int = 0):
         """emb_rows: rows that carry an embedding / per-sample bias (n_bias by default; N when the embedding itself
         has a tangent — NormalizeLogRadius conditioning)."""
         geom, Ho, Wo = self._geom(N, Hi, Wi)
@@ -212,7 +218,9 @@ class ConvOp:
         ops.conv_forward(geom, srcs[0], self.srcC[0], self.Wp, self.Cout, out,
                          src1=srcs[1] if len(srcs) > 1 else None, C1=self.srcC[1] if len(srcs) > 1 else 0,
                          bias=self.bias.detach() if self.bias is not None else None, samp_bias=sb, n_bias=n_bias,
-                         accumulate=accumulate, CoutP=self.CoutP, n_samp=er)
+                         accumulate=accumulate, CoutP=self.CoutP, n_samp=er, residual=residual,
+                         in_scale=in_affine[0] if in_affine is not None else None,
+                         in_shift=in_affine[1] if in_affine is not None else None, in_act=in_act)
         if self.embC:
             # taps 0 / 2 fall on the zero padding at l = 0 / L-1 (rows that carry an embedding)
             ops.add_row(out, self._E[0], er, Ho * Wo, self.Cout, 0, -1.0)

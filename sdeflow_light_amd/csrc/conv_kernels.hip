@@ -46,6 +46,12 @@ struct ConvArgs {
   int n_bias, n_samp;
   float* out;                 // [N][Ho][Wo][Cout]
   int accumulate;             // out += result (fused residual / skip add)
+  const float* residual;      // [N][Ho][Wo][Cout] or null: added in the epilogue (ResBlock / attention skip path)
+  // optional transform of the INPUT while it is staged (halo-tile kernel only): the conv reads act(a x + b) with
+  // per-(sample, input channel) a, b — GroupNorm (+ SiLU) folded into the consuming convolution
+  const float* in_scale;      // [N][Ctot] or null, Ctot = sum of the sources' channels
+  const float* in_shift;      // [N][Ctot]
+  int in_act;                 // 0 none, 1 SiLU
 };
 
 // input coordinate of output coordinate o for tap k; returns false when the tap falls outside
@@ -208,11 +214,12 @@ __global__ void __launch_bounds__(256) k_conv_gemm(ConvArgs A) {
       }
       if (full) {
         if (A.accumulate) v += *reinterpret_cast<const f32x4*>(op);
+        if (A.residual) v += *reinterpret_cast<const f32x4*>(A.residual + (op - A.out));
         *reinterpret_cast<f32x4*>(op) = v;
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (co + r < A.Cout) op[r] = A.accumulate ? op[r] + v[r] : v[r];
+          if (co + r < A.Cout) op[r] = (A.accumulate ? op[r] + v[r] : v[r]) + (A.residual ? A.residual[(op - A.out) + r] : 0.f);
       }
     }
   }
@@ -267,6 +274,7 @@ __global__ void __launch_bounds__(256) k_conv_tile(ConvArgs A, int flip, int til
   const int n_items = halo * (CT_KC / 4);
   const int padH = g.padH, padW = g.padW;
   const int up = g.ups ? 1 : 0;          // Upsample folded into the gather (model/unet.py:60-73)
+  const int ctot_all = A.C[0] + (A.nsrc > 1 ? A.C[1] : 0);
   auto tile_origin = [&](int t, int& n, int& y0, int& x0) {
     const int tx_i = t % tiles_x; t /= tiles_x;
     const int ty_i = t % tiles_y;
@@ -277,6 +285,15 @@ __global__ void __launch_bounds__(256) k_conv_tile(ConvArgs A, int flip, int til
     tile_origin(t, n, y0, x0);
     const int C = A.C[s];
     const float* base = A.src[s] + (size_t)n * g.Hi * g.Wi * C;
+    // folded GroupNorm(+SiLU): this thread's 4 channels are the same for every k (256 % 8 == 0), so a and b are
+    // fetched once per staged chunk; zero padding stays zero (the transform is applied to real pixels only)
+    f32x4 ga = {1.f, 1.f, 1.f, 1.f}, gb = {0.f, 0.f, 0.f, 0.f};
+    const int cq = c0 + 4 * (tid & 7);
+    if (A.in_scale && cq < C) {
+      const size_t o = (size_t)n * ctot_all + (s ? A.C[0] : 0) + cq;
+      ga = *reinterpret_cast<const f32x4*>(A.in_scale + o);
+      gb = *reinterpret_cast<const f32x4*>(A.in_shift + o);
+    }
 #pragma unroll
     for (int k = 0; k < MAXST; ++k) {
       const int idx = tid + 256 * k;
@@ -286,8 +303,16 @@ __global__ void __launch_bounds__(256) k_conv_tile(ConvArgs A, int flip, int til
         const int hy = hp / HW, hx = hp - hy * HW;
         const int iy = y0 + hy - padH, ix = x0 + hx - padW;     // on the (2x nearest-upsampled, if ups) input grid
         const int c = c0 + 4 * c4;
-        if (iy >= 0 && iy < (g.Hi << up) && ix >= 0 && ix < (g.Wi << up) && c < C)
+        if (iy >= 0 && iy < (g.Hi << up) && ix >= 0 && ix < (g.Wi << up) && c < C) {
           v = *reinterpret_cast<const f32x4*>(base + ((size_t)(iy >> up) * g.Wi + (ix >> up)) * C + c);
+          if (A.in_scale) {
+            v = v * ga + gb;
+            if (A.in_act == 1) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[r]));
+            }
+          }
+        }
       }
       st[k] = v;
     }
@@ -396,11 +421,12 @@ __global__ void __launch_bounds__(256) k_conv_tile(ConvArgs A, int flip, int til
           }
           if (full) {
             if (A.accumulate) v += *reinterpret_cast<const f32x4*>(op);
+            if (A.residual) v += *reinterpret_cast<const f32x4*>(A.residual + (op - A.out));
             *reinterpret_cast<f32x4*>(op) = v;
           } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              if (co + r < A.Cout) op[r] = A.accumulate ? op[r] + v[r] : v[r];
+              if (co + r < A.Cout) op[r] = (A.accumulate ? op[r] + v[r] : v[r]) + (A.residual ? A.residual[(op - A.out) + r] : 0.f);
           }
         }
       }
@@ -824,12 +850,41 @@ static ConvGeom to_geom(const msgm_conv_geom_t* g) {
 
 extern "C" {
 
+// is this (geometry, channels) served by the halo-tile kernel?  (the only one that can transform its input)
+static bool conv_tile_eligible(const msgm_conv_geom_t* geom, int32_t C0, const float* src1, int32_t C1, int32_t CoutP) {
+  const bool fast = (C0 % 16 == 0) && (!src1 || C1 % 16 == 0);
+  const int ups_sh = geom->ups ? 1 : 0;
+  const bool same = geom->strideH == 1 && geom->strideW == 1 && (!geom->ups || geom->mode == 0) &&
+                    (geom->Hi << ups_sh) == geom->Ho && (geom->Wi << ups_sh) == geom->Wo &&
+                    (geom->KH & 1) && (geom->KW & 1) && geom->padH == (geom->KH - 1) / 2 && geom->padW == (geom->KW - 1) / 2 &&
+                    geom->KH <= 3 && geom->KW <= 3;
+  return same && fast && CoutP % 32 == 0 && (int64_t)geom->Ho * geom->Wo >= 64 && (geom->Ho > 1 || geom->KH == 1) &&
+         !getenv("MSGM_NO_CONV_TILE");
+}
+
+int msgm_conv_input_transform_supported(const msgm_conv_geom_t* geom, int32_t C0, int32_t C1, int32_t CoutP) {
+  if (check_geom(geom)) return 0;
+  static const float dummy = 0.f;
+  return conv_tile_eligible(geom, C0, C1 > 0 ? &dummy : nullptr, C1, CoutP) ? 1 : 0;
+}
+
 int msgm_conv_forward(const msgm_conv_geom_t* geom, const float* src0, int32_t C0, const float* src1, int32_t C1,
                       const float* Wp, int32_t Cout, int32_t CoutP, int32_t Ktot, const float* bias,
                       const float* samp_bias, int32_t n_bias, int32_t n_samp, float* out, int32_t accumulate,
                       msgm_stream_t stream) {
+  return msgm_conv_forward_fused(geom, src0, C0, src1, C1, Wp, Cout, CoutP, Ktot, bias, samp_bias, n_bias, n_samp, out,
+                                 accumulate, nullptr, stream);
+}
+
+int msgm_conv_forward_fused(const msgm_conv_geom_t* geom, const float* src0, int32_t C0, const float* src1, int32_t C1,
+                            const float* Wp, int32_t Cout, int32_t CoutP, int32_t Ktot, const float* bias,
+                            const float* samp_bias, int32_t n_bias, int32_t n_samp, float* out, int32_t accumulate,
+                            const msgm_conv_fuse_t* fuse, msgm_stream_t stream) {
   int rc = check_geom(geom);
   if (rc) return rc;
+  if (fuse && ((fuse->in_scale == nullptr) != (fuse->in_shift == nullptr) || (fuse->in_act != 0 && fuse->in_act != 1)))
+    return MSGM_E_BADARG;
+  if (fuse && fuse->in_scale && !conv_tile_eligible(geom, C0, src1, C1, CoutP)) return MSGM_E_UNSUPPORTED;
   if (!src0 || !Wp || !out || C0 <= 0 || Cout <= 0 || (src1 && C1 <= 0)) return MSGM_E_BADARG;
   const int k0 = ((C0 + 15) / 16) * 16, k1 = src1 ? ((C1 + 15) / 16) * 16 : 0;
   if (Ktot != k0 + k1 || CoutP % 16 || CoutP < Cout) return MSGM_E_BADARG;
@@ -840,16 +895,11 @@ int msgm_conv_forward(const msgm_conv_geom_t* geom, const float* src0, int32_t C
   A.nsrc = src1 ? 2 : 1;
   A.Wp = Wp; A.Cout = Cout; A.CoutP = CoutP; A.Ktot = Ktot;
   A.bias = bias; A.samp_bias = samp_bias; A.n_bias = n_bias; A.n_samp = n_samp; A.out = out; A.accumulate = accumulate;
+  if (fuse) { A.residual = fuse->residual; A.in_scale = fuse->in_scale; A.in_shift = fuse->in_shift; A.in_act = fuse->in_act; }
   const int64_t Mtot = (int64_t)geom->N * geom->Ho * geom->Wo;
   const bool fast = (C0 % 16 == 0) && (!src1 || C1 % 16 == 0);
   // stride-1 "same" convolution (or its dgrad) on a big enough image: halo-tile kernel
-  const int ups_sh = geom->ups ? 1 : 0;
-  const bool same = geom->strideH == 1 && geom->strideW == 1 && (!geom->ups || geom->mode == 0) &&
-                    (geom->Hi << ups_sh) == geom->Ho && (geom->Wi << ups_sh) == geom->Wo &&
-                    (geom->KH & 1) && (geom->KW & 1) && geom->padH == (geom->KH - 1) / 2 && geom->padW == (geom->KW - 1) / 2 &&
-                    geom->KH <= 3 && geom->KW <= 3;
-  if (same && fast && CoutP % 32 == 0 && (int64_t)geom->Ho * geom->Wo >= 64 && (geom->Ho > 1 || geom->KH == 1) &&
-      !getenv("MSGM_NO_CONV_TILE")) {
+  if (conv_tile_eligible(geom, C0, src1, C1, CoutP)) {
     const bool two_d = geom->Ho > 1;
     const int TH = two_d ? 8 : 1, TW = two_d ? 16 : 128;
     const int tiles_x = (geom->Wo + TW - 1) / TW, tiles_y = (geom->Ho + TH - 1) / TH;

@@ -38,6 +38,8 @@ struct GnArgs {
   float eps;
   // backward
   const float* gout; float* gx; float* dgamma; float* dbeta;
+  // forward statistics over the channel concatenation of two tensors (x: C0 channels, x1: C - C0), no tangent
+  const float* x1; int C0;
 };
 
 // V values per thread (channels V*cv .. V*cv+V-1 of pixel lane pl): LDS image [pl][C], then one thread per group sums
@@ -69,8 +71,12 @@ __global__ void __launch_bounds__(256) k_gn_fwd_reduce(GnArgs A) {
   const int CV = C / V, PL = 256 / CV;
   const bool live = tid < CV * PL;
   const int cv = live ? tid % CV : 0, pl = live ? tid / CV : 0;
-  const float* xp = A.x + (size_t)b * P * C;
-  const float* xt = A.x + (size_t)(b + A.Bp) * P * C;
+  // channel V*cv of the (possibly concatenated) input lives in x (pitch C0) or in x1 (pitch C - C0)
+  const int C0 = A.x1 ? A.C0 : C;
+  const bool second = V * cv >= C0;
+  const int pitch = second ? C - C0 : C0, coff = second ? V * cv - C0 : V * cv;
+  const float* xp = (second ? A.x1 : A.x) + (size_t)b * P * pitch + coff;
+  const float* xt = (second ? A.x1 : A.x) + (size_t)(b + A.Bp) * P * pitch + coff;
   const int p0 = blockIdx.y * A.chunk, p1 = min(p0 + A.chunk, P);
   float s0[V], s1[V], s2[V], s3[V];
 #pragma unroll
@@ -79,17 +85,17 @@ __global__ void __launch_bounds__(256) k_gn_fwd_reduce(GnArgs A) {
     for (int p = p0 + pl; p < p1; p += PL) {
       float xv[V], dv[V];
       if (VEC) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(xp + (size_t)p * C + 4 * cv);
+        const f32x4 t = *reinterpret_cast<const f32x4*>(xp + (size_t)p * pitch);
 #pragma unroll
         for (int k = 0; k < V; ++k) xv[k] = t[k];
         if (A.dual) {
-          const f32x4 u = *reinterpret_cast<const f32x4*>(xt + (size_t)p * C + 4 * cv);
+          const f32x4 u = *reinterpret_cast<const f32x4*>(xt + (size_t)p * pitch);
 #pragma unroll
           for (int k = 0; k < V; ++k) dv[k] = u[k];
         }
       } else {
-        xv[0] = xp[(size_t)p * C + cv];
-        if (A.dual) dv[0] = xt[(size_t)p * C + cv];
+        xv[0] = xp[(size_t)p * pitch];
+        if (A.dual) dv[0] = xt[(size_t)p * pitch];
       }
 #pragma unroll
       for (int k = 0; k < V; ++k) {
@@ -128,6 +134,22 @@ __global__ void __launch_bounds__(256) k_gn_finalize(GnArgs A, float* __restrict
   acc[0] = 0.0; acc[1] = 0.0; acc[2] = 0.0; acc[3] = 0.0;      // leave the accumulators zero for the next call
   *reinterpret_cast<f32x4*>(wstats + (size_t)i * 4) = f32x4{mu, inv, md, a};
   if (A.stats) *reinterpret_cast<f32x4*>(A.stats + (size_t)i * 4) = f32x4{mu, inv, md, a};
+}
+
+// GroupNorm as a per-(sample, channel) affine map y = a x + b (a = gamma/sigma, b = beta - mean a) for a consumer that
+// applies it while reading x (msgm_conv_forward_fused).  One block per sample; clears the accumulators afterwards.
+__global__ void __launch_bounds__(256) k_gn_affine(GnArgs A, float* __restrict__ scale, float* __restrict__ shift) {
+  const int b = blockIdx.x, c = threadIdx.x, cpg = A.C / A.G;
+  const double cnt = (double)A.P * cpg;
+  if (c < A.C) {
+    float mu, inv, md, a;
+    gn_stats(A.acc + ((size_t)b * A.G + c / cpg) * 8, cnt, A.eps, mu, inv, md, a);
+    const float sc = inv * A.gamma[c];
+    scale[(size_t)b * A.C + c] = sc;
+    shift[(size_t)b * A.C + c] = A.beta[c] - mu * sc;
+  }
+  __syncthreads();
+  if (c < A.G) { double* acc = A.acc + ((size_t)b * A.G + c) * 8; acc[0] = 0.0; acc[1] = 0.0; }
 }
 
 // Elementwise pass.  VEC: grid (pixel chunk, sample); a thread owns 4 consecutive channels (its statistics and
@@ -657,6 +679,23 @@ int msgm_groupnorm_dual_forward(const float* x, const float* gamma, const float*
   hipLaunchKernelGGL(k_gn_finalize, dim3((Bp * G + 255) / 256), dim3(256), 0, S(stream), A, wstats);
   if (C % 4 == 0) hipLaunchKernelGGL(k_gn_fwd_apply<true>, dim3(nch, Bp), dim3(256), 0, S(stream), A, (const float*)wstats);
   else hipLaunchKernelGGL(k_gn_fwd_apply<false>, dim3(nch, Bp), dim3(256), 0, S(stream), A, (const float*)wstats);
+  return msgm_check_launch();
+}
+
+int msgm_groupnorm_affine(const float* x0, int32_t C0, const float* x1, int32_t C1, const float* gamma, const float* beta,
+                          float* scale, float* shift, int32_t Bp, int32_t P, int32_t G, float eps, void* workspace,
+                          size_t workspace_bytes, msgm_stream_t stream) {
+  if (!x0 || !gamma || !beta || !scale || !shift || !workspace || Bp <= 0 || P <= 0 || C0 <= 0 || G <= 0 || (x1 && C1 <= 0))
+    return MSGM_E_BADARG;
+  const int C = C0 + (x1 ? C1 : 0);
+  if (C % G || C > 256 || G > 64 || (x1 && (C0 % 4 || C1 % 4))) return MSGM_E_UNSUPPORTED;
+  if (workspace_bytes < msgm_groupnorm_workspace(Bp, G)) return MSGM_E_WORKSPACE;
+  GnArgs A{x0, gamma, beta, nullptr, reinterpret_cast<double*>(workspace), nullptr, P, C, G, Bp, 0, 0, 0, eps,
+           nullptr, nullptr, nullptr, nullptr, x1, C0};
+  const int nch = gn_chunks(Bp, P, &A.chunk);
+  if (C % 4 == 0 && C0 % 4 == 0) hipLaunchKernelGGL(k_gn_fwd_reduce<true>, dim3(Bp, nch), dim3(256), 0, S(stream), A);
+  else hipLaunchKernelGGL(k_gn_fwd_reduce<false>, dim3(Bp, nch), dim3(256), 0, S(stream), A);
+  hipLaunchKernelGGL(k_gn_affine, dim3(Bp), dim3(256), 0, S(stream), A, scale, shift);
   return msgm_check_launch();
 }
 

@@ -271,8 +271,12 @@ def pad16(c: int) -> int:
 def conv_forward(geom: L.ConvGeomT, src0: torch.Tensor, C0: int, Wp: torch.Tensor, Cout: int, out: torch.Tensor,
                  src1: Optional[torch.Tensor] = None, C1: int = 0, bias: Optional[torch.Tensor] = None,
                  samp_bias: Optional[torch.Tensor] = None, n_bias: int = 0, accumulate: bool = False,
-                 CoutP: Optional[int] = None, n_samp: Optional[int] = None) -> torch.Tensor:
-    """out[N][Ho][Wo][Cout] (+)= implicit-GEMM convolution of channels-last inputs (K6/K11)."""
+                 CoutP: Optional[int] = None, n_samp: Optional[int] = None, residual: Optional[torch.Tensor] = None,
+                 in_scale: Optional[torch.Tensor] = None, in_shift: Optional[torch.Tensor] = None,
+                 in_act: int = 0) -> torch.Tensor:
+    """out[N][Ho][Wo][Cout] (+)= implicit-GEMM convolution of channels-last inputs (K6/K11).
+    residual: added in the epilogue.  in_scale / in_shift [N][C0+C1] (+ in_act=1: SiLU): the conv reads
+    act(a x + b) — GroupNorm(+SiLU) folded into the input staging (see conv_input_transform_supported)."""
     CoutP = pad16(Cout) if CoutP is None else CoutP
     Ktot = pad16(C0) + (pad16(C1) if src1 is not None else 0)
     taps = geom.KH * geom.KW
@@ -289,10 +293,37 @@ def conv_forward(geom: L.ConvGeomT, src0: torch.Tensor, C0: int, Wp: torch.Tenso
     n_samp = n_bias if n_samp is None else n_samp
     if samp_bias is not None and samp_bias.numel() != n_samp * Cout:
         raise MsgmError("samp_bias must be [n_samp][Cout]")
-    check(lib().msgm_conv_forward(geom, ptr(f32(src0)), C0, ptr(src1), C1, ptr(f32(Wp)), Cout, CoutP, Ktot, ptr(bias),
-                                  ptr(samp_bias), int(n_bias), int(n_samp), ptr(f32(out)), int(bool(accumulate)), stream()),
-          "msgm_conv_forward")
+    fuse = None
+    if residual is not None or in_scale is not None:
+        ctot = C0 + (C1 if src1 is not None else 0)
+        if residual is not None and residual.numel() != out.numel():
+            raise MsgmError("residual must have the output's size")
+        if (in_scale is None) != (in_shift is None) or (in_scale is not None and
+                                                        (in_scale.numel() != geom.N * ctot or in_shift.numel() != geom.N * ctot)):
+            raise MsgmError("in_scale / in_shift must both be [N][C0+C1]")
+        fuse = L.ConvFuseT(ptr(residual), ptr(in_scale), ptr(in_shift), int(in_act), 0)
+    check(lib().msgm_conv_forward_fused(geom, ptr(f32(src0)), C0, ptr(src1), C1, ptr(f32(Wp)), Cout, CoutP, Ktot, ptr(bias),
+                                        ptr(samp_bias), int(n_bias), int(n_samp), ptr(f32(out)), int(bool(accumulate)),
+                                        fuse, stream()), "msgm_conv_forward")
     return out
+
+
+def conv_input_transform_supported(geom: L.ConvGeomT, C0: int, C1: int, CoutP: int) -> bool:
+    return bool(lib().msgm_conv_input_transform_supported(geom, int(C0), int(C1), int(CoutP)))
+
+
+def groupnorm_affine(x0, C0, gamma, beta, Bp, P, G, x1=None, C1=0, eps=1e-5):
+    """GroupNorm statistics of x0 (| x1 concatenated along channels) as a per-(sample, channel) affine map
+    (scale, shift), each [Bp][C0+C1], for conv_forward(in_scale=, in_shift=).  No tangent."""
+    C = C0 + (C1 if x1 is not None else 0)
+    if x0.numel() != Bp * P * C0 or (x1 is not None and x1.numel() != Bp * P * C1) or gamma.numel() != C or beta.numel() != C:
+        raise MsgmError("groupnorm_affine: size mismatch")
+    scale = torch.empty(Bp * C, dtype=torch.float32, device=x0.device)
+    shift = torch.empty_like(scale)
+    ws = _gn_ws(Bp, G, x0.device)
+    check(lib().msgm_groupnorm_affine(ptr(f32(x0)), C0, ptr(x1), C1, ptr(f32(gamma)), ptr(f32(beta)), ptr(scale), ptr(shift),
+                                      Bp, P, G, float(eps), ptr(ws), ws.numel() * 8, stream()), "msgm_groupnorm_affine")
+    return scale, shift
 
 
 def conv_wgrad(geom: L.ConvGeomT, gy: torch.Tensor, src: torch.Tensor, C: int, koff: int, dWp: torch.Tensor, Cout: int,

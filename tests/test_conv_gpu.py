@@ -199,3 +199,54 @@ def test_colsum_rows():
         ops.add_row(xd, E.to(DEV), N, P, C, 0, -1.0)
         ref = x.clone(); ref[:, 0] -= E
         assert rel_l2(xd.cpu(), ref) <= 1e-6
+
+
+@pytest.mark.parametrize("N,C0,C1,Cout,H,W_,k,act,ups", [(3, 32, 0, 32, 16, 16, 3, 1, False), (2, 64, 32, 64, 8, 16, 3, 1, False),
+                                                         (2, 32, 0, 96, 1, 128, 1, 0, False), (2, 64, 0, 64, 8, 8, 3, 1, True)])
+def test_conv_fused_groupnorm_silu_input_and_residual(N, C0, C1, Cout, H, W_, k, act, ups):
+    """msgm_conv_forward_fused: GroupNorm(+SiLU) folded into the input staging (two sources = channel concat, folded
+    2x upsample) and the residual added in the epilogue, vs GroupNorm -> SiLU -> (upsample) -> conv -> + residual in
+    plain PyTorch fp32.  1e-5 rel-L2."""
+    from sdeflow_light_amd import ops
+    torch.manual_seed(C0 + C1 + H)
+    C = C0 + C1
+    G = min(C, 32)
+    x = torch.randn(N, C, H, W_) * 1.5 + 0.3
+    gam, bet = torch.randn(C) * 0.5 + 1.0, torch.randn(C) * 0.2
+    w, b = torch.randn(Cout, C, k if H > 1 else 1, k) * 0.1, torch.randn(Cout) * 0.1
+    Ho, Wo = (2 * H, 2 * W_) if ups else (H, W_)
+    res = torch.randn(N, Cout, Ho, Wo)
+    h = F.group_norm(x, G, gam, bet, 1e-5)
+    if act:
+        h = F.silu(h)
+    if ups:
+        h = F.interpolate(h, scale_factor=2, mode="nearest")
+    ref = F.conv2d(h, w, b, 1, ((k - 1) // 2 if H > 1 else 0, (k - 1) // 2)) + res
+    kk = (k, k) if H > 1 else (k,)
+    op = mk(w.reshape(Cout, C, -1) if H == 1 else w, b, "conv", kk, 1, (k - 1) // 2, [C0, C1] if C1 else [C0], ups=ups)
+    assert op.can_transform_input(N, H, W_)
+    x0 = cl2(x[:, :C0]).reshape(-1).to(DEV)
+    x1 = cl2(x[:, C0:]).reshape(-1).to(DEV) if C1 else None
+    sc, sh = ops.groupnorm_affine(x0, C0, gam.to(DEV), bet.to(DEV), N, H * W_, G, x1=x1, C1=C1)
+    xh = (x - x.reshape(N, G, -1).mean(2).repeat_interleave(C // G, 1)[:, :, None, None])       # check the affine itself
+    inv = 1.0 / torch.sqrt(x.reshape(N, G, -1).var(2, unbiased=False) + 1e-5).repeat_interleave(C // G, 1)
+    assert rel_l2(sc.view(N, C).cpu(), inv * gam) <= 1e-5
+    out, ho, wo = op.forward([x0] + ([x1] if C1 else []), N, H, W_, N, in_affine=(sc, sh), in_act=act,
+                             residual=cl2(res).reshape(-1).to(DEV))
+    assert (ho, wo) == (Ho, Wo)
+    assert rel_l2(out.view(N, Ho, Wo, Cout).cpu(), cl2(ref)) <= 1e-5
+
+
+def test_conv_input_transform_refused_where_not_built():
+    from sdeflow_light_amd import ops
+    from sdeflow_light_amd._lib import MsgmError
+    w, b = torch.randn(32, 32, 3, 3) * 0.1, None
+    op = mk(w, b, "conv", (3, 3), 2, 1, [32])                       # strided: not a halo-tile shape
+    assert not op.can_transform_input(2, 16, 16)
+    x = torch.randn(2 * 16 * 16 * 32, device=DEV)
+    ab = (torch.ones(2 * 32, device=DEV), torch.zeros(2 * 32, device=DEV))
+    with pytest.raises(MsgmError):
+        op.forward([x], 2, 16, 16, 2, in_affine=ab)
+    out, _, _ = op.forward([x], 2, 16, 16, 2, residual=torch.ones(2 * 8 * 8 * 32, device=DEV))    # residual works everywhere
+    ref, _, _ = op.forward([x], 2, 16, 16, 2)
+    assert rel_l2(out.cpu(), (ref + 1.0).cpu()) <= 1e-6

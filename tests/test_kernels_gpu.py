@@ -313,3 +313,49 @@ def test_mlp_em_sampler_golden(ops, L):
         ops.sde_stage(x2, x2, 1.0, x2, a, st, L.PROC_REVERSE, False, float(ts[i]), delta, 0.0, z=dev(z[i]))
     assert rel_l2(x2.cpu(), g["sgm_em_traj"][steps]) <= 1e-4
     assert rel_l2(x2.cpu(), x.cpu()) <= 1e-5
+
+
+# ---- BASELINE full size (C2: B = 65 536): size-independent properties ---------------------------------------------
+def test_c2_full_size_shard_equivalence_and_row_independence(ops, L):
+    """At the full C2 batch the oracle is too slow, so check what must hold at any size:
+    (i) data-parallel equivalence — the mean gradient of the full batch equals the average of the two half-batch
+        gradients and the per-sample losses are the concatenation (rows never interact; SURVEY §8e);
+    (ii) the sampler's rows are independent and its noise is addressed by (step, element): changing the second half
+        of the state leaves the first half of a 5-step Euler-Maruyama run bit-identical."""
+    from tests_util import mlp_shapes
+    from oracle.det_params import det_state_dict
+    torch.manual_seed(7)
+    B, d = 65536, 2
+    sp = S.SdeSpec()
+    p = det_state_dict(mlp_shapes(d, None))
+    P, keep = _mlp_P(ops, p, None)
+    t = S.clamp_time(sp, torch.rand(B, 1)).reshape(-1)
+    y = torch.randn(B, d) * 1.5
+    v = S.rademacher_from_uniform(torch.rand(B, d))
+    n = ops.mlp_num_params(d, False)
+    ws = ops.mlp_ssm_workspace(d, False, DEV)
+    st = sgm_struct(L)
+
+    def run(sl):
+        yy, tt, vv = dev(y[sl].contiguous()), dev(t[sl].contiguous()), dev(v[sl].contiguous())
+        grads, per, lsum = torch.empty(n, device=DEV), torch.empty(yy.shape[0], device=DEV), torch.empty(1, device=DEV)
+        ops.mlp_ssm_grad(P, yy, tt, vv, st, 1.0 / yy.shape[0], grads, ws, per, lsum)
+        return grads.cpu(), per.cpu(), float(lsum)
+
+    gf, pf, lf = run(slice(0, B))
+    g0, p0, l0 = run(slice(0, B // 2))
+    g1, p1, l1 = run(slice(B // 2, B))
+    assert torch.isfinite(gf).all() and torch.isfinite(pf).all()
+    assert torch.equal(pf, torch.cat([p0, p1]))                       # same per-row arithmetic wherever the row sits
+    assert rel_l2(0.5 * (g0 + g1), gf) <= 2e-5
+    assert 0.5 * (l0 + l1) == pytest.approx(lf, rel=1e-5)
+
+    ts = (torch.linspace(0, 1, 6) * 1.0).to(DEV)
+    rng = L.PhiloxState(99, torch.device(DEV))
+    xa = dev(torch.randn(B, d))
+    xb = xa.clone()
+    xb[B // 2:] = 3.0 * torch.randn(B // 2, d, device=DEV)
+    ops.mlp_em_loop(P, xa, st, ts, 0.2, 0.0, rng, 0)
+    ops.mlp_em_loop(P, xb, st, ts, 0.2, 0.0, rng, 0)
+    assert torch.isfinite(xa).all() and torch.isfinite(xb).all()
+    assert torch.equal(xa[: B // 2], xb[: B // 2]) and not torch.equal(xa[B // 2:], xb[B // 2:])

@@ -369,3 +369,19 @@ def test_unet_trainer_graph_replay_equals_eager(kind):
     for a, b in zip(out[False][0], out[True][0]):
         assert abs(a - b) <= 2e-4 * max(1.0, abs(a))     # later steps: float-atomics order feeds back through Adam
     assert rel_l2(out[True][1], out[False][1]) <= 2e-4
+
+
+def test_unet2d_sampler_forward_gn_fold_equals_unfused(monkeypatch):
+    """The no-tangent forward folds GroupNorm(+SiLU) into the consuming conv and the residual into its epilogue;
+    with MSGM_NO_GN_FOLD the separate GroupNorm kernels run.  Same net, same input: 2e-4 (whole network)."""
+    from sdeflow_light_amd.NNUnet import VorticityUNet
+    from oracle.det_params import load_det_
+    torch.manual_seed(4)
+    net = VorticityUNet(base_channels=32, channel_mults=(1, 2), num_res_blocks=2, in_space=16, attention_resolutions=(1, 2),
+                        flatten_order="F", premodule="NormalizeLogRadius").to(DEV)
+    load_det_(net.core)
+    x, t = torch.randn(5, 256, device=DEV), torch.rand(5, device=DEV)
+    fused = net(x, t).clone()
+    monkeypatch.setenv("MSGM_NO_GN_FOLD", "1")
+    plain = net(x, t)
+    assert rel_l2(fused.cpu(), plain.cpu()) <= 2e-4
