@@ -272,6 +272,37 @@ __device__ __forceinline__ void store_act(float* buf, int fb, int il, int q, con
 template <int KT, int IT, bool SWISH>
 __device__ __forceinline__ void wgrad_core(const float* zb, const float* hb, int hb_pitch, int fb, int il, int q,
                                            f32x4 (&dW)[IT][KT], const f32x4 (*z)[2], f32x4 (*g)[2]) {
+  if (KT * IT <= 4) {
+    // thin products (dW1, dW4: one or two MFMAs per step): a one-step-ahead pipeline would expose one LDS round trip
+    // per step (~8 x 130 cycles for 8 x 32 cycles of MFMA), so ALL operands are fetched first
+    float pa[8][IT], pb[8][KT];
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      const int n = (st >> 2) * 16 + 4 * (st & 3) + q;
+#pragma unroll
+      for (int it = 0; it < IT; ++it) pa[st][it] = zb[n * ACT_P + fb + 16 * it + il];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) pb[st][kt] = hb[n * hb_pitch + 16 * kt + il];
+    }
+    if (SWISH) {
+#pragma unroll
+      for (int st = 0; st < 4 * IT; ++st) {
+        const int it = st >> 2, r = st & 3;
+        float s0, s1, s2;
+        swish012(z[it][0][r], s0, s1, s2);
+        const float gt = g[it][1][r];
+        g[it][0][r] = g[it][0][r] * s1 + gt * (s2 * z[it][1][r]);
+        g[it][1][r] = gt * s1;
+      }
+    }
+#pragma unroll
+    for (int st = 0; st < 8; ++st)
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int it = 0; it < IT; ++it) dW[it][kt] = mfma16(pa[st][it], pb[st][kt], dW[it][kt]);
+    return;
+  }
   float na[IT], nb[KT];
   {
     const int n = q;
