@@ -170,6 +170,9 @@ __device__ __forceinline__ f32x4 load_afrag(wrsrc_t W, int fb, int il, int q, in
 #ifndef MLP_OVL_BWD
 #define MLP_OVL_BWD 1
 #endif
+#ifndef MLP_STAGGER
+#define MLP_STAGGER 1
+#endif
 struct WPre { f32x4 a[PF]; };     // fragments j = 0..PF-1 of the next gemm (j = it*8 + g: row tile 0 first)
 
 template <bool TR>
@@ -355,6 +358,21 @@ __device__ __forceinline__ void wgrad_core(const float* zb, const float* hb, int
     }
   }
 }
+// dual Swish backward in registers, in place: (gP,gT) cotangents of (hP,hT) -> cotangents of (zP,zT)
+template <int IT>
+__device__ __forceinline__ void swish_bwd_inplace(const f32x4 (&z)[IT][2], f32x4 (&g)[IT][2]) {
+#pragma unroll
+  for (int it = 0; it < IT; ++it)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float s0, s1, s2;
+      swish012(z[it][0][r], s0, s1, s2);
+      const float gt = g[it][1][r];
+      g[it][0][r] = g[it][0][r] * s1 + gt * (s2 * z[it][1][r]);
+      g[it][1][r] = gt * s1;
+    }
+}
+
 template <int KT, int IT>
 __device__ __forceinline__ void wgrad(const float* zb, const float* hb, int hb_pitch, int fb, int il, int q, f32x4 (&dW)[IT][KT]) {
   wgrad_core<KT, IT, false>(zb, hb, hb_pitch, fb, il, q, dW, nullptr, nullptr);
@@ -553,6 +571,10 @@ __global__ void __launch_bounds__(64 * NW, 1) k_mlp(MlpArgs A) {
   const int64_t n_tiles = (A.B + SPT - 1) / SPT;
   const float ca = 1.0f - 0.5f * A.lmbd;
   int cur = 0;      // parity of the tile: selects the h0 / raw buffers and which of X / Y holds h1
+  // Waves w and w + NW/2 share a SIMD and would otherwise walk through the backward phases in lockstep (both in their
+  // LDS-latency head, both in their VALU tail).  The second one runs its weight-gradient product BEFORE its dgrad, so
+  // one wave's heads and tails fall under the other's MFMAs.
+  const bool late = MLP_STAGGER && NW == 8 && w >= NW / 2;
 
   // Work items are (step, tile) with the tile index fastest; training / forward / single-step EM have one step.
   // EM loop (n_steps > 1): rows never interact (sde_scheme.py:82-86), so a workgroup takes its tiles through ALL
@@ -721,9 +743,16 @@ __global__ void __launch_bounds__(64 * NW, 1) k_mlp(MlpArgs A) {
       // ---- phase 6: dgrad layer 3 (W3^T), dW3, Swish' on layer 2 -----------
 #pragma unroll
       for (int it = 0; it < IT; ++it) { g[it][0] = f32x4{0, 0, 0, 0}; g[it][1] = f32x4{0, 0, 0, 0}; }
-      gemm128<true, 0, IT>(R3, pre, U, fb, il, q, g, nullptr, h);
-      prefetch_w<true>(R2, fb, il, q, pre);          // W2^T for the next dgrad
-      wgrad_swish<8, IT>(U, Yc, ACT_P, fb, il, q, dW3, z2, g);
+      if (!late) {
+        gemm128<true, 0, IT>(R3, pre, U, fb, il, q, g, nullptr, h);
+        prefetch_w<true>(R2, fb, il, q, pre);        // W2^T for the next dgrad
+        wgrad_swish<8, IT>(U, Yc, ACT_P, fb, il, q, dW3, z2, g);
+      } else {                                         // the SIMD's other wave: weight gradient first (it only needs
+        wgrad<8, IT>(U, Yc, ACT_P, fb, il, q, dW3);    // this wave's zbar3 columns), dgrad second, Swish' last
+        gemm128<true, 0, IT>(R3, pre, U, fb, il, q, g, nullptr, h);
+        prefetch_w<true>(R2, fb, il, q, pre);
+        swish_bwd_inplace<IT>(z2, g);
+      }
 #pragma unroll
       for (int it = 0; it < IT; ++it) db2[it] += g[it][0];
       store_act<IT>(Z, fb, il, q, g);                      // h3 is dead after phase 5
@@ -733,9 +762,16 @@ __global__ void __launch_bounds__(64 * NW, 1) k_mlp(MlpArgs A) {
       // ---- phase 7: dgrad layer 2 (W2^T), dW2, Swish' on layer 1 -----------
 #pragma unroll
       for (int it = 0; it < IT; ++it) { g[it][0] = f32x4{0, 0, 0, 0}; g[it][1] = f32x4{0, 0, 0, 0}; }
-      gemm128<true, 0, IT>(R2, pre, Z, fb, il, q, g, nullptr, h);
-      prefetch_w<false>(R2, fb, il, q, pre);         // next tile's layer 2
-      wgrad_swish<8, IT>(Z, Xc, ACT_P, fb, il, q, dW2, z1, g);
+      if (!late) {
+        gemm128<true, 0, IT>(R2, pre, Z, fb, il, q, g, nullptr, h);
+        prefetch_w<false>(R2, fb, il, q, pre);       // next tile's layer 2
+        wgrad_swish<8, IT>(Z, Xc, ACT_P, fb, il, q, dW2, z1, g);
+      } else {
+        wgrad<8, IT>(Z, Xc, ACT_P, fb, il, q, dW2);
+        gemm128<true, 0, IT>(R2, pre, Z, fb, il, q, g, nullptr, h);
+        prefetch_w<false>(R2, fb, il, q, pre);
+        swish_bwd_inplace<IT>(z1, g);
+      }
 #pragma unroll
       for (int it = 0; it < IT; ++it) db1[it] += g[it][0];
       store_act<IT>(U, fb, il, q, g);                      // zbar3 is dead after phase 6
