@@ -325,7 +325,8 @@ int msgm_unpack_weight(float* dW, const float* dWp, int32_t rows, int32_t ncols,
                        int32_t accumulate, msgm_stream_t stream);
 
 /* One launch for every (un)pack job of a network.  `jobs` is a DEVICE array; job j copies
- * Wp[t][r][kp_off+c] <- W[r*sr + (col_off+c)*sc + t*st] (unpack != 0: the other way, overwriting W).  The
+ * Wp[t][r][kp_off+c] <- W[r*sr + (col_off+c)*sc + t*st] (unpack != 0: the other way, overwriting W, or adding
+ * atomically when the job's `reserved` field is 1).  The
  * table is static as long as the parameter buckets and packed images do not move. */
 typedef struct {
   float* W; float* Wp;

@@ -14,6 +14,8 @@ backward.
 """
 from __future__ import annotations
 
+import os
+
 from typing import Optional
 
 import torch
@@ -22,7 +24,7 @@ import torch.nn as nn
 from . import ops
 from ._lib import MsgmError
 from .NN import FlatParamMixin, NormalizeLogRadius
-from .convnet import ConvOp, ConvOpSet
+from .convnet import ConvOp, ConvOpSet, Stride2PairOp
 
 GELU = ops.ACT_GELU
 
@@ -74,6 +76,10 @@ class UNet1D(nn.Module, FlatParamMixin):
         if self._ops is not None and self._ops["t0"].weight is first and self._ops["t0"].Wp.device == first.device:
             return self._ops
         E, chs = self.emb_dim, self.chs
+        # Downsample / Upsample (k=4, s=2, p=1) as 3-tap stride-1 convs over position PAIRS (convnet.Stride2PairOp):
+        # needs an even length at every level and channel counts that are multiples of 16
+        paired = (self.input_dim % (1 << len(chs)) == 0 and all(c % 16 == 0 for c in chs)
+                  and not os.environ.get("MSGM_NO_PAIRED_STRIDE"))
         o = {"t0": ConvOp(self.time_mlp[0].weight, self.time_mlp[0].bias, "linear", (1,), 1, 0, [1]),
              "t2": ConvOp(self.time_mlp[2].weight, self.time_mlp[2].bias, "linear", (1,), 1, 0, [E])}
         if self.scale_embed is not None:
@@ -84,13 +90,15 @@ class UNet1D(nn.Module, FlatParamMixin):
             b = self.enc_blocks[i].net
             o[f"e{i}a"] = ConvOp(b[0].weight, b[0].bias, "conv", (3,), 1, 1, [cin], emb_channels=E)
             o[f"e{i}b"] = ConvOp(b[2].weight, b[2].bias, "conv", (3,), 1, 1, [c])
-            o[f"d{i}"] = ConvOp(self.downs[i].weight, self.downs[i].bias, "conv", (4,), 2, 1, [c])
+            o[f"d{i}"] = (Stride2PairOp(self.downs[i].weight, self.downs[i].bias, "conv") if paired
+                          else ConvOp(self.downs[i].weight, self.downs[i].bias, "conv", (4,), 2, 1, [c]))
             cin = c
         m = self.middle.net
         o["ma"] = ConvOp(m[0].weight, m[0].bias, "conv", (3,), 1, 1, [cin], emb_channels=E)
         o["mb"] = ConvOp(m[2].weight, m[2].bias, "conv", (3,), 1, 1, [cin])
         for i, c in enumerate(reversed(chs)):
-            o[f"u{i}"] = ConvOp(self.up_convs[i].weight, self.up_convs[i].bias, "convT", (4,), 2, 1, [cin])
+            o[f"u{i}"] = (Stride2PairOp(self.up_convs[i].weight, self.up_convs[i].bias, "convT") if paired
+                          else ConvOp(self.up_convs[i].weight, self.up_convs[i].bias, "convT", (4,), 2, 1, [cin]))
             b = self.dec_blocks[i].net
             o[f"x{i}a"] = ConvOp(b[0].weight, b[0].bias, "conv", (3,), 1, 1, [c, c], emb_channels=E)
             o[f"x{i}b"] = ConvOp(b[2].weight, b[2].bias, "conv", (3,), 1, 1, [c])

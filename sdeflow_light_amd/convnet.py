@@ -38,17 +38,16 @@ class ConvOpSet:
     def __init__(self, ops_list: List["ConvOp"]):
         self.ops = list(ops_list)
         dev = self.ops[0].weight.device
-        sizes = []
-        for o in self.ops:
-            sizes.append(o.dWp.numel())
-            if o.embC:
-                sizes.append(o.dWpE.numel())
-        self.gimg = torch.zeros(sum(sizes), device=dev)
+        names = ("dWp", "dWpE", "dbias_i")                       # every gradient image an op accumulates into
+        total = sum(getattr(o, a).numel() for o in self.ops for a in names if getattr(o, a, None) is not None)
+        self.gimg = torch.zeros(total, device=dev)
         off = 0
         for o in self.ops:
-            n = o.dWp.numel(); o.dWp = self.gimg[off:off + n]; off += n
-            if o.embC:
-                n = o.dWpE.numel(); o.dWpE = self.gimg[off:off + n]; off += n
+            for a in names:
+                t = getattr(o, a, None)
+                if t is not None:
+                    n = t.numel()
+                    setattr(o, a, self.gimg[off:off + n]); off += n
         self._pack = self._unpack = None
         self._pack_sig = self._unpack_sig = None
 
@@ -304,3 +303,136 @@ class ConvOp:
         gup = torch.empty(N * 4 * Hi * Wi * C, device=dev)
         ops.conv_forward(gd, gy, self.Cout, self.Wd[0], C, gup, CoutP=pad16(C))
         return ops.sum2x2(gup, N, Hi, Wi, C)
+
+
+class Stride2PairOp:
+    """Conv1d(k=4, s=2, p=1) / ConvTranspose1d(k=4, s=2, p=1) — the 1-D U-Net's Downsample / Upsample
+    (NNUnet1D.py:84,98) — run on the stride-1 halo-tile kernels.
+
+    In channels-last memory two neighbouring positions (2j, 2j+1) of C channels ARE one position of 2C channels, so
+    a reinterpretation (no copy) turns the stride-2 conv into a 3-tap stride-1 "same" conv over pairs:
+        out[o] = W0 x[2o-1] + W1 x[2o] + W2 x[2o+1] + W3 x[2o+2]
+               = [0 | W0] xp[o-1] + [W1 | W2] xp[o] + [W3 | 0] xp[o+1],     xp[j] = [x[2j] | x[2j+1]],
+    and the transposed conv into a 3-tap conv whose OUTPUT is pairs:
+        [out[2j] | out[2j+1]] = [W3 | 0] x[j-1] + [W1 | W2] x[j] + [0 | W0] x[j+1].
+    Two of the six (tap, half) weight blocks are zero (1.5x the FLOPs), but forward, dgrad and wgrad all become
+    shapes the LDS-tiled kernels serve (measured: the strided implicit GEMM ran these layers at ~40 TFLOP/s, the tile
+    kernels at ~90).  Same interface as ConvOp (forward / backward / pack_jobs / unpack_jobs); L must be even.
+    Blocks (tap t, half) -> original tap k:  conv: (0,1)->0 (1,0)->1 (1,1)->2 (2,0)->3;  convT: (0,0)->3 (1,0)->1
+    (1,1)->2 (2,1)->0."""
+
+    BLOCKS = {"conv": ((0, 1, 0), (1, 0, 1), (1, 1, 2), (2, 0, 3)), "convT": ((0, 0, 3), (1, 0, 1), (1, 1, 2), (2, 1, 0))}
+
+    def __init__(self, weight: torch.nn.Parameter, bias: Optional[torch.nn.Parameter], kind: str):
+        if kind not in ("conv", "convT") or weight.shape[2] != 4:
+            raise MsgmError("Stride2PairOp is Conv1d / ConvTranspose1d with k=4, s=2, p=1")
+        self.weight, self.bias, self.kind = weight, bias, kind
+        if kind == "conv":
+            self.Cout, self.C = weight.shape[0], weight.shape[1]
+            self.cin_i, self.cout_i = 2 * self.C, self.Cout                 # inner conv: pairs in
+        else:
+            self.C, self.Cout = weight.shape[0], weight.shape[1]
+            self.cin_i, self.cout_i = self.C, 2 * self.Cout                 # inner conv: pairs out
+        if self.C % 16 or self.Cout % 16:
+            raise MsgmError("Stride2PairOp needs channel counts that are multiples of 16")
+        dev = weight.device
+        self.embC, self.srcC = 0, [self.C]
+        self.CoutP, self.Ktot = pad16(self.cout_i), pad16(self.cin_i)
+        self.Wp = torch.zeros(3 * self.CoutP * self.Ktot, device=dev)              # forward image of the inner conv
+        self.dWp = torch.zeros_like(self.Wp)
+        self.Wd = torch.zeros(3 * pad16(self.cin_i) * pad16(self.cout_i), device=dev)    # dgrad image
+        self.bias_i = torch.zeros(self.cout_i, device=dev) if bias is not None else None   # convT: [b | b]
+        self.dbias_i = torch.zeros(self.cout_i, device=dev) if (bias is not None and kind == "convT") else None
+        self._bias_zeroed = False
+
+    # ---- geometry
+    def out_hw(self, Hi, Wi):
+        return 1, (Wi // 2 if self.kind == "conv" else 2 * Wi)
+
+    def _inner(self, N, Wi):
+        if self.kind == "conv" and Wi % 2:
+            raise MsgmError("Stride2PairOp: odd length (use the generic ConvOp)")
+        Lp = Wi // 2 if self.kind == "conv" else Wi                                     # positions of the inner conv
+        return ops.conv_geom(N, 1, Lp, 1, Lp, 1, 3, 1, 1, 0, 0), Lp
+
+    # ---- weight images
+    def _jobs(self, Wt, img_f, img_d, bias_t, bias_img):
+        """(un)pack jobs between a tensor in the weight's PyTorch layout and the inner conv's images."""
+        jobs = []
+        C, Co = self.C, self.Cout
+        if self.kind == "conv":                       # W (Cout, Cin, 4): (co, ci, k) at co*Cin*4 + ci*4 + k
+            for t, half, k in self.BLOCKS["conv"]:
+                if img_f is not None:
+                    jobs.append((Wt, k, img_f[t * self.CoutP * self.Ktot:], Co, C, 0, 1, C * 4, 4, 1, self.CoutP, self.Ktot, half * C))
+                if img_d is not None:                 # rows = inner input channel (half*C + ci), K = co
+                    rp, kt = pad16(self.cin_i), pad16(self.cout_i)
+                    jobs.append((Wt, k, img_d[(t * rp + half * C) * kt:], C, Co, 0, 1, 4, C * 4, 1, C, kt, 0))
+        else:                                         # W (Cin, Cout, 4): (ci, co, k) at ci*Cout*4 + co*4 + k
+            for t, half, k in self.BLOCKS["convT"]:
+                if img_f is not None:                 # rows = inner output channel (half*Cout + co), K = ci
+                    jobs.append((Wt, k, img_f[(t * self.CoutP + half * Co) * self.Ktot:], Co, C, 0, 1, 4, Co * 4, 1, Co, self.Ktot, 0))
+                if img_d is not None:                 # rows = ci, K = inner output channel
+                    rp, kt = pad16(self.cin_i), pad16(self.cout_i)
+                    jobs.append((Wt, k, img_d[t * rp * kt:], C, Co, 0, 1, Co * 4, 4, 1, rp, kt, half * Co))
+        if bias_t is not None and bias_img is not None and self.kind == "convT":
+            for half in (0, 1):
+                jobs.append((bias_t, 0, bias_img[half * Co:], 1, Co, 0, 1, 0, 1, 1, 1, Co, 0))
+        return jobs
+
+    def pack_jobs(self):
+        return self._jobs(self.weight.detach(), self.Wp, self.Wd, self.bias.detach() if self.bias is not None else None,
+                          self.bias_i)
+
+    def unpack_jobs(self):
+        """Gradient images -> .grad (weight; convT bias: the two halves are ADDED into the zeroed bias.grad)."""
+        jobs = self._jobs(self.weight.grad, self.dWp, None, None, None)
+        if self.dbias_i is not None:
+            for half in (0, 1):
+                jobs.append((self.bias.grad, 0, self.dbias_i[half * self.Cout:], 1, self.Cout, 0, 1, 0, 1, 1, 1, self.Cout, 0, True))
+        return jobs
+
+    def pack(self):
+        ops.PackTable(self.pack_jobs(), self.weight.device).run(False)
+
+    def zero_grad_images(self):
+        self.dWp.zero_()
+        if self.dbias_i is not None:
+            self.dbias_i.zero_()
+
+    def unpack_grads(self):
+        ops.PackTable(self.unpack_jobs(), self.weight.device).run(True)
+
+    # ---- forward / backward (ConvOp's interface)
+    def forward(self, srcs, N, Hi, Wi, n_bias, out=None, accumulate=False, **_):
+        geom, Lp = self._inner(N, Wi)
+        _, Lo = self.out_hw(Hi, Wi)
+        if out is None:
+            out = torch.empty(N * Lo * self.Cout, device=srcs[0].device)
+        b = None if self.bias is None else (self.bias.detach() if self.kind == "conv" else self.bias_i)
+        ops.conv_forward(geom, srcs[0], self.cin_i, self.Wp, self.cout_i, out, bias=b, n_bias=n_bias, accumulate=accumulate,
+                         CoutP=self.CoutP)
+        return out, 1, Lo
+
+    def backward(self, gy, srcs, N, Hi, Wi, n_bias, need=None, dsrc=None, dacc=None, bias_grad_zeroed=False, **_):
+        geom, Lp = self._inner(N, Wi)
+        zeroed = bias_grad_zeroed or self._bias_zeroed
+        self._bias_zeroed = False
+        db = None
+        if self.bias is not None:
+            if self.kind == "conv":
+                if not zeroed:
+                    self.bias.grad.zero_()
+                db = self.bias.grad.view(-1)
+            else:
+                if not zeroed:
+                    self.bias.grad.zero_()
+                    self.dbias_i.zero_()
+                db = self.dbias_i
+        ops.conv_wgrad(geom, gy, srcs[0], self.cin_i, 0, self.dWp, self.cout_i, self.CoutP, self.Ktot, dbias=db, n_bias=n_bias)
+        if need is not None and not need[0]:
+            return [None]
+        d = dsrc[0] if (dsrc is not None and dsrc[0] is not None) else torch.empty(N * Wi * self.C, device=gy.device)
+        gd = ops.conv_geom(N, 1, Lp, 1, Lp, 1, 3, 1, 1, 1, 0)                    # transposed gather of the inner conv
+        ops.conv_forward(gd, gy, self.cout_i, self.Wd, self.cin_i, d, accumulate=bool(dacc[0]) if dacc is not None else False,
+                         CoutP=pad16(self.cin_i))
+        return [d]

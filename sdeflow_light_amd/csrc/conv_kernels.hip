@@ -1027,7 +1027,9 @@ __global__ void __launch_bounds__(256) k_pack_batched(const msgm_pack_job_t* __r
     const int t = (int)(e / ((int64_t)J.ncols * J.rows));
     float* w = J.W + r * J.sr + (J.col_off + c) * J.sc + t * J.st;
     float* p = J.Wp + ((int64_t)t * J.rowsP + r) * J.Ktot + J.kp_off + c;
-    if (unpack) *w = *p; else *p = *w;
+    if (!unpack) *p = *w;
+    else if (J.reserved) atomicAdd(w, *p);               // several images fold into one parameter (paired-stride bias)
+    else *w = *p;
   }
 }
 

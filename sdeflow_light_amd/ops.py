@@ -356,12 +356,14 @@ class PackTable:
         import ctypes as C
         arr = (L.PackJobT * len(jobs))()
         self.keep = []
-        for i, (W, w_off, Wp, rows, ncols, col_off, taps, sr, sc, st, rowsP, Ktot, kp_off) in enumerate(jobs):
+        for i, job in enumerate(jobs):
+            W, w_off, Wp, rows, ncols, col_off, taps, sr, sc, st, rowsP, Ktot, kp_off = job[:13]
+            acc = int(bool(job[13])) if len(job) > 13 else 0          # unpack only: add (atomically) instead of overwrite
             need = w_off + (rows - 1) * sr + (col_off + ncols - 1) * sc + (taps - 1) * st + 1
             if need > W.numel() or Wp.numel() < taps * rowsP * Ktot or kp_off + ncols > Ktot or rowsP < rows:
                 raise MsgmError("pack table: job out of range")
             arr[i] = L.PackJobT(ptr(f32(W)) + 4 * w_off, ptr(f32(Wp)), sr, sc, st, rows, ncols, col_off, taps, rowsP, Ktot,
-                                kp_off, 0)
+                                kp_off, acc)
             self.keep.append((W, Wp))
         raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
         self.table = raw.to(device)

@@ -250,3 +250,40 @@ def test_conv_input_transform_refused_where_not_built():
     out, _, _ = op.forward([x], 2, 16, 16, 2, residual=torch.ones(2 * 8 * 8 * 32, device=DEV))    # residual works everywhere
     ref, _, _ = op.forward([x], 2, 16, 16, 2)
     assert rel_l2(out.cpu(), (ref + 1.0).cpu()) <= 1e-6
+
+
+@pytest.mark.parametrize("kind,N,Cin,Cout,L", [("conv", 3, 32, 32, 128), ("conv", 2, 64, 64, 256), ("conv", 2, 128, 128, 34),
+                                               ("convT", 3, 128, 128, 128), ("convT", 2, 64, 32, 256), ("convT", 2, 32, 64, 17)])
+def test_stride2_pair_op_fwd_bwd(kind, N, Cin, Cout, L):
+    """Downsample / Upsample of the 1-D U-Net (k=4, s=2, p=1; NNUnet1D.py:84,98) re-expressed as 3-tap stride-1 convs
+    over position pairs (convnet.Stride2PairOp) vs plain PyTorch fp32: forward (incl. tangent rows without bias),
+    dgrad, wgrad and the bias gradient.  Small L exercises the generic kernels, large L the LDS-tiled ones."""
+    from sdeflow_light_amd.convnet import Stride2PairOp
+    torch.manual_seed(Cin + Cout + L)
+    x = torch.randn(N, Cin, L, requires_grad=True)
+    W = torch.randn(*((Cout, Cin, 4) if kind == "conv" else (Cin, Cout, 4))) * 0.2
+    b = torch.randn(Cout) * 0.1
+    Wt, bt = W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    f = (lambda xx, ww, bb: F.conv1d(xx, ww, bb, stride=2, padding=1)) if kind == "conv" else \
+        (lambda xx, ww, bb: F.conv_transpose1d(xx, ww, bb, stride=2, padding=1))
+    y = f(x, Wt, bt)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    w, bp = torch.nn.Parameter(W.to(DEV)), torch.nn.Parameter(b.to(DEV))
+    w.grad, bp.grad = torch.zeros_like(w), torch.zeros_like(bp)
+    op = Stride2PairOp(w, bp, kind)
+    op.pack()
+    op.zero_grad_images()
+    xs = cl1(x.detach()).to(DEV).reshape(-1)
+    out, _, Lo = op.forward([xs], N, 1, L, n_bias=N)
+    assert Lo == y.shape[-1]
+    assert rel_l2(out.view(N, Lo, Cout).cpu(), cl1(y.detach())) <= 1e-5
+    (dx,) = op.backward(cl1(gy).to(DEV).reshape(-1), [xs], N, 1, L, n_bias=N)
+    assert rel_l2(dx.view(N, L, Cin).cpu(), cl1(x.grad)) <= 1e-5
+    op.unpack_grads()
+    assert rel_l2(op.weight.grad.cpu(), Wt.grad) <= 1e-5
+    assert rel_l2(op.bias.grad.cpu(), bt.grad) <= 1e-5
+    out2, _, _ = op.forward([torch.cat([xs, xs])], 2 * N, 1, L, n_bias=N)          # tangent rows: no bias
+    o2 = out2.view(2 * N, Lo, Cout).cpu()
+    assert rel_l2(o2[:N], cl1(y.detach())) <= 1e-5
+    assert rel_l2(o2[N:], cl1(f(x.detach(), W, None))) <= 1e-5
