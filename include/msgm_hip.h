@@ -299,6 +299,11 @@ typedef struct {
   const float* in_shift;
   int32_t in_act;
   int32_t reserved;
+  /* structurally-zero weight blocks the halo-tile kernel may skip (ignored by the other kernels, whose packed
+   * weights hold the zeros): bit t = tap t present; 0 = all taps.  tapmask_in[i]: i-th 32-channel input chunk
+   * (flattened over the sources); tapmask_out[y]: y-th output-channel block of 32 (CoutP % 64 != 0) or 64. */
+  uint16_t tapmask_in[16];
+  uint16_t tapmask_out[8];
 } msgm_conv_fuse_t;
 int msgm_conv_input_transform_supported(const msgm_conv_geom_t* geom, int32_t C0, int32_t C1, int32_t CoutP);
 int msgm_conv_forward_fused(const msgm_conv_geom_t* geom, const float* src0, int32_t C0, const float* src1, int32_t C1,
@@ -309,10 +314,13 @@ int msgm_conv_forward_fused(const msgm_conv_geom_t* geom, const float* src0, int
 /* dWp[tap][co][koff + c] += sum_m gy[m][co] in[src(m,tap)][c] (float atomics across
  * position chunks; zero dWp first).  One call per concatenated source.
  * dbias (may be NULL): dbias[co] += sum over the primal rows n < n_bias and all pixels of gy — the bias gradient
- * (torch: conv backward's grad_bias) as a by-product of the tiles the kernel stages anyway; zero it first. */
+ * (torch: conv backward's grad_bias) as a by-product of the tiles the kernel stages anyway; zero it first.
+ * tapmask_c32 / tapmask_co32 (HOST arrays, may be NULL): per 32-channel block of the input / output channels, bit t =
+ * tap t of that block is a real weight (0 = all); blocks that are structurally zero are not computed (the tile
+ * kernel only — their dWp entries are then left untouched). */
 int msgm_conv_wgrad(const msgm_conv_geom_t* geom, const float* gy, const float* src, int32_t C, int32_t koff,
                     float* dWp, int32_t Cout, int32_t CoutP, int32_t Ktot, float* dbias, int32_t n_bias,
-                    msgm_stream_t stream);
+                    const uint16_t* tapmask_c32, const uint16_t* tapmask_co32, msgm_stream_t stream);
 
 /* Wp[t][r][kp_off + c] = W[r*sr + (col_off + c)*sc + t*st] for r < rows, c < ncols
  * (strides in elements: any of the PyTorch layouts (Cout,Cin,k), (Cin,Cout,k) and

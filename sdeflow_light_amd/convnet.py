@@ -344,6 +344,19 @@ class Stride2PairOp:
         self.bias_i = torch.zeros(self.cout_i, device=dev) if bias is not None else None   # convT: [b | b]
         self.dbias_i = torch.zeros(self.cout_i, device=dev) if (bias is not None and kind == "convT") else None
         self._bias_zeroed = False
+        # taps present per half of the paired channel axis (bit t = tap t): the tile kernels skip the zero blocks
+        half_taps = [0, 0]
+        for t, half, _ in self.BLOCKS[kind]:
+            half_taps[half] |= 1 << t
+        nch = 2 * (self.C if kind == "conv" else self.Cout)                 # the paired axis: 2C in / 2Cout out
+        per_half = nch // 2
+
+        def masks(block):                                                   # one mask per `block` channels of the axis
+            if per_half % block:
+                return None                                                 # a block straddles the halves: keep all taps
+            return [half_taps[(i * block) // per_half] for i in range(nch // block)]
+        self.mask32 = masks(32)                                             # per 32-channel input chunk
+        self.mask_ob = masks(64 if pad16(nch) % 64 == 0 else 32)            # per output-channel block of the tile kernel
 
     # ---- geometry
     def out_hw(self, Hi, Wi):
@@ -410,7 +423,8 @@ class Stride2PairOp:
             out = torch.empty(N * Lo * self.Cout, device=srcs[0].device)
         b = None if self.bias is None else (self.bias.detach() if self.kind == "conv" else self.bias_i)
         ops.conv_forward(geom, srcs[0], self.cin_i, self.Wp, self.cout_i, out, bias=b, n_bias=n_bias, accumulate=accumulate,
-                         CoutP=self.CoutP)
+                         CoutP=self.CoutP, tapmask_in=self.mask32 if self.kind == "conv" else None,
+                         tapmask_out=self.mask_ob if self.kind == "convT" else None)
         return out, 1, Lo
 
     def backward(self, gy, srcs, N, Hi, Wi, n_bias, need=None, dsrc=None, dacc=None, bias_grad_zeroed=False, **_):
@@ -428,11 +442,14 @@ class Stride2PairOp:
                     self.bias.grad.zero_()
                     self.dbias_i.zero_()
                 db = self.dbias_i
-        ops.conv_wgrad(geom, gy, srcs[0], self.cin_i, 0, self.dWp, self.cout_i, self.CoutP, self.Ktot, dbias=db, n_bias=n_bias)
+        ops.conv_wgrad(geom, gy, srcs[0], self.cin_i, 0, self.dWp, self.cout_i, self.CoutP, self.Ktot, dbias=db, n_bias=n_bias,
+                       tapmask_c32=self.mask32 if self.kind == "conv" else None,
+                       tapmask_co32=self.mask32 if self.kind == "convT" else None)
         if need is not None and not need[0]:
             return [None]
         d = dsrc[0] if (dsrc is not None and dsrc[0] is not None) else torch.empty(N * Wi * self.C, device=gy.device)
         gd = ops.conv_geom(N, 1, Lp, 1, Lp, 1, 3, 1, 1, 1, 0)                    # transposed gather of the inner conv
         ops.conv_forward(gd, gy, self.cout_i, self.Wd, self.cin_i, d, accumulate=bool(dacc[0]) if dacc is not None else False,
-                         CoutP=pad16(self.cin_i))
+                         CoutP=pad16(self.cin_i), tapmask_in=self.mask32 if self.kind == "convT" else None,
+                         tapmask_out=self.mask_ob if self.kind == "conv" else None)
         return [d]

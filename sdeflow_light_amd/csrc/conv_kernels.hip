@@ -52,6 +52,10 @@ struct ConvArgs {
   const float* in_scale;      // [N][Ctot] or null, Ctot = sum of the sources' channels
   const float* in_shift;      // [N][Ctot]
   int in_act;                 // 0 none, 1 SiLU
+  // structurally-zero weight blocks (halo-tile kernel): bit t of a mask = tap t is present; 0 = all taps.
+  // tapmask_in[i]: per 32-channel input chunk (flattened over the sources), tapmask_out[y]: per output-channel block
+  unsigned short tapmask_in[16];
+  unsigned short tapmask_out[8];
 };
 
 // input coordinate of output coordinate o for tap k; returns false when the tap falls outside
@@ -347,22 +351,32 @@ __global__ void __launch_bounds__(256) k_conv_tile(ConvArgs A, int flip, int til
     const int c0 = cc * CT_KC;
     const int ngrp = (C - c0 >= CT_KC) ? 2 : ((C - c0 + 15) >> 4);
     const float* wbase = A.Wp + (size_t)(co0 + il) * A.Ktot + A.koff[cs] + c0 + 4 * q;
-    const int npairs = taps * ngrp;
+    // taps whose weight block is structurally zero for this (input chunk, output block) are skipped (Stride2PairOp)
+    unsigned tmask = (1u << taps) - 1u;
+    {
+      const int chunk_flat = (cs ? nch[0] : 0) + cc;
+      const unsigned mi = chunk_flat < 16 ? A.tapmask_in[chunk_flat] : 0u, mo = blockIdx.y < 8 ? A.tapmask_out[blockIdx.y] : 0u;
+      if (mi) tmask &= mi;
+      if (mo) tmask &= mo;
+    }
+    auto next_tap = [&](int t) { const unsigned rem = tmask & ~((2u << t) - 1u); return rem ? __ffs(rem) - 1 : taps; };
+    const int tap0 = tmask ? __ffs(tmask) - 1 : taps;
+    const int npairs = __popc(tmask) * ngrp;
     // weight fragments are fetched WD (tap, group) pairs ahead (one pair = 8*NCO MFMAs = 256*NCO cycles of matrix
     // pipe).  WD = 2 for the narrow variant measured no gain (3-4 resident waves per SIMD already cover the L2 hit).
     constexpr int WD = 1;
     f32x4 an[WD][NCO];
-    int ftap = 0, fgrp = 0;                // next pair to fetch
+    int ftap = tap0, fgrp = 0;             // next pair to fetch
 #pragma unroll
     for (int d = 0; d < WD; ++d) {
       if (d < npairs) {
         const float* wp = wbase + (size_t)ftap * A.CoutP * A.Ktot + 16 * fgrp;
 #pragma unroll
         for (int c = 0; c < NCO; ++c) an[d][c] = *reinterpret_cast<const f32x4*>(wp + c * a_co_stride);
-        if (++fgrp == ngrp) { fgrp = 0; ++ftap; }
+        if (++fgrp == ngrp) { fgrp = 0; ftap = next_tap(ftap); }
       }
     }
-    int tap = 0, grp = 0;
+    int tap = tap0, grp = 0;
     for (int pr = 0; pr < npairs; ++pr) {
       f32x4 a[NCO];
 #pragma unroll
@@ -372,12 +386,12 @@ __global__ void __launch_bounds__(256) k_conv_tile(ConvArgs A, int flip, int til
 #pragma unroll
         for (int c = 0; c < NCO; ++c) an[d][c] = an[d + 1][c];
       int ntap = tap, ngr = grp + 1;
-      if (ngr == ngrp) { ngr = 0; ++ntap; }
+      if (ngr == ngrp) { ngr = 0; ntap = next_tap(tap); }
       if (pr + WD < npairs) {
         const float* wp = wbase + (size_t)ftap * A.CoutP * A.Ktot + 16 * fgrp;
 #pragma unroll
         for (int c = 0; c < NCO; ++c) an[WD - 1][c] = *reinterpret_cast<const f32x4*>(wp + c * a_co_stride);
-        if (++fgrp == ngrp) { fgrp = 0; ++ftap; }
+        if (++fgrp == ngrp) { fgrp = 0; ftap = next_tap(ftap); }
       }
       const int kh = tap / KW, kw = tap - kh * KW;
       const int oy = flip ? (KH - 1 - kh) : kh, ox = flip ? (KW - 1 - kw) : kw;
@@ -450,6 +464,8 @@ struct WgradArgs {
   int chunk;                  // output positions per workgroup
   float* dbias;               // optional: dbias[co] += sum over primal rows (n < n_bias) and pixels of gy (tile kernel)
   int n_bias;
+  // structurally-zero weight blocks (tile kernel): bit t = tap t present, 0 = all; per 32-channel block of c / of co
+  unsigned short tm_c[16], tm_o[16];
 };
 
 // One workgroup = one (position chunk, tap, co block of 16*MT, c block of 16*KT).
@@ -619,6 +635,9 @@ __global__ void __launch_bounds__(256) k_wgrad_tile(WgradArgs A, int tiles_x, in
     }
   };
 
+  unsigned tmask = (1u << TAPS) - 1u;
+  if (cblk < 16 && A.tm_c[cblk]) tmask &= A.tm_c[cblk];
+  if (coblk < 16 && A.tm_o[coblk]) tmask &= A.tm_o[coblk];
   const bool do_bias = A.dbias != nullptr && cblk == 0;
   const int tiles_per_sample = tiles_x * tiles_y;
   float bsum = 0.f;                                        // thread (co = tid>>3, 16-pixel part = tid&7)
@@ -649,6 +668,7 @@ __global__ void __launch_bounds__(256) k_wgrad_tile(WgradArgs A, int tiles_x, in
       a[1] = *reinterpret_cast<const f32x4*>(gT + (16 + il) * WT_GP + p0);
 #pragma unroll
       for (int t = 0; t < TAPS; ++t) {
+        if (!((tmask >> t) & 1u)) continue;                 // this (tap, block) of the weight is structurally zero
         const int kh = t / KW, kw = t - kh * KW;
         const int hb = (ty + kh) * HW + tx + kw;            // halo index of pixel p0 shifted by the tap
         float b[2][4];
@@ -681,6 +701,7 @@ __global__ void __launch_bounds__(256) k_wgrad_tile(WgradArgs A, int tiles_x, in
   __syncthreads();
 #pragma unroll
   for (int t = 0; t < TAPS; ++t) {
+    if (!((tmask >> t) & 1u)) continue;                     // workgroup-uniform: the barriers below stay matched
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -895,7 +916,11 @@ int msgm_conv_forward_fused(const msgm_conv_geom_t* geom, const float* src0, int
   A.nsrc = src1 ? 2 : 1;
   A.Wp = Wp; A.Cout = Cout; A.CoutP = CoutP; A.Ktot = Ktot;
   A.bias = bias; A.samp_bias = samp_bias; A.n_bias = n_bias; A.n_samp = n_samp; A.out = out; A.accumulate = accumulate;
-  if (fuse) { A.residual = fuse->residual; A.in_scale = fuse->in_scale; A.in_shift = fuse->in_shift; A.in_act = fuse->in_act; }
+  if (fuse) {
+    A.residual = fuse->residual; A.in_scale = fuse->in_scale; A.in_shift = fuse->in_shift; A.in_act = fuse->in_act;
+    for (int i = 0; i < 16; ++i) A.tapmask_in[i] = fuse->tapmask_in[i];
+    for (int i = 0; i < 8; ++i) A.tapmask_out[i] = fuse->tapmask_out[i];
+  }
   const int64_t Mtot = (int64_t)geom->N * geom->Ho * geom->Wo;
   const bool fast = (C0 % 16 == 0) && (!src1 || C1 % 16 == 0);
   // stride-1 "same" convolution (or its dgrad) on a big enough image: halo-tile kernel
@@ -942,11 +967,16 @@ int msgm_conv_forward_fused(const msgm_conv_geom_t* geom, const float* src0, int
 }
 
 int msgm_conv_wgrad(const msgm_conv_geom_t* geom, const float* gy, const float* src, int32_t C, int32_t koff,
-                    float* dWp, int32_t Cout, int32_t CoutP, int32_t Ktot, float* dbias, int32_t n_bias, msgm_stream_t stream) {
+                    float* dWp, int32_t Cout, int32_t CoutP, int32_t Ktot, float* dbias, int32_t n_bias,
+                    const uint16_t* tapmask_c32, const uint16_t* tapmask_co32, msgm_stream_t stream) {
   int rc = check_geom(geom);
   if (rc) return rc;
   if (!gy || !src || !dWp || C <= 0 || Cout <= 0 || koff < 0 || koff + C > Ktot || (dbias && n_bias <= 0)) return MSGM_E_BADARG;
-  WgradArgs A{to_geom(geom), gy, src, C, koff, dWp, Cout, CoutP, Ktot, 0, dbias, n_bias};
+  WgradArgs A{to_geom(geom), gy, src, C, koff, dWp, Cout, CoutP, Ktot, 0, dbias, n_bias, {0}, {0}};
+  for (int i = 0; i < 16; ++i) {
+    A.tm_c[i] = (tapmask_c32 && i < (C + 31) / 32) ? tapmask_c32[i] : 0;
+    A.tm_o[i] = (tapmask_co32 && i < (Cout + 31) / 32) ? tapmask_co32[i] : 0;
+  }
   const int64_t Mtot = (int64_t)geom->N * geom->Ho * geom->Wo;
   const int taps = geom->KH * geom->KW;
   const int ups_sh = geom->ups ? 1 : 0;

@@ -273,7 +273,7 @@ def conv_forward(geom: L.ConvGeomT, src0: torch.Tensor, C0: int, Wp: torch.Tenso
                  samp_bias: Optional[torch.Tensor] = None, n_bias: int = 0, accumulate: bool = False,
                  CoutP: Optional[int] = None, n_samp: Optional[int] = None, residual: Optional[torch.Tensor] = None,
                  in_scale: Optional[torch.Tensor] = None, in_shift: Optional[torch.Tensor] = None,
-                 in_act: int = 0) -> torch.Tensor:
+                 in_act: int = 0, tapmask_in=None, tapmask_out=None) -> torch.Tensor:
     """out[N][Ho][Wo][Cout] (+)= implicit-GEMM convolution of channels-last inputs (K6/K11).
     residual: added in the epilogue.  in_scale / in_shift [N][C0+C1] (+ in_act=1: SiLU): the conv reads
     act(a x + b) — GroupNorm(+SiLU) folded into the input staging (see conv_input_transform_supported)."""
@@ -294,7 +294,7 @@ def conv_forward(geom: L.ConvGeomT, src0: torch.Tensor, C0: int, Wp: torch.Tenso
     if samp_bias is not None and samp_bias.numel() != n_samp * Cout:
         raise MsgmError("samp_bias must be [n_samp][Cout]")
     fuse = None
-    if residual is not None or in_scale is not None:
+    if residual is not None or in_scale is not None or tapmask_in or tapmask_out:
         ctot = C0 + (C1 if src1 is not None else 0)
         if residual is not None and residual.numel() != out.numel():
             raise MsgmError("residual must have the output's size")
@@ -302,6 +302,10 @@ def conv_forward(geom: L.ConvGeomT, src0: torch.Tensor, C0: int, Wp: torch.Tenso
                                                         (in_scale.numel() != geom.N * ctot or in_shift.numel() != geom.N * ctot)):
             raise MsgmError("in_scale / in_shift must both be [N][C0+C1]")
         fuse = L.ConvFuseT(ptr(residual), ptr(in_scale), ptr(in_shift), int(in_act), 0)
+        for i, m in enumerate((tapmask_in or [])[:16]):      # structurally-zero weight blocks (tile kernel skips them)
+            fuse.tapmask_in[i] = int(m)
+        for i, m in enumerate((tapmask_out or [])[:8]):
+            fuse.tapmask_out[i] = int(m)
     check(lib().msgm_conv_forward_fused(geom, ptr(f32(src0)), C0, ptr(src1), C1, ptr(f32(Wp)), Cout, CoutP, Ktot, ptr(bias),
                                         ptr(samp_bias), int(n_bias), int(n_samp), ptr(f32(out)), int(bool(accumulate)),
                                         fuse, stream()), "msgm_conv_forward")
@@ -327,7 +331,8 @@ def groupnorm_affine(x0, C0, gamma, beta, Bp, P, G, x1=None, C1=0, eps=1e-5):
 
 
 def conv_wgrad(geom: L.ConvGeomT, gy: torch.Tensor, src: torch.Tensor, C: int, koff: int, dWp: torch.Tensor, Cout: int,
-               CoutP: int, Ktot: int, dbias: Optional[torch.Tensor] = None, n_bias: int = 0):
+               CoutP: int, Ktot: int, dbias: Optional[torch.Tensor] = None, n_bias: int = 0, tapmask_c32=None,
+               tapmask_co32=None):
     """dbias (Cout floats, ACCUMULATED into): bias gradient over the primal rows n < n_bias, as a by-product."""
     taps = geom.KH * geom.KW
     if dbias is not None and (dbias.numel() != Cout or n_bias <= 0 or n_bias > geom.N):
@@ -336,8 +341,13 @@ def conv_wgrad(geom: L.ConvGeomT, gy: torch.Tensor, src: torch.Tensor, C: int, k
         raise MsgmError("wgrad operands do not match the geometry")
     if dWp.numel() < taps * CoutP * Ktot:
         raise MsgmError("packed gradient too small")
+    import ctypes as C_
+    mc = (C_.c_uint16 * len(tapmask_c32))(*tapmask_c32) if tapmask_c32 else None
+    mo = (C_.c_uint16 * len(tapmask_co32))(*tapmask_co32) if tapmask_co32 else None
+    if (mc is not None and len(mc) < (C + 31) // 32) or (mo is not None and len(mo) < (Cout + 31) // 32):
+        raise MsgmError("wgrad: tap masks need one entry per 32-channel block")
     check(lib().msgm_conv_wgrad(geom, ptr(f32(gy)), ptr(f32(src)), C, koff, ptr(f32(dWp)), Cout, CoutP, Ktot,
-                                ptr(dbias), int(n_bias), stream()), "msgm_conv_wgrad")
+                                ptr(dbias), int(n_bias), mc, mo, stream()), "msgm_conv_wgrad")
 
 
 def pack_weight(W: torch.Tensor, w_off: int, Wp: torch.Tensor, rows, ncols, col_off, taps, sr, sc, st, rowsP, Ktot, kp_off):
