@@ -1,0 +1,68 @@
+"""-m gpu: the product's N>1 path (MLPScoreTrainer / UNetScoreTrainer with world=2) rehearsed with two ranks sharing
+the one GPU of the test box over gloo (RCCL needs one GPU per rank; the collective call site is the same
+`parallel.allreduce_sum_`).  Checks what data parallelism must guarantee: after every step both ranks hold identical
+parameters (same all-reduced bucket, same Adam state), the loss is the global mean, and training moves them."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, kind, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), MSGM_DIST_BACKEND="gloo")
+    import torch.distributed as dist
+    from sdeflow_light_amd import parallel
+    from sdeflow_light_amd.SDEs import SGMsde, PluginReverseSDE
+    from sdeflow_light_amd.train import MLPScoreTrainer, UNetScoreTrainer
+    r, local, w = parallel.init_distributed()
+    dev = parallel.local_device(local)
+    torch.cuda.set_device(dev)
+    torch.manual_seed(0)                                   # same initial parameters on both ranks
+    T = torch.nn.Parameter(torch.FloatTensor([1.0]), requires_grad=False)
+    if kind == "mlp":
+        from sdeflow_light_amd.NN import MLP
+        net, d, B = MLP(2).to(dev), 2, 1024
+    else:
+        from sdeflow_light_amd.NNUnet1D import UNet1D
+        net, d, B = UNet1D(input_dim=128, base_channels=16, channel_mults=(1, 2), emb_dim=32).to(dev), 128, 8
+    gen = PluginReverseSDE(SGMsde(T=T, num_steps_forward=16, device=dev), net, T, deviceReverseSDE=dev).to(dev)
+    flat, _ = net.flat_parameters()
+    parallel.broadcast_(flat, 0)
+    p0 = flat.clone()
+    tr = (MLPScoreTrainer(gen, B, lr=1e-3, world=w, seed=1 + r) if kind == "mlp"
+          else UNetScoreTrainer(gen, B, d, lr=1e-3, world=w, seed=1 + r))
+    torch.manual_seed(100 + r)                             # different data shard per rank
+    tr.set_data(torch.randn(B, d, device=dev))
+    losses = [float(tr.step()) for _ in range(3)]
+    flat, _ = net.flat_parameters()
+    q.put((r, losses, flat.detach().cpu().numpy().tobytes(), float((flat - p0).abs().max())))   # bytes: no shared-memory handle to outlive
+    parallel.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("kind", ["mlp", "unet1d"])
+def test_two_rank_training_keeps_ranks_identical(kind):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, kind, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted([q.get(timeout=500) for _ in range(world)], key=lambda t: t[0])
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    (_, l0, f0, m0), (_, l1, f1, m1) = res
+    assert all(abs(a - b) <= 1e-6 * max(1.0, abs(a)) for a, b in zip(l0, l1)), (l0, l1)     # the all-reduced global mean
+    assert f0 == f1 and len(f0) > 0                                                          # bitwise identical replicas
+    assert m0 > 1e-5 and all(map(lambda v: v == v, l0))
