@@ -139,6 +139,20 @@ class _Res:
         self.skip = None if isinstance(m.skip_connection, nn.Identity) else \
             ConvOp(m.skip_connection.weight, m.skip_connection.bias, "conv", (1, 1), 1, 0, [ci])
         self.ops = [self.conv1, self.lin, self.conv2] + ([self.skip] if self.skip else [])
+        self.conv1_2 = self.skip_2 = None      # two-source twins for decoder blocks (sampler path, see make_two_source)
+        self.split = None
+
+    def make_two_source(self, C0: int, C1: int):
+        """Decoder ResBlocks read cat([h, skip]) (model/unet.py:514).  On the sampler path the concatenation is never
+        materialised: GroupNorm statistics, conv1 and the 1x1 skip conv read the two tensors directly.  The twins
+        share the weight Parameters and only differ in the packed layout (each source padded to 16 channels)."""
+        m = self.m
+        if self.skip is None or C0 + C1 != self.ci:
+            raise MsgmError("two-source twins are for decoder ResBlocks with a skip convolution")
+        self.split = (C0, C1)
+        self.conv1_2 = ConvOp(m.in_layers[2].weight, m.in_layers[2].bias, "conv", (3, 3), 1, 1, [C0, C1])
+        self.skip_2 = ConvOp(m.skip_connection.weight, m.skip_connection.bias, "conv", (1, 1), 1, 0, [C0, C1])
+        return [self.conv1_2, self.skip_2]
 
 
 class _Attn:
@@ -213,6 +227,18 @@ class VorticityUNet(nn.Module, FlatParamMixin):
                 allops += o.ops if kind in ("res", "attn") else [o]
         x["all"] = allops
         x["set"] = ConvOpSet(allops)
+        # channel count after every input block = the skip tensors the decoder pops (model/unet.py:506-514)
+        chans = []
+        for blk in x["in"]:
+            kind, o = blk[-1] if blk[-1][0] != "attn" else blk[-2]
+            chans.append(o.co if kind == "res" else o.Cout)
+        twins = []
+        for blk in x["outb"]:
+            Cs = chans.pop()
+            kind, res = blk[0]
+            if kind == "res" and res.skip is not None and res.ci > Cs and (res.ci - Cs) % 16 == 0 and Cs % 16 == 0:
+                twins += res.make_two_source(res.ci - Cs, Cs)
+        x["set2"] = ConvOpSet(twins) if twins else None
         self._x = x
         return x
 
@@ -230,6 +256,20 @@ class VorticityUNet(nn.Module, FlatParamMixin):
     def _res_fwd(self, r: _Res, x, N, Bp, H, W, semb, dual, tape, er):
         P = H * W
         eo, _, _ = r.lin.forward([semb], er, 1, 1, Bp)           # er rows carry an embedding (N with log-radius conditioning)
+        if isinstance(x, tuple):                                 # (h, skip): decoder block without the concatenation
+            h0, s0 = x
+            C0, C1 = r.split
+            gnm = r.m.in_layers[0]
+            aff = ops.groupnorm_affine(h0, C0, gnm.weight.detach(), gnm.bias.detach(), Bp, P, gnm.num_groups, x1=s0, C1=C1)
+            h2, _, _ = r.conv1_2.forward([h0, s0], N, H, W, Bp, samp_bias=eo, emb_rows=er, in_affine=aff, in_act=1)
+            out, _, _ = r.skip_2.forward([h0, s0], N, H, W, Bp)
+            if r.conv2.can_transform_input(N, H, W):
+                r.conv2.forward([h2], N, H, W, Bp, out=out, accumulate=True,
+                                in_affine=self._gn_fold(r.m.out_layers[0], h2, Bp, P, r.co), in_act=1)
+            else:
+                h3, _ = self._gn(r.m.out_layers[0], h2, Bp, P, r.co, False, True, None)
+                r.conv2.forward([h3], N, H, W, Bp, out=out, accumulate=True)
+            return out
         fold = (not dual and tape is None and not os.environ.get("MSGM_NO_GN_FOLD")
                 and r.conv1.can_transform_input(N, H, W) and r.conv2.can_transform_input(N, H, W))
         if fold:
@@ -346,8 +386,17 @@ class VorticityUNet(nn.Module, FlatParamMixin):
             if tape is not None:
                 tape.append(("save_skip",))
         h, C, H, W = run_block(x["mid"], h, C, H, W)
+        nocat = (not dual and tape is None and x["set2"] is not None and not os.environ.get("MSGM_NO_GN_FOLD"))
+        if nocat:
+            x["set2"].pack()
         for blk in x["outb"]:
             s, Cs = hs.pop()
+            r0 = blk[0][1]
+            if nocat and blk[0][0] == "res" and r0.split == (C, Cs) and r0.conv1_2.can_transform_input(N, H, W):
+                # sampler path: the decoder ResBlock reads h and the skip tensor as two sources — no concatenation
+                h = self._res_fwd(r0, (h, s), N, Bp, H, W, semb, dual, tape, er)
+                h, C, H, W = run_block(blk[1:], h, r0.co, H, W)
+                continue
             cat = torch.cat([h.view(N, H * W, C), s.view(N, H * W, Cs)], dim=2).reshape(-1)    # model/unet.py:514
             if tape is not None:
                 tape.append(("cat", C, Cs, H, W))
