@@ -243,13 +243,15 @@ __global__ void __launch_bounds__(256) k_conv_gemm(ConvArgs A) {
 // flip = 1 evaluates the transposed stride-1 gather i = o + pad - k (the dgrad of the same convolution).
 #define CT_KC 32
 #define CT_P 36
-template <int TH, int TW, int NCO>
+// KS = kernel size (1 or 3; the 1-D variants have KH = 1): compile-time, so the halo index arithmetic of the staging
+// (hp / HW per staged 16 B) is multiplications by constants instead of integer divisions.
+template <int TH, int TW, int NCO, int KS>
 __global__ void __launch_bounds__(256) k_conv_tile(ConvArgs A, int flip, int tiles_x, int tiles_y, int tiles_per_wg, int n_tiles) {
   extern __shared__ __attribute__((aligned(16))) float ct_lds[];
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, il = lane & 15, q = lane >> 4;
   const ConvGeom g = A.g;
-  const int KH = g.KH, KW = g.KW, taps = KH * KW;
-  const int HH = TH + KH - 1, HW = TW + KW - 1, halo = HH * HW;
+  constexpr int KH = TH == 1 ? 1 : KS, KW = KS, taps = KH * KW;
+  constexpr int HH = TH + KH - 1, HW = TW + KW - 1, halo = HH * HW;
   float* cur = ct_lds;
   float* nxt = ct_lds + halo * CT_P;
   const int co0 = blockIdx.y * (NCO * 16);
@@ -273,9 +275,9 @@ __global__ void __launch_bounds__(256) k_conv_tile(ConvArgs A, int flip, int til
   for (int s = 0; s < CONV_MAX_SRC; ++s) { nch[s] = s < A.nsrc ? (A.C[s] + CT_KC - 1) / CT_KC : 0; total_chunks += nch[s]; }
 
   // ---- staging: halo pixel hp, 16-B column c4 (8 per pixel)
-  constexpr int MAXST = ((TH == 1 ? 1 : TH + 2) * (TW + 2) * (CT_KC / 4) + 255) / 256;   // 1-D: no vertical halo
+  constexpr int MAXST = (halo * (CT_KC / 4) + 255) / 256;
   f32x4 st[MAXST];
-  const int n_items = halo * (CT_KC / 4);
+  constexpr int n_items = halo * (CT_KC / 4);
   const int padH = g.padH, padW = g.padW;
   const int up = g.ups ? 1 : 0;          // Upsample folded into the gather (model/unet.py:60-73)
   const int ctot_all = A.C[0] + (A.nsrc > 1 ? A.C[1] : 0);
@@ -307,7 +309,11 @@ __global__ void __launch_bounds__(256) k_conv_tile(ConvArgs A, int flip, int til
         const int hy = hp / HW, hx = hp - hy * HW;
         const int iy = y0 + hy - padH, ix = x0 + hx - padW;     // on the (2x nearest-upsampled, if ups) input grid
         const int c = c0 + 4 * c4;
+#ifdef CT_EXP_NOSTAGE    // diagnostic: no halo loads / index arithmetic
+        if (false) {
+#else
         if (iy >= 0 && iy < (g.Hi << up) && ix >= 0 && ix < (g.Wi << up) && c < C) {
+#endif
           v = *reinterpret_cast<const f32x4*>(base + ((size_t)(iy >> up) * g.Wi + (ix >> up)) * C + c);
           if (A.in_scale) {
             v = v * ga + gb;
@@ -387,18 +393,25 @@ __global__ void __launch_bounds__(256) k_conv_tile(ConvArgs A, int flip, int til
         for (int c = 0; c < NCO; ++c) an[d][c] = an[d + 1][c];
       int ntap = tap, ngr = grp + 1;
       if (ngr == ngrp) { ngr = 0; ntap = next_tap(tap); }
+#ifndef CT_EXP_NOW      // diagnostic: -DCT_EXP_NOW keeps the first weight fragment (no further weight loads)
       if (pr + WD < npairs) {
         const float* wp = wbase + (size_t)ftap * A.CoutP * A.Ktot + 16 * fgrp;
 #pragma unroll
         for (int c = 0; c < NCO; ++c) an[WD - 1][c] = *reinterpret_cast<const f32x4*>(wp + c * a_co_stride);
         if (++fgrp == ngrp) { fgrp = 0; ftap = next_tap(ftap); }
       }
+#endif
       const int kh = tap / KW, kw = tap - kh * KW;
       const int oy = flip ? (KH - 1 - kh) : kh, ox = flip ? (KW - 1 - kw) : kw;
       f32x4 b[2];
+#ifndef CT_EXP_NOLDS    // diagnostic: -DCT_EXP_NOLDS feeds the MFMAs from registers (no activation reads)
 #pragma unroll
       for (int pt = 0; pt < 2; ++pt)
         b[pt] = *reinterpret_cast<const f32x4*>(cur + ((pty[pt] + oy) * HW + ptx[pt] + ox) * CT_P + 16 * grp + 4 * q);
+#else
+      b[0] = a[0]; b[1] = a[NCO - 1];
+      (void)oy; (void)ox;
+#endif
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -410,7 +423,12 @@ __global__ void __launch_bounds__(256) k_conv_tile(ConvArgs A, int flip, int til
     }
 
     // ---- epilogue of a finished tile (same contract as k_conv_gemm)
+#ifdef CT_EXP_NOEPI      // diagnostic: one lane stores one value
+    if (last_chunk && tid == 0 && tile == t_beg) A.out[0] = acc[0][0][0] + acc[NCO - 1][1][3];
+    if (false) {
+#else
     if (last_chunk) {
+#endif
       int n, y0, x0;
       tile_origin(tile, n, y0, x0);
 #pragma unroll
@@ -447,7 +465,8 @@ __global__ void __launch_bounds__(256) k_conv_tile(ConvArgs A, int flip, int til
     }
     if (!more) break;
     stage_store(nxt);
-    __syncthreads();
+    // LDS hand-off only: __syncthreads() would also drain vmcnt, i.e. wait for this tile's output stores to land
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     float* t = cur; cur = nxt; nxt = t;
     tile = ntile; cs = ns; cc = nc;
   }
@@ -879,7 +898,8 @@ static bool conv_tile_eligible(const msgm_conv_geom_t* geom, int32_t C0, const f
                     (geom->Hi << ups_sh) == geom->Ho && (geom->Wi << ups_sh) == geom->Wo &&
                     (geom->KH & 1) && (geom->KW & 1) && geom->padH == (geom->KH - 1) / 2 && geom->padW == (geom->KW - 1) / 2 &&
                     geom->KH <= 3 && geom->KW <= 3;
-  return same && fast && CoutP % 32 == 0 && (int64_t)geom->Ho * geom->Wo >= 64 && (geom->Ho > 1 || geom->KH == 1) &&
+  return same && fast && CoutP % 32 == 0 && (int64_t)geom->Ho * geom->Wo >= 64 &&
+         (geom->Ho > 1 ? geom->KH == geom->KW : geom->KH == 1) &&          // square kernels in 2-D, KH = 1 in 1-D
          !getenv("MSGM_NO_CONV_TILE");
 }
 
@@ -941,13 +961,17 @@ int msgm_conv_forward_fused(const msgm_conv_geom_t* geom, const float* src0, int
     if (per < 1) per = 1;
     dim3 grid((unsigned)((n_tiles + per - 1) / per), (unsigned)gy);
     const int flip = geom->mode;
+#define CT_LAUNCH(TH_, TW_, NCO_, KS_) \
+  hipLaunchKernelGGL((k_conv_tile<TH_, TW_, NCO_, KS_>), grid, dim3(256), lds, S(stream), A, flip, tiles_x, tiles_y, per, n_tiles)
+    const bool k3 = geom->KW == 3;
     if (two_d) {
-      if (nco == 4) hipLaunchKernelGGL((k_conv_tile<8, 16, 4>), grid, dim3(256), lds, S(stream), A, flip, tiles_x, tiles_y, per, n_tiles);
-      else hipLaunchKernelGGL((k_conv_tile<8, 16, 2>), grid, dim3(256), lds, S(stream), A, flip, tiles_x, tiles_y, per, n_tiles);
+      if (nco == 4) { if (k3) CT_LAUNCH(8, 16, 4, 3); else CT_LAUNCH(8, 16, 4, 1); }
+      else { if (k3) CT_LAUNCH(8, 16, 2, 3); else CT_LAUNCH(8, 16, 2, 1); }
     } else {
-      if (nco == 4) hipLaunchKernelGGL((k_conv_tile<1, 128, 4>), grid, dim3(256), lds, S(stream), A, flip, tiles_x, tiles_y, per, n_tiles);
-      else hipLaunchKernelGGL((k_conv_tile<1, 128, 2>), grid, dim3(256), lds, S(stream), A, flip, tiles_x, tiles_y, per, n_tiles);
+      if (nco == 4) { if (k3) CT_LAUNCH(1, 128, 4, 3); else CT_LAUNCH(1, 128, 4, 1); }
+      else { if (k3) CT_LAUNCH(1, 128, 2, 3); else CT_LAUNCH(1, 128, 2, 1); }
     }
+#undef CT_LAUNCH
     return msgm_check_launch();
   }
   if (CoutP >= 64 && CoutP % 64 == 0) {
