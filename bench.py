@@ -44,17 +44,20 @@ def build_model(dev, B):
 
 
 def time_kernel_events(fn, iters, dev):
-    """Average device time per call of fn (HIP events on the launch stream)."""
+    """Average duration of ONE launch of fn: every launch is bracketed by its own pair of HIP events on the launch
+    stream (start-to-end of the kernel, as rocprofv3's per-kernel duration counts it — the cross-check committed under
+    profiles/).  A loop of back-to-back launches timed as a whole reads ~5 % lower (the next launch's workgroups start
+    while the previous one drains) and an eager loop ~3 % higher (host launch gaps); neither is the kernel's duration."""
     for _ in range(3):
         fn()
     torch.cuda.synchronize(dev)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for e0, e1 in pairs:
+        e0.record()
         fn()
-    e1.record()
+        e1.record()
     torch.cuda.synchronize(dev)
-    return e0.elapsed_time(e1) / iters * 1e-3
+    return sum(e0.elapsed_time(e1) for e0, e1 in pairs) / iters * 1e-3
 
 
 def cpu_baseline(budget_s=12.0):
