@@ -58,13 +58,19 @@ __host__ __device__ static inline int64_t slab_stride(int64_t n_params) { return
 // NARROW nets (in_dim <= 16 and d <= 16) use 20-float small rows and 16 padded outputs; the forward / sampler
 // modes drop the backward-only buffers — 67 KB instead of 134 KB, so TWO workgroups share a CU there and each
 // one's barrier bubbles are filled by the other's MFMAs.
-template <int MODE, bool WIDE, int NW>
+// TINY (inference modes, in_dim <= 4 and d <= 4 — the C1/C2 nets): the small rows shrink to 8 floats, only 4 rows of
+// W4 are kept (the MFMA's other 12 output rows are zeros and are fed from registers), so the carve drops from 74 KB
+// to 52 KB and THREE workgroups share a CU.
+template <int MODE, bool WIDE, int NW, bool TINY = false>
 struct MlpLds {
-  static constexpr int SMP = WIDE ? 36 : 20;       // pitch of h0 / abar / partial rows
+  static_assert(!TINY || (MODE != 2 && !WIDE), "the tiny carve is for the narrow inference modes");
+  static constexpr int SMP = WIDE ? 36 : (TINY ? 8 : 20);   // pitch of h0 / abar / W1 rows
+  static constexpr int PP = TINY ? 8 : SMP;        // pitch of a layer-4 partial row
   static constexpr int DP = WIDE ? 32 : 16;        // padded output width
+  static constexpr int DROWS = TINY ? 4 : DP;      // rows of W4 held in LDS
   static constexpr bool TRAIN = MODE == 2;
   static constexpr int SPT = TRAIN ? 16 : 32;      // samples per tile
-  static constexpr int DMAX = WIDE ? 32 : 16;      // raw rows are packed (pitch d), sized for d <= DMAX
+  static constexpr int DMAX = WIDE ? 32 : (TINY ? 4 : 16);   // raw rows are packed (pitch d), sized for d <= DMAX
   // one raw input buffer: the tile's y | v | u chunks, t and cst, copied verbatim from global one tile ahead
   static constexpr int RY = 0;
   static constexpr int RV = RY + SPT * DMAX;
@@ -79,9 +85,9 @@ struct MlpLds {
   static constexpr int H0 = U + (TRAIN ? 32 * ACT_P : 0);
   static constexpr int ABAR = H0 + 2 * 32 * SMP;   // h0 is double-buffered (built one tile ahead)
   static constexpr int PART = ABAR + (TRAIN ? 32 * SMP : 0);
-  static constexpr int W1 = PART + NW * 32 * SMP;   // one layer-4 K-slice per wave
+  static constexpr int W1 = PART + NW * 32 * PP;    // one layer-4 K-slice per wave
   static constexpr int W4 = W1 + HID * SMP;
-  static constexpr int B1 = W4 + DP * ACT_P;
+  static constexpr int B1 = W4 + DROWS * ACT_P;
   static constexpr int B2 = B1 + HID;
   static constexpr int B3 = B2 + HID;
   static constexpr int B4 = B3 + HID;
@@ -383,7 +389,7 @@ __device__ __forceinline__ void wgrad_swish(const float* zbuf, const float* hb, 
   wgrad_core<KT, IT, true>(zbuf, hb, hb_pitch, fb, il, q, dW, z, g);
 }
 
-template <int MODE, bool WIDE, int NW>
+template <int MODE, bool WIDE, int NW, bool TINY = false>
 __global__ void __launch_bounds__(64 * NW, 1) k_mlp(MlpArgs A) {
   constexpr int NT = 64 * NW;         // threads
   constexpr int IT = 8 / NW;          // 16-feature row tiles per wave: 4 waves x 2 or 8 waves x 1
@@ -396,8 +402,8 @@ __global__ void __launch_bounds__(64 * NW, 1) k_mlp(MlpArgs A) {
   const int w = tid >> 6, lane = tid & 63, il = lane & 15, q = lane >> 4;
   const int d = A.P.d;
   const int fb = FW * w;              // this wave's first feature
-  using LO = MlpLds<MODE, WIDE, NW>;
-  constexpr int SM_P = LO::SMP, DPAD = LO::DP;
+  using LO = MlpLds<MODE, WIDE, NW, TINY>;
+  constexpr int SM_P = LO::SMP, DPAD = LO::DP, PP = LO::PP, DROWS = LO::DROWS;
   float* X = lds + LO::X; float* Y = lds + LO::Y; float* Z = lds + LO::Z; float* U = lds + LO::U;
   float* H0 = lds + LO::H0; float* ABAR = lds + LO::ABAR; float* PART = lds + LO::PART;
   float* W1s = lds + LO::W1; float* W4s = lds + LO::W4;
@@ -511,7 +517,7 @@ __global__ void __launch_bounds__(64 * NW, 1) k_mlp(MlpArgs A) {
   WPre pre;
   prefetch_w<false>(R2, fb, il, q, pre);
   {
-    constexpr int N1 = (HID * SM_P + NT - 1) / NT, N4 = (DPAD * ACT_P + NT - 1) / NT;
+    constexpr int N1 = (HID * SM_P + NT - 1) / NT, N4 = (DROWS * ACT_P + NT - 1) / NT;
     float v1[N1], v4[N4], vb[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < N1; ++k) {
@@ -521,14 +527,14 @@ __global__ void __launch_bounds__(64 * NW, 1) k_mlp(MlpArgs A) {
 #pragma unroll
     for (int k = 0; k < N4; ++k) {
       const int i = tid + NT * k, r = i / ACT_P, c = i - r * ACT_P;
-      v4[k] = (i < DPAD * ACT_P && r < d && c < HID) ? A.P.W4[r * HID + c] : 0.f;
+      v4[k] = (i < DROWS * ACT_P && r < d && c < HID) ? A.P.W4[r * HID + c] : 0.f;
     }
     if (tid < HID) { vb[0] = A.P.b1[tid]; vb[1] = A.P.b2[tid]; vb[2] = A.P.b3[tid]; }
     if (tid < d) vb[3] = A.P.b4[tid];
 #pragma unroll
     for (int k = 0; k < N1; ++k) { const int i = tid + NT * k; if (i < HID * SM_P) W1s[i] = v1[k]; }
 #pragma unroll
-    for (int k = 0; k < N4; ++k) { const int i = tid + NT * k; if (i < DPAD * ACT_P) W4s[i] = v4[k]; }
+    for (int k = 0; k < N4; ++k) { const int i = tid + NT * k; if (i < DROWS * ACT_P) W4s[i] = v4[k]; }
     if (tid < HID) { B1s[tid] = vb[0]; B2s[tid] = vb[1]; B3s[tid] = vb[2]; }
     if (tid < 32) B4s[tid] = vb[3];
     if (MODE == MODE_TRAIN) {
@@ -625,15 +631,18 @@ __global__ void __launch_bounds__(64 * NW, 1) k_mlp(MlpArgs A) {
         f32x4 p0 = {0, 0, 0, 0}, p1 = {0, 0, 0, 0};
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
-          const f32x4 a4 = *reinterpret_cast<const f32x4*>(W4s + (16 * ot + il) * ACT_P + fb + 16 * it + 4 * q);
+          f32x4 a4 = {0.f, 0.f, 0.f, 0.f};                  // output rows >= DROWS are zero padding
+          if (16 * ot + il < DROWS) a4 = *reinterpret_cast<const f32x4*>(W4s + (16 * ot + il) * ACT_P + fb + 16 * it + 4 * q);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             p0 = mfma16(a4[r], h[it][0][r], p0);
             p1 = mfma16(a4[r], h[it][1][r], p1);
           }
         }
-        *reinterpret_cast<f32x4*>(PART + (w * 32 + il) * SM_P + 16 * ot + 4 * q) = p0;
-        *reinterpret_cast<f32x4*>(PART + (w * 32 + 16 + il) * SM_P + 16 * ot + 4 * q) = p1;
+        if (16 * ot + 4 * q < PP) {                         // (tiny carve: only the first 8 output columns exist)
+          *reinterpret_cast<f32x4*>(PART + (w * 32 + il) * PP + 16 * ot + 4 * q) = p0;
+          *reinterpret_cast<f32x4*>(PART + (w * 32 + 16 + il) * PP + 16 * ot + 4 * q) = p1;
+        }
       }
     }
     if (MODE == MODE_TRAIN) raw_commit(Rn);
@@ -650,7 +659,7 @@ __global__ void __launch_bounds__(64 * NW, 1) k_mlp(MlpArgs A) {
         if (smp < A.B) {
           float a = B4s[o];
 #pragma unroll
-          for (int ww = 0; ww < NW; ++ww) a += PART[(ww * 32 + c) * SM_P + o];
+          for (int ww = 0; ww < NW; ++ww) a += PART[(ww * 32 + c) * PP + o];
           const int64_t e = smp * d + o;
           if (MODE == MODE_FWD) {
             A.out[e] = a;
@@ -689,7 +698,7 @@ __global__ void __launch_bounds__(64 * NW, 1) k_mlp(MlpArgs A) {
           const bool oo = o < d;
           float a = B4s[o], ad = 0.f;
 #pragma unroll
-          for (int ww = 0; ww < NW; ++ww) { a += PART[(ww * 32 + c) * SM_P + o]; ad += PART[(ww * 32 + 16 + c) * SM_P + o]; }
+          for (int ww = 0; ww < NW; ++ww) { a += PART[(ww * 32 + c) * PP + o]; ad += PART[(ww * 32 + 16 + c) * PP + o]; }
           float adb;
           if (A.u) {
             // general form: loss_b = sum_o adot_o u_o + cst_b + 1/2 a_o^2, u = (d mu/d a)^T v  (MSGM: G(y)^T v)
@@ -916,24 +925,33 @@ static const int MLP_MAX_GRID = 256;
 template <int MODE, bool WIDE>
 struct MlpCfg { static constexpr int NW = WIDE ? 4 : (MODE == MODE_TRAIN ? MLP_NW_TRAIN : MLP_NW_FWD); };
 
-template <int MODE, bool WIDE>
+template <int MODE, bool WIDE, bool TINY>
 static void set_lds_attr() {
   static const int once = [] {
     constexpr int NW = MlpCfg<MODE, WIDE>::NW;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp<MODE, WIDE, NW>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, MlpLds<MODE, WIDE, NW>::BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp<MODE, WIDE, NW, TINY>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, MlpLds<MODE, WIDE, NW, TINY>::BYTES);
     return 0;
   }();
   (void)once;
 }
+
+// workgroups that fit one CU with this carve (inference modes: 2, or 3 with the tiny carve)
+static bool mlp_tiny(const MlpArgs& A) { return A.in_dim <= 4 && A.P.d <= 4 && !getenv("MSGM_NO_TINY_CARVE"); }
 
 template <int MODE>
 static int launch_mlp(const MlpArgs& A, int grid, hipStream_t st) {
   const bool wide = A.in_dim > 16 || A.P.d > 16;
   constexpr int nw_w = MlpCfg<MODE, true>::NW, nw_n = MlpCfg<MODE, false>::NW;
   constexpr size_t lds_wide = MlpLds<MODE, true, nw_w>::BYTES, lds_narrow = MlpLds<MODE, false, nw_n>::BYTES;
-  if (wide) { set_lds_attr<MODE, true>(); hipLaunchKernelGGL((k_mlp<MODE, true, nw_w>), dim3(grid), dim3(64 * nw_w), lds_wide, st, A); }
-  else { set_lds_attr<MODE, false>(); hipLaunchKernelGGL((k_mlp<MODE, false, nw_n>), dim3(grid), dim3(64 * nw_n), lds_narrow, st, A); }
+  if (wide) { set_lds_attr<MODE, true, false>(); hipLaunchKernelGGL((k_mlp<MODE, true, nw_w, false>), dim3(grid), dim3(64 * nw_w), lds_wide, st, A); }
+  else if (MODE != MODE_TRAIN && mlp_tiny(A)) {
+    constexpr bool T = MODE != MODE_TRAIN;     // never instantiated for training
+    constexpr size_t lds_tiny = MlpLds<MODE, false, nw_n, T>::BYTES;
+    set_lds_attr<MODE, false, T>();
+    hipLaunchKernelGGL((k_mlp<MODE, false, nw_n, T>), dim3(grid), dim3(64 * nw_n), lds_tiny, st, A);
+  }
+  else { set_lds_attr<MODE, false, false>(); hipLaunchKernelGGL((k_mlp<MODE, false, nw_n, false>), dim3(grid), dim3(64 * nw_n), lds_narrow, st, A); }
   return msgm_check_launch();
 }
 
@@ -965,7 +983,7 @@ int msgm_mlp_forward(const msgm_mlp_params_t* P, const float* y, const float* t,
   if (!y || !t || !a) return MSGM_E_BADARG;
   A.y = y; A.t = t; A.out = a;
   const int64_t tiles = (B + 31) / 32;
-  const int64_t cap = 2 * MLP_MAX_GRID;          // forward modes fit two workgroups per CU
+  const int64_t cap = (mlp_tiny(A) ? 3 : 2) * MLP_MAX_GRID;   // forward modes: two (tiny carve: three) workgroups per CU
   return launch_mlp<MODE_FWD>(A, (int)(tiles < cap ? tiles : cap), S(stream));
 }
 
@@ -981,7 +999,7 @@ int msgm_mlp_em_step(const msgm_mlp_params_t* P, float* x, int64_t B, const msgm
   A.delta = delta; A.sqrt_delta = (float)sqrt((double)delta); A.lmbd = lmbd;
   A.z = z; A.rng = rng; A.rng_step = rng_step;
   const int64_t tiles = (B + 31) / 32;
-  const int64_t cap = 2 * MLP_MAX_GRID;
+  const int64_t cap = (mlp_tiny(A) ? 3 : 2) * MLP_MAX_GRID;
   return launch_mlp<MODE_EM>(A, (int)(tiles < cap ? tiles : cap), S(stream));
 }
 
@@ -999,7 +1017,7 @@ int msgm_mlp_em_loop(const msgm_mlp_params_t* P, float* x, int64_t B, const msgm
   A.delta = delta; A.sqrt_delta = (float)sqrt((double)delta); A.lmbd = lmbd;
   A.z = nullptr; A.rng = rng; A.rng_step = rng_step0;
   A.n_steps = n_steps; A.ts = ts;
-  const int64_t cap = 2 * MLP_MAX_GRID;
+  const int64_t cap = (mlp_tiny(A) ? 3 : 2) * MLP_MAX_GRID;
   const int64_t grid = tiles / 2 < cap ? tiles / 2 : cap;
   return launch_mlp<MODE_EM>(A, (int)grid, S(stream));
 }
