@@ -47,18 +47,24 @@ __global__ void k_perturb_vp(const float* __restrict__ x0, float* __restrict__ y
     const int64_t e0 = q << 2;
     f32x4 ez;
     if (eps == nullptr) ez = philox_normal4(rng, 0, RNG_STREAM_EPS, q);
+    // the row's time (one Philox block + two exp) is evaluated once per row the quad touches, not once per element
+    int64_t b_prev = -1;
+    float t = 0.f, mw = 0.f, sd = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int64_t e = e0 + k;
       if (e >= n) break;
       const int64_t b = e / d;
-      float ub = u ? u[b] : philox_uniform1(rng, 0, RNG_STREAM_T, (uint64_t)b);
-      float t = ub * T;
-      float m = (t <= t_eps) ? 1.0f : 0.0f;              // mask arithmetic as upstream
-      t = m * t_eps + (1.0f - m) * t;
+      if (b != b_prev) {
+        const float ub = u ? u[b] : philox_uniform1(rng, 0, RNG_STREAM_T, (uint64_t)b);
+        t = ub * T;
+        const float m = (t <= t_eps) ? 1.0f : 0.0f;      // mask arithmetic as upstream
+        t = m * t_eps + (1.0f - m) * t;
+        mw = vp_mean_weight(b0, b1, t);
+        sd = sqrtf(vp_var(b0, b1, t));
+        b_prev = b;
+      }
       float ee = eps ? eps[e] : ez[k];
-      float mw = vp_mean_weight(b0, b1, t);
-      float sd = sqrtf(vp_var(b0, b1, t));
       y[e] = ee * sd + mw * x0[e];
       if (eps_out) eps_out[e] = ee;
       if (e - b * d == 0) t_out[b] = t;
@@ -78,15 +84,22 @@ __global__ void k_ssm_prep(const float* __restrict__ x0, float* __restrict__ y, 
     const int64_t e0 = q << 2;
     const f32x4 ez = philox_normal4(rng, 0, RNG_STREAM_EPS, q);
     const f32x4 uv = philox_uniform4(rng, 0, RNG_STREAM_V, q);
+    int64_t b_prev = -1;
+    float t = 0.f, mw = 0.f, sd = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int64_t e = e0 + k;
       if (e >= n) break;
       const int64_t b = e / d;
-      float t = philox_uniform1(rng, 0, RNG_STREAM_T, (uint64_t)b) * T;
-      const float m = (t <= t_eps) ? 1.0f : 0.0f;
-      t = m * t_eps + (1.0f - m) * t;
-      y[e] = ez[k] * sqrtf(vp_var(b0, b1, t)) + vp_mean_weight(b0, b1, t) * x0[e];
+      if (b != b_prev) {                                 // once per row the quad touches
+        t = philox_uniform1(rng, 0, RNG_STREAM_T, (uint64_t)b) * T;
+        const float m = (t <= t_eps) ? 1.0f : 0.0f;
+        t = m * t_eps + (1.0f - m) * t;
+        mw = vp_mean_weight(b0, b1, t);
+        sd = sqrtf(vp_var(b0, b1, t));
+        b_prev = b;
+      }
+      y[e] = ez[k] * sd + mw * x0[e];
       v[e] = (uv[k] >= 0.5f) ? 1.0f : -1.0f;
       if (e - b * d == 0) t_out[b] = t;
     }
