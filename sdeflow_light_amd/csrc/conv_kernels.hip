@@ -431,26 +431,34 @@ __global__ void __launch_bounds__(256) k_conv_tile(ConvArgs A, int flip, int til
 #endif
       int n, y0, x0;
       tile_origin(tile, n, y0, x0);
+      const bool primal = n < A.n_bias;
+      const bool vec = (A.Cout & 3) == 0;                 // 16-B accesses along the output channels
 #pragma unroll
-      for (int pt = 0; pt < 2; ++pt) {
-        if (!((y0 + pty[pt] < g.Ho) && (x0 + ptx[pt] < g.Wo))) continue;
-        const size_t m = ((size_t)n * g.Ho + y0 + pty[pt]) * g.Wo + x0 + ptx[pt];
-        const bool primal = n < A.n_bias;
+      for (int c = 0; c < NCO; ++c) {
+        const int co = co0 + 16 * c + 4 * q;
+        if (co >= A.Cout) continue;
+        const bool full = vec && (co + 3 < A.Cout);
+        // bias / per-sample bias of this lane's 4 channels: fetched once, shared by its two pixels
+        f32x4 add = {0.f, 0.f, 0.f, 0.f};
+        if (primal && A.bias) {
+          if (full) add = *reinterpret_cast<const f32x4*>(A.bias + co);
+          else
 #pragma unroll
-        for (int c = 0; c < NCO; ++c) {
-          const int co = co0 + 16 * c + 4 * q;
-          if (co >= A.Cout) continue;
-          f32x4 v = acc[c][pt];
+            for (int r = 0; r < 4; ++r) if (co + r < A.Cout) add[r] = A.bias[co + r];
+        }
+        if (A.samp_bias && n < A.n_samp) {
+          const float* sbp = A.samp_bias + (size_t)n * A.Cout + co;
+          if (full) add += *reinterpret_cast<const f32x4*>(sbp);
+          else
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (co + r < A.Cout) add[r] += sbp[r];
+        }
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+          if (!((y0 + pty[pt] < g.Ho) && (x0 + ptx[pt] < g.Wo))) continue;
+          const size_t m = ((size_t)n * g.Ho + y0 + pty[pt]) * g.Wo + x0 + ptx[pt];
+          f32x4 v = acc[c][pt] + add;
           float* op = A.out + m * A.Cout + co;
-          const bool full = (co + 3 < A.Cout) && ((A.Cout & 3) == 0);
-          if (primal && A.bias) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) if (co + r < A.Cout) v[r] += A.bias[co + r];
-          }
-          if (A.samp_bias && n < A.n_samp) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) if (co + r < A.Cout) v[r] += A.samp_bias[(size_t)n * A.Cout + co + r];
-          }
           if (full) {
             if (A.accumulate) v += *reinterpret_cast<const f32x4*>(op);
             if (A.residual) v += *reinterpret_cast<const f32x4*>(A.residual + (op - A.out));
