@@ -286,6 +286,14 @@ __global__ void __launch_bounds__(256) k_conv_tile(ConvArgs A, int flip, int til
     const int ty_i = t % tiles_y;
     n = t / tiles_y; y0 = ty_i * TH; x0 = tx_i * TW;
   };
+  // this thread's halo positions are the same for every tile: (row, column) inside the halo, packed, once
+  int hyx[MAXST];
+#pragma unroll
+  for (int k = 0; k < MAXST; ++k) {
+    const int hp = (tid + 256 * k) >> 3;
+    const int hy = hp / HW;
+    hyx[k] = (hy << 16) | (hp - hy * HW);
+  }
   auto stage_load = [&](int t, int s, int c0) {
     int n, y0, x0;
     tile_origin(t, n, y0, x0);
@@ -305,8 +313,8 @@ __global__ void __launch_bounds__(256) k_conv_tile(ConvArgs A, int flip, int til
       const int idx = tid + 256 * k;
       f32x4 v = {0, 0, 0, 0};
       if (idx < n_items) {
-        const int hp = idx >> 3, c4 = idx & 7;
-        const int hy = hp / HW, hx = hp - hy * HW;
+        const int c4 = idx & 7;
+        const int hy = hyx[k] >> 16, hx = hyx[k] & 0xffff;
         const int iy = y0 + hy - padH, ix = x0 + hx - padW;     // on the (2x nearest-upsampled, if ups) input grid
         const int c = c0 + 4 * c4;
 #ifdef CT_EXP_NOSTAGE    // diagnostic: no halo loads / index arithmetic
