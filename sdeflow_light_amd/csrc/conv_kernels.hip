@@ -594,16 +594,18 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(WgradArgs A) {
 // float atomic per element per workgroup.
 #define WT_GP 132
 template <int TH, int TW, int TAPS>
-__global__ void __launch_bounds__(256) k_wgrad_tile(WgradArgs A, int tiles_x, int tiles_y, int tiles_per_wg, int n_tiles) {
+__global__ void __launch_bounds__(256, 2) k_wgrad_tile(WgradArgs A, int tiles_x, int tiles_y, int tiles_per_wg, int n_tiles) {
   extern __shared__ __attribute__((aligned(16))) float wt_lds[];
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, il = lane & 15, q = lane >> 4;
   const ConvGeom g = A.g;
-  const int KH = g.KH, KW = g.KW;
-  const int HH = TH + KH - 1, HW = TW + KW - 1, halo = HH * HW;
-  const int IP = ((halo + 7) & ~7) + 3;                    // pitch of an input channel row: = 3 (mod 8) keeps the
-                                                           // (channel il, pixel 4q) scalar reads at most 2 per bank
-  float* gyT[2] = {wt_lds, wt_lds + 32 * WT_GP + 32 * IP};
-  float* inT[2] = {wt_lds + 32 * WT_GP, wt_lds + 2 * 32 * WT_GP + 32 * IP};
+  constexpr int KW = (TH == 1) ? TAPS : (TAPS == 9 ? 3 : 1), KH = TAPS / KW;    // compile-time: constant index arithmetic
+  constexpr int HH = TH + KH - 1, HW = TW + KW - 1, halo = HH * HW;
+  // pitch of an input channel row: = 5 (mod 8) keeps the (channel il, pixel 4q) scalar reads at <= 3 lanes per bank
+  // (brute-forced; 3 (mod 8) is equivalent) and makes the 3x3 buffer 80.1 KB, so TWO such workgroups share a CU
+  constexpr int IP = ((halo + 2) & ~7) + 5;
+  constexpr int BUF = 32 * WT_GP + 32 * IP;               // one staging buffer: gy^T [32][WT_GP] | input^T [32][IP]
+  auto gyT = [&](int b) { return wt_lds + b * BUF; };
+  auto inT = [&](int b) { return wt_lds + b * BUF + 32 * WT_GP; };
   const int cblocks = (A.C + 31) / 32;
   const int coblk = blockIdx.y / cblocks, cblk = blockIdx.y - coblk * cblocks;
   const int co0 = coblk * 32, c0 = cblk * 32;
@@ -657,7 +659,7 @@ __global__ void __launch_bounds__(256) k_wgrad_tile(WgradArgs A, int tiles_x, in
       const int idx = tid + 256 * k;
       const int p = idx >> 3, c4 = idx & 7;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) gyT[b][(4 * c4 + r) * WT_GP + p] = sg[k][r];
+      for (int r = 0; r < 4; ++r) gyT(b)[(4 * c4 + r) * WT_GP + p] = sg[k][r];
     }
 #pragma unroll
     for (int k = 0; k < MAXIN; ++k) {
@@ -665,7 +667,7 @@ __global__ void __launch_bounds__(256) k_wgrad_tile(WgradArgs A, int tiles_x, in
       if (idx < n_in) {
         const int hp = idx >> 3, c4 = idx & 7;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) inT[b][(4 * c4 + r) * IP + hp] = si[k][r];
+        for (int r = 0; r < 4; ++r) inT(b)[(4 * c4 + r) * IP + hp] = si[k][r];
       }
     }
   };
@@ -683,8 +685,8 @@ __global__ void __launch_bounds__(256) k_wgrad_tile(WgradArgs A, int tiles_x, in
   for (int tile = t_beg; tile < t_end; ++tile) {
     const bool more = tile + 1 < t_end;
     if (more) stage_load(tile + 1);
-    const float* gT = gyT[cur];
-    const float* iT = inT[cur];
+    const float* gT = gyT(cur);
+    const float* iT = inT(cur);
     if (do_bias && tile / tiles_per_sample < A.n_bias) {   // bias gradient as a by-product of the staged gy tile
       const float* gr = gT + (tid >> 3) * WT_GP + 16 * (tid & 7);
       f32x4 t4 = *reinterpret_cast<const f32x4*>(gr);
@@ -1037,7 +1039,7 @@ int msgm_conv_wgrad(const msgm_conv_geom_t* geom, const float* gy, const float* 
     if (per < min_per) per = n_tiles < min_per ? n_tiles : min_per;
     wgs = (n_tiles + per - 1) / per;
     const int halo = (TH + geom->KH - 1) * (TW + geom->KW - 1);
-    const int IP = ((halo + 7) & ~7) + 3;
+    const int IP = ((halo + 2) & ~7) + 5;
     size_t lds = (size_t)2 * (32 * WT_GP + 32 * IP) * sizeof(float);
     if (lds < 4096 * sizeof(float)) lds = 4096 * sizeof(float);
     dim3 grid((unsigned)wgs, (unsigned)yblocks);
