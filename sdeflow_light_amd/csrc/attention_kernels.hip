@@ -155,7 +155,10 @@ int msgm_attention_supported(int32_t T, int32_t C) {
 int msgm_attention_forward(const float* qkv, float* out, int64_t N, int32_t T, int32_t C, float scale, msgm_stream_t stream) {
   if (!qkv || !out || N <= 0 || T <= 0 || C <= 0) return MSGM_E_BADARG;
   if (!msgm_attention_supported(T, C) || N * (int64_t)(T / 64) > 0x7fffffffLL) return MSGM_E_UNSUPPORTED;
-  const bool two = T % 128 == 0;                           // 128 queries per workgroup when T allows
+  static const bool force1 = getenv("MSGM_ATTN_QT1") != nullptr;   // diagnostic A/B
+  // 128 queries per workgroup when T allows — except at C = 128, where the second query tile costs the second
+  // resident wave per SIMD (357 registers): 89 vs 102 TFLOP/s at T = 256
+  const bool two = T % 128 == 0 && C < 128 && !force1;
   if (C == 32) return two ? launch_attn<2, 2>(qkv, out, N, T, scale, S(stream)) : launch_attn<2, 1>(qkv, out, N, T, scale, S(stream));
   if (C == 64) return two ? launch_attn<4, 2>(qkv, out, N, T, scale, S(stream)) : launch_attn<4, 1>(qkv, out, N, T, scale, S(stream));
   return two ? launch_attn<8, 2>(qkv, out, N, T, scale, S(stream)) : launch_attn<8, 1>(qkv, out, N, T, scale, S(stream));
