@@ -398,6 +398,15 @@ int msgm_bmm(const float* A, const float* B, const float* A2, const float* B2, f
              int64_t sAb, int64_t sAi, int64_t sAk, int64_t sBb, int64_t sBk, int64_t sBj,
              int64_t sCb, int64_t sCi, int64_t sCj, float alpha, int32_t accumulate, msgm_stream_t stream);
 
+/* The same with a SECOND output that shares the A operand: C3 = alpha A.B3 (B3 with B's strides, C3 with C's).
+ * The dual-number attention always needs such a pair — P v next to Pdot v + P vdot, and the three adjoint pairs of
+ * the backward alike — so the (T,T) operand is streamed from HBM once instead of twice.  Built for outputs that are
+ * contiguous along j (sCj == 1) and K % 16 == 0; MSGM_E_UNSUPPORTED otherwise.  B3 / C3 NULL = msgm_bmm. */
+int msgm_bmm_dual(const float* A, const float* B, const float* A2, const float* B2, const float* B3, float* C, float* C3,
+                  int32_t M, int32_t N, int32_t K, int32_t batch,
+                  int64_t sAb, int64_t sAi, int64_t sAk, int64_t sBb, int64_t sBk, int64_t sBj,
+                  int64_t sCb, int64_t sCi, int64_t sCj, float alpha, int32_t accumulate, msgm_stream_t stream);
+
 /* Row softmax on dual numbers (model/unet.py:249): S (primal logits) is
  * overwritten by P = softmax(S); with dual, Wd holds the tangent logits (kept
  * for backward) and Pd receives Pdot = P (Wd - sum_j P Wd).  Backward, in place:

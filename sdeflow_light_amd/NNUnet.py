@@ -324,10 +324,13 @@ class VorticityUNet(nn.Module, FlatParamMixin):
         ops.softmax_dual_forward(S, T, Wd, Pd)                           # S <- P
         att = torch.empty(N * T * C, device=dev)
         sP, sv, sa = (T * T, T, 1), (T * ld, ld, 1), (T * C, C, 1)
-        ops.bmm(S, 0, qkv, 2 * C, att, 0, T, C, T, Bp, sP, sv, sa)                                   # a = P v
         if dual:
+            # adot = P vdot + Pdot v and a = P v in ONE pass over P (msgm_bmm_dual)
             offa = Bp * T * C
-            ops.bmm(Pd, 0, qkv, 2 * C, att, offa, T, C, T, Bp, sP, sv, sa, pair2=(S, 0, qkv, half + 2 * C))   # Pdot v + P vdot
+            ops.bmm(S, 0, qkv, half + 2 * C, att, offa, T, C, T, Bp, sP, sv, sa, pair2=(Pd, 0, qkv, 2 * C),
+                    third=(qkv, 2 * C, att, 0))
+        else:
+            ops.bmm(S, 0, qkv, 2 * C, att, 0, T, C, T, Bp, sP, sv, sa)                               # a = P v
         out, _, _ = a.proj.forward([att], N, 1, T, Bp, residual=x)
         if tape is not None:
             tape.append(("attn", a, x, H, W, hn, st, qkv, S, Wd, Pd, att))
@@ -560,8 +563,8 @@ class VorticityUNet(nn.Module, FlatParamMixin):
         sP, sPt = (T * T, T, 1), (T * T, 1, T)                          # P(t,s) / P^T(s,t)
         sa, sq = (T * C, C, 1), (T * ld, ld, 1)
         # vbar = P^T abar + Pdot^T adotbar ; vdotbar = P^T adotbar
-        ops.bmm(Pm, 0, datt, 0, dqkv, 2 * C, T, C, T, Bp, sPt, sa, sq, pair2=(Pd, 0, datt, offa))
-        ops.bmm(Pm, 0, datt, offa, dqkv, half + 2 * C, T, C, T, Bp, sPt, sa, sq)
+        ops.bmm(Pm, 0, datt, 0, dqkv, 2 * C, T, C, T, Bp, sPt, sa, sq, pair2=(Pd, 0, datt, offa),
+                third=(datt, offa, dqkv, half + 2 * C))                  # both from one pass over P^T
         # Pbar = abar v^T + adotbar vdot^T ; Pdotbar = adotbar v^T
         Pb, Pdb = torch.empty_like(Pm), torch.empty_like(Pm)
         svT = (T * ld, 1, ld)                                            # B(k=c, j=s) = v[s][c]
@@ -569,11 +572,11 @@ class VorticityUNet(nn.Module, FlatParamMixin):
         ops.bmm(datt, offa, qkv, 2 * C, Pdb, 0, T, T, C, Bp, sa, svT, sP)
         ops.softmax_dual_backward(Pm, Wd, Pb, Pdb, T)                   # Pb <- Wbar, Pdb <- Wdotbar
         # qbar = s2 (Wbar k + Wdotbar kdot) ; qdotbar = s2 Wdotbar k
-        ops.bmm(Pb, 0, qkv, C, dqkv, 0, T, C, T, Bp, sP, sq, sq, alpha=s2, pair2=(Pdb, 0, qkv, half + C))
-        ops.bmm(Pdb, 0, qkv, C, dqkv, half, T, C, T, Bp, sP, sq, sq, alpha=s2)
+        ops.bmm(Pdb, 0, qkv, half + C, dqkv, 0, T, C, T, Bp, sP, sq, sq, alpha=s2, pair2=(Pb, 0, qkv, C),
+                third=(qkv, C, dqkv, half))                              # Wdotbar streamed once for both
         # kbar = s2 (Wbar^T q + Wdotbar^T qdot) ; kdotbar = s2 Wdotbar^T q
-        ops.bmm(Pb, 0, qkv, 0, dqkv, C, T, C, T, Bp, sPt, sq, sq, alpha=s2, pair2=(Pdb, 0, qkv, half))
-        ops.bmm(Pdb, 0, qkv, 0, dqkv, half + C, T, C, T, Bp, sPt, sq, sq, alpha=s2)
+        ops.bmm(Pdb, 0, qkv, half, dqkv, C, T, C, T, Bp, sPt, sq, sq, alpha=s2, pair2=(Pb, 0, qkv, 0),
+                third=(qkv, 0, dqkv, half + C))
         (dhn,) = a.qkv.backward(dqkv, [hn], N, 1, T, Bp)
         dx = self._gn_bwd(a.m.norm, xin, st, dhn, Bp, T, C, False)
         ops.lincomb(dx, dx, 1.0, dout, 1.0)

@@ -94,6 +94,8 @@ SIGNATURES = {
     "msgm_groupnorm_dual_forward": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _F, _P, _SZ, _P]),
     "msgm_groupnorm_dual_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _F, _P, _SZ, _P]),
     "msgm_bmm": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, _I32, _P]),
+    "msgm_bmm_dual": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64,
+                                _F, _I32, _P]),
     "msgm_softmax_dual_forward": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P]),
     "msgm_softmax_dual_backward": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P]),
     "msgm_pack_weights_batched": (C.c_int, [_P, _I32, _I32, _P]),

@@ -369,6 +369,10 @@ struct BmmArgs {
   int M, N, K, batch;
   long sAb, sAi, sAk, sBb, sBk, sBj, sCb, sCi, sCj;
   float alpha; int accumulate;
+  // DUAL: a second output C3 = alpha * A3 . B that shares the (big) B operand of the first pair — the dual-number
+  // attention always needs P v next to Pdot v + P vdot (and the three adjoint pairs alike), so the (T,T) operand is
+  // streamed once for both.  A3 has A's strides, C3 has C's.
+  const float* A3; float* C3;
 };
 template <bool VEC>
 __device__ __forceinline__ f32x4 bmm_frag(const float* p, long sk, bool valid) {
@@ -376,18 +380,18 @@ __device__ __forceinline__ f32x4 bmm_frag(const float* p, long sk, bool valid) {
   if (VEC) return *reinterpret_cast<const f32x4*>(p);
   return f32x4{p[0], p[sk], p[2 * sk], p[3 * sk]};
 }
-template <int MT, int NT, bool AVEC, bool BVEC>
+template <int MT, int NT, bool AVEC, bool BVEC, bool DUAL = false>
 __global__ void __launch_bounds__(256) k_bmm(BmmArgs P) {
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, il = lane & 15, q = lane >> 4;
   const int tiles_n = (P.N + 32 * NT - 1) / (32 * NT);
   const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
   const int i0 = tm * 32 * MT + (w >> 1) * 16 * MT, j0 = tn * 32 * NT + (w & 1) * 16 * NT;
   if (i0 >= P.M || j0 >= P.N) return;
-  f32x4 acc[MT][NT];
+  f32x4 acc[MT][NT], acc3[DUAL ? MT : 1][DUAL ? NT : 1];
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0, 0, 0, 0};
+    for (int n = 0; n < NT; ++n) { acc[m][n] = f32x4{0, 0, 0, 0}; if (DUAL) acc3[m][n] = f32x4{0, 0, 0, 0}; }
   bool vi[MT], vj[NT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) vi[m] = i0 + 16 * m + il < P.M;
@@ -407,15 +411,24 @@ __global__ void __launch_bounds__(256) k_bmm(BmmArgs P) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) bp[n] = Bb + (size_t)(vj[n] ? j0 + 16 * n + il : 0) * P.sBj + (size_t)(4 * q) * P.sBk;
     const size_t stepA = (size_t)16 * P.sAk, stepB = (size_t)16 * P.sBk;
-    f32x4 na[MT], nb[NT];
+    const bool third = DUAL && pair == 0;                 // A3 rides along with the first pair's B operand
+    const float* ap3[MT];
+    f32x4 na[MT], nb[NT], na3[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) na[m] = bmm_frag<AVEC>(ap[m], P.sAk, vi[m]);
 #pragma unroll
     for (int n = 0; n < NT; ++n) nb[n] = bmm_frag<BVEC>(bp[n], P.sBk, vj[n]);
-    for (int g = 0; g < ngroups; ++g) {
-      f32x4 a[MT], b[NT];
+    if (third) {
 #pragma unroll
-      for (int m = 0; m < MT; ++m) { a[m] = na[m]; ap[m] += stepA; }
+      for (int m = 0; m < MT; ++m) {
+        ap3[m] = P.A3 + (size_t)blockIdx.y * P.sAb + (size_t)(vi[m] ? i0 + 16 * m + il : 0) * P.sAi + (size_t)(4 * q) * P.sAk;
+        na3[m] = bmm_frag<AVEC>(ap3[m], P.sAk, vi[m]);
+      }
+    }
+    for (int g = 0; g < ngroups; ++g) {
+      f32x4 a[MT], b[NT], a3[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) { a[m] = na[m]; ap[m] += stepA; if (third) { a3[m] = na3[m]; ap3[m] += stepA; } }
 #pragma unroll
       for (int n = 0; n < NT; ++n) { b[n] = nb[n]; bp[n] += stepB; }
       if (g + 1 < ngroups) {
@@ -423,17 +436,26 @@ __global__ void __launch_bounds__(256) k_bmm(BmmArgs P) {
         for (int m = 0; m < MT; ++m) na[m] = bmm_frag<AVEC>(ap[m], P.sAk, vi[m]);
 #pragma unroll
         for (int n = 0; n < NT; ++n) nb[n] = bmm_frag<BVEC>(bp[n], P.sBk, vj[n]);
+        if (third) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m) na3[m] = bmm_frag<AVEC>(ap3[m], P.sAk, vi[m]);
+        }
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int n = 0; n < NT; ++n) acc[m][n] = mfma16u(a[m][r], b[n][r], acc[m][n]);
+          for (int n = 0; n < NT; ++n) {
+            acc[m][n] = mfma16u(a[m][r], b[n][r], acc[m][n]);
+            if (third) acc3[m][n] = mfma16u(a3[m][r], b[n][r], acc3[m][n]);
+          }
     }
   }
-  float* Cb = P.C + (size_t)blockIdx.y * P.sCb;
-  const bool cvec = P.sCi == 1 && (P.sCj & 3) == 0 && (P.sCb & 3) == 0 && ((reinterpret_cast<uintptr_t>(P.C) & 15) == 0);
+#pragma unroll
+  for (int which = 0; which < (DUAL ? 2 : 1); ++which) {
+  float* Cb = (which ? P.C3 : P.C) + (size_t)blockIdx.y * P.sCb;
+  const bool cvec = P.sCi == 1 && (P.sCj & 3) == 0 && (P.sCb & 3) == 0 && ((reinterpret_cast<uintptr_t>(which ? P.C3 : P.C) & 15) == 0);
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -442,7 +464,7 @@ __global__ void __launch_bounds__(256) k_bmm(BmmArgs P) {
       if (j >= P.N) continue;
       const int i = i0 + 16 * m + 4 * q;
       if (i >= P.M) continue;
-      f32x4 v = P.alpha * acc[m][n];
+      f32x4 v = P.alpha * (which ? acc3[DUAL ? m : 0][DUAL ? n : 0] : acc[m][n]);
       if (cvec && i + 3 < P.M) {
         float* cp = Cb + (size_t)j * P.sCj + i;
         if (P.accumulate) v += *reinterpret_cast<const f32x4*>(cp);
@@ -456,6 +478,7 @@ __global__ void __launch_bounds__(256) k_bmm(BmmArgs P) {
         }
       }
     }
+  }
 }
 
 // generic-K fallback (K % 16 != 0): scalar, one k per lane quarter
@@ -720,8 +743,20 @@ int msgm_groupnorm_dual_backward(const float* x, const float* gamma, const float
 int msgm_bmm(const float* A, const float* B, const float* A2, const float* B2, float* C, int32_t M, int32_t N, int32_t K,
              int32_t batch, int64_t sAb, int64_t sAi, int64_t sAk, int64_t sBb, int64_t sBk, int64_t sBj, int64_t sCb,
              int64_t sCi, int64_t sCj, float alpha, int32_t accumulate, msgm_stream_t stream) {
+  return msgm_bmm_dual(A, B, A2, B2, nullptr, C, nullptr, M, N, K, batch, sAb, sAi, sAk, sBb, sBk, sBj, sCb, sCi, sCj, alpha,
+                       accumulate, stream);
+}
+
+int msgm_bmm_dual(const float* A, const float* B, const float* A2, const float* B2, const float* B3, float* C, float* C3,
+                  int32_t M, int32_t N, int32_t K, int32_t batch, int64_t sAb, int64_t sAi, int64_t sAk, int64_t sBb,
+                  int64_t sBk, int64_t sBj, int64_t sCb, int64_t sCi, int64_t sCj, float alpha, int32_t accumulate,
+                  msgm_stream_t stream) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || ((A2 == nullptr) != (B2 == nullptr))) return MSGM_E_BADARG;
-  BmmArgs P{A, B, A2, B2, C, M, N, K, batch, sAb, sAi, sAk, sBb, sBk, sBj, sCb, sCi, sCj, alpha, accumulate};
+  if ((B3 == nullptr) != (C3 == nullptr)) return MSGM_E_BADARG;
+  // the second output shares the A operand: C3 = alpha A.B3 — built for the case where the host swap below turns A
+  // into the kernel's B role (outputs contiguous along j, as every attention product here), K % 16 == 0
+  if (B3 && (!(sCj == 1 && sCi != 1) || K % 16)) return MSGM_E_UNSUPPORTED;
+  BmmArgs P{A, B, A2, B2, C, M, N, K, batch, sAb, sAi, sAk, sBb, sBk, sBj, sCb, sCi, sCj, alpha, accumulate, B3, C3};
   if (sCj == 1 && sCi != 1) {
     // C^T = B^T A^T: make the output's contiguous dimension the MFMA row index (16-B stores)
     P.A = B; P.B = A; P.A2 = B2; P.B2 = A2;
@@ -740,6 +775,14 @@ int msgm_bmm(const float* A, const float* B, const float* A2, const float* B2, f
   const bool bvec = P.sBk == 1 && (P.sBj % 4 == 0) && (P.sBb % 4 == 0) && al16(P.B) && al16(P.B2);
   const int tiles = ((P.M + 63) / 64) * ((P.N + 63) / 64);
   dim3 grid((unsigned)tiles, (unsigned)batch);
+  if (P.A3) {
+    const bool avec3 = avec && al16(P.A3);
+    if (avec3 && bvec) hipLaunchKernelGGL((k_bmm<2, 2, true, true, true>), grid, dim3(256), 0, S(stream), P);
+    else if (avec3) hipLaunchKernelGGL((k_bmm<2, 2, true, false, true>), grid, dim3(256), 0, S(stream), P);
+    else if (bvec) hipLaunchKernelGGL((k_bmm<2, 2, false, true, true>), grid, dim3(256), 0, S(stream), P);
+    else hipLaunchKernelGGL((k_bmm<2, 2, false, false, true>), grid, dim3(256), 0, S(stream), P);
+    return msgm_check_launch();
+  }
   if (avec && bvec) hipLaunchKernelGGL((k_bmm<2, 2, true, true>), grid, dim3(256), 0, S(stream), P);
   else if (avec) hipLaunchKernelGGL((k_bmm<2, 2, true, false>), grid, dim3(256), 0, S(stream), P);
   else if (bvec) hipLaunchKernelGGL((k_bmm<2, 2, false, true>), grid, dim3(256), 0, S(stream), P);

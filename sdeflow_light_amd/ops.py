@@ -473,7 +473,7 @@ def groupnorm_dual_backward(x, gamma, beta, stats, gout, dgamma, dbeta, Bp, P, C
     return gx
 
 
-def bmm(A, a_off, B, b_off, Cm, c_off, M, N, K, batch, sA, sB, sC, alpha=1.0, accumulate=False, pair2=None):
+def bmm(A, a_off, B, b_off, Cm, c_off, M, N, K, batch, sA, sB, sC, alpha=1.0, accumulate=False, pair2=None, third=None):
     """C[b](i,j) (+)= alpha (sum_k A[b](i,k) B[b](k,j) [+ A2.B2]); sA = (batch, i, k), sB = (batch, k, j),
     sC = (batch, i, j) element strides; *_off are element offsets into the given tensors (channel slices of a fused
     qkv tensor).  pair2 = (A2, a2_off, B2, b2_off): a second product with the same strides, summed in registers."""
@@ -488,9 +488,15 @@ def bmm(A, a_off, B, b_off, Cm, c_off, M, N, K, batch, sA, sB, sC, alpha=1.0, ac
         if span(a2_off, sA, (batch, M, K)) > A2.numel() or span(b2_off, sB, (batch, K, N)) > B2.numel():
             raise MsgmError("bmm: second pair runs past the end of a tensor")
         pa2, pb2 = ptr(f32(A2)) + 4 * a2_off, ptr(f32(B2)) + 4 * b2_off
-    check(lib().msgm_bmm(ptr(f32(A)) + 4 * a_off, ptr(f32(B)) + 4 * b_off, pa2, pb2, ptr(f32(Cm)) + 4 * c_off, M, N, K, batch,
-                         sA[0], sA[1], sA[2], sB[0], sB[1], sB[2], sC[0], sC[1], sC[2], float(alpha), int(bool(accumulate)),
-                         stream()), "msgm_bmm")
+    pb3 = pc3 = None
+    if third is not None:        # third = (B3, b3_off, C3, c3_off): second output C3 = alpha A.B3, A streamed once
+        B3, b3_off, C3, c3_off = third
+        if span(b3_off, sB, (batch, K, N)) > B3.numel() or span(c3_off, sC, (batch, M, N)) > C3.numel():
+            raise MsgmError("bmm: third operand / second output runs past the end of a tensor")
+        pb3, pc3 = ptr(f32(B3)) + 4 * b3_off, ptr(f32(C3)) + 4 * c3_off
+    check(lib().msgm_bmm_dual(ptr(f32(A)) + 4 * a_off, ptr(f32(B)) + 4 * b_off, pa2, pb2, pb3, ptr(f32(Cm)) + 4 * c_off, pc3,
+                              M, N, K, batch, sA[0], sA[1], sA[2], sB[0], sB[1], sB[2], sC[0], sC[1], sC[2], float(alpha),
+                              int(bool(accumulate)), stream()), "msgm_bmm")
 
 
 def softmax_dual_forward(S, T, Wd=None, Pd=None):

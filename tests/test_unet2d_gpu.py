@@ -385,3 +385,33 @@ def test_unet2d_sampler_forward_gn_fold_equals_unfused(monkeypatch):
     monkeypatch.setenv("MSGM_NO_GN_FOLD", "1")
     plain = net(x, t)
     assert rel_l2(fused.cpu(), plain.cpu()) <= 2e-4
+
+
+def test_bmm_dual_output_shares_the_big_operand():
+    """msgm_bmm_dual: C = A.B + A2.B2 and C3 = A.B3 in one pass over A (the (T,T) operand of the dual attention),
+    plain and transposed A, channel-sliced operands — vs torch einsum, 1e-5."""
+    from sdeflow_light_amd import ops
+    torch.manual_seed(9)
+    Bn, T, C = 3, 96, 32
+    ld = 3 * C
+    P, Pd = torch.randn(Bn, T, T), torch.randn(Bn, T, T)
+    qkv = torch.randn(2 * Bn, T, ld)                                   # primal | tangent rows
+    v, vd = qkv[:Bn, :, 2 * C:], qkv[Bn:, :, 2 * C:]
+    half = Bn * T * ld
+    qd, Pg, Pdg = qkv.to(DEV).contiguous().view(-1), P.to(DEV).contiguous().view(-1), Pd.to(DEV).contiguous().view(-1)
+    att = torch.full((2 * Bn * T * C,), float("nan"), device=DEV)
+    sP, sPt, sv, sa = (T * T, T, 1), (T * T, 1, T), (T * ld, ld, 1), (T * C, C, 1)
+    ops.bmm(Pg, 0, qd, half + 2 * C, att, Bn * T * C, T, C, T, Bn, sP, sv, sa, pair2=(Pdg, 0, qd, 2 * C), third=(qd, 2 * C, att, 0))
+    a_ref = torch.einsum("bts,bsc->btc", P, v)
+    ad_ref = torch.einsum("bts,bsc->btc", P, vd) + torch.einsum("bts,bsc->btc", Pd, v)
+    out = att.view(2 * Bn, T, C).cpu()
+    assert rel_l2(out[:Bn], a_ref) <= 1e-5 and rel_l2(out[Bn:], ad_ref) <= 1e-5
+    # transposed shared operand, alpha, outputs written into channel slices of a wider tensor
+    dq = torch.zeros(2 * Bn * T * ld, device=DEV)
+    ops.bmm(Pdg, 0, qd, half, dq, C, T, C, T, Bn, sPt, sv, sv, alpha=0.5, pair2=(Pg, 0, qd, 0), third=(qd, 0, dq, half + C))
+    q_, qdot = qkv[:Bn, :, :C], qkv[Bn:, :, :C]
+    k_ref = 0.5 * (torch.einsum("bts,btc->bsc", Pd, qdot) + torch.einsum("bts,btc->bsc", P, q_))
+    kd_ref = 0.5 * torch.einsum("bts,btc->bsc", Pd, q_)
+    o = dq.view(2 * Bn, T, ld).cpu()
+    assert rel_l2(o[:Bn, :, C:2 * C], k_ref) <= 1e-5 and rel_l2(o[Bn:, :, C:2 * C], kd_ref) <= 1e-5
+    assert float(o[:, :, :C].abs().max()) == 0.0 and float(o[:, :, 2 * C:].abs().max()) == 0.0
