@@ -246,7 +246,10 @@ __global__ void __launch_bounds__(256) k_conv_gemm(ConvArgs A) {
 // KS = kernel size (1 or 3; the 1-D variants have KH = 1): compile-time, so the halo index arithmetic of the staging
 // (hp / HW per staged 16 B) is multiplications by constants instead of integer divisions.
 template <int TH, int TW, int NCO, int KS>
-__global__ void __launch_bounds__(256) k_conv_tile(ConvArgs A, int flip, int tiles_x, int tiles_y, int tiles_per_wg, int n_tiles) {
+#ifndef CT_MINWG
+#define CT_MINWG 1
+#endif
+__global__ void __launch_bounds__(256, CT_MINWG) k_conv_tile(ConvArgs A, int flip, int tiles_x, int tiles_y, int tiles_per_wg, int n_tiles) {
   extern __shared__ __attribute__((aligned(16))) float ct_lds[];
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, il = lane & 15, q = lane >> 4;
   const ConvGeom g = A.g;
@@ -355,7 +358,9 @@ __global__ void __launch_bounds__(256) k_conv_tile(ConvArgs A, int flip, int til
     const bool last_chunk = ns >= A.nsrc || nch[ns] == 0;
     if (last_chunk) { ntile = tile + 1; ns = 0; nc = 0; }
     const bool more = ntile < t_end;
+#ifndef CT_SINGLE
     if (more) stage_load(ntile, ns, nc * CT_KC);
+#endif
     if (cs == 0 && cc == 0) {
 #pragma unroll
       for (int c = 0; c < NCO; ++c) { acc[c][0] = f32x4{0, 0, 0, 0}; acc[c][1] = f32x4{0, 0, 0, 0}; }
@@ -480,6 +485,14 @@ __global__ void __launch_bounds__(256) k_conv_tile(ConvArgs A, int flip, int til
       }
     }
     if (!more) break;
+#ifdef CT_SINGLE        // diagnostic: one LDS buffer, the next item is fetched after this one's MFMAs
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    stage_load(ntile, ns, nc * CT_KC);
+    stage_store(cur);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    tile = ntile; cs = ns; cc = nc;
+    continue;
+#endif
     stage_store(nxt);
     // LDS hand-off only: __syncthreads() would also drain vmcnt, i.e. wait for this tile's output stores to land
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -967,7 +980,11 @@ int msgm_conv_forward_fused(const msgm_conv_geom_t* geom, const float* src0, int
     const int TH = two_d ? 8 : 1, TW = two_d ? 16 : 128;
     const int tiles_x = (geom->Wo + TW - 1) / TW, tiles_y = (geom->Ho + TH - 1) / TH;
     const int halo = (TH + geom->KH - 1) * (TW + geom->KW - 1);
+#ifdef CT_SINGLE
+    const size_t lds = (size_t)1 * halo * CT_P * sizeof(float);
+#else
     const size_t lds = (size_t)2 * halo * CT_P * sizeof(float);
+#endif
     const int nco = (CoutP % 64 == 0) ? 4 : 2;
     const int n_tiles = tiles_x * tiles_y * geom->N, gy = CoutP / (16 * nco);
     // several consecutive tiles per workgroup (the next tile's halo loads overlap this tile's MFMAs) — but only
