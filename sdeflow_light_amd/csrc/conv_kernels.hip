@@ -606,6 +606,9 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(WgradArgs A) {
 // Each wave reduces its own 32 pixels; the four partial sums meet in LDS at the end and are added to dWp with one
 // float atomic per element per workgroup.
 #define WT_GP 132
+#ifndef WT_DBUF
+#define WT_DBUF(TAPS) ((TAPS) == 9)
+#endif
 template <int TH, int TW, int TAPS>
 __global__ void __launch_bounds__(256, 2) k_wgrad_tile(WgradArgs A, int tiles_x, int tiles_y, int tiles_per_wg, int n_tiles) {
   extern __shared__ __attribute__((aligned(16))) float wt_lds[];
@@ -691,6 +694,10 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_tile(WgradArgs A, int tiles_x,
   const bool do_bias = A.dbias != nullptr && cblk == 0;
   const int tiles_per_sample = tiles_x * tiles_y;
   float bsum = 0.f;                                        // thread (co = tid>>3, 16-pixel part = tid&7)
+  // LDS buffering: the 3x3 variant is register-bound to two workgroups per CU and keeps two LDS buffers (one barrier
+  // per tile); the others have registers for three and keep ONE buffer (34 KB) so that three fit — the next tile
+  // still travels global -> registers under this tile's MFMAs, only its LDS store waits for an extra barrier.
+  constexpr bool DBUF = WT_DBUF(TAPS);
   stage_load(t_beg);
   stage_store(0);
   __syncthreads();
@@ -735,9 +742,15 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_tile(WgradArgs A, int tiles_x,
           }
       }
     }
-    if (more) stage_store(cur ^ 1);
-    __syncthreads();
-    cur ^= 1;
+    if (DBUF) {
+      if (more) stage_store(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    } else {
+      __syncthreads();                                       // every wave is done reading the buffer
+      if (more) stage_store(0);
+      __syncthreads();
+    }
   }
   if (do_bias) {
     bsum += __shfl_xor(bsum, 1, 64);
@@ -1057,7 +1070,7 @@ int msgm_conv_wgrad(const msgm_conv_geom_t* geom, const float* gy, const float* 
     wgs = (n_tiles + per - 1) / per;
     const int halo = (TH + geom->KH - 1) * (TW + geom->KW - 1);
     const int IP = ((halo + 2) & ~7) + 5;
-    size_t lds = (size_t)2 * (32 * WT_GP + 32 * IP) * sizeof(float);
+    size_t lds = (size_t)(WT_DBUF(taps) ? 2 : 1) * (32 * WT_GP + 32 * IP) * sizeof(float);
     if (lds < 4096 * sizeof(float)) lds = 4096 * sizeof(float);
     dim3 grid((unsigned)wgs, (unsigned)yblocks);
     // more than 64 KB of dynamic LDS has to be opted into per kernel (160 KB per CU on gfx950)
