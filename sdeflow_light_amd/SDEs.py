@@ -95,6 +95,37 @@ class SDE(nn.Module):
     def IJK(self):
         return None, None, None
 
+    # -- forward-process samplers of the base class (SDEs.py:78-146), same names and arguments ----------------
+    @torch.no_grad()
+    def sample_scheme(self, t, y0, keep_all_samples=False, return_noise=False):
+        """y_t | y_0 by RK4 on the forward process (SDEs.py:78-122) — one device-resident masked multi-stop
+        integration instead of the per-row Python loop; ``keep_all_samples`` only chose the capture buffer upstream."""
+        if return_noise:
+            raise NotImplementedError('See the official repository.')
+        from .sde_scheme import msgm_forward_perturb
+        return msgm_forward_perturb(self, t, y0)
+
+    @torch.no_grad()
+    def sample_scheme_allt(self, y0, include_t0=True, keep_all_samples=True, samplesToKeep=None):
+        """y_0, y_{t_1}, ..., y_T | y_0 (SDEs.py:124-132)."""
+        from .sde_scheme import rk4_stratonovich_sampler
+        return rk4_stratonovich_sampler(forward_SDE(self, self.T).to(self.device), y0, num_steps=self.num_steps_forward, lmbd=0,
+                                        keep_all_samples=keep_all_samples, samplesToKeep=samplesToKeep, include_t0=include_t0)
+
+    def sample_Song_et_al(self, t, y0, return_noise=False, eps=None):
+        """Closed-form y_t | y_0 of the VP SDE (SDEs.py:134-146) in one kernel; with ``return_noise`` also
+        (epsilon, std, g(t, y_t)) as upstream."""
+        if self.kind != L.SDE_SGM:
+            raise MsgmError("sample_Song_et_al is the closed form of the additive (VP) SDE")
+        T = self.T_float()
+        y, _, e = ops.perturb_vp(y0.contiguous().float(), self.struct(), u=(t.reshape(-1) / T).contiguous().float(), eps=eps,
+                                 rng=None if eps is not None else self.philox(y0.device), return_eps=True)
+        if eps is None:
+            self.rng.advance(1)
+        if not return_noise:
+            return y
+        return y, e, self.var(t) ** 0.5, self.g(t, y)
+
     def sample_debiasing_t(self, shape):
         raise NotImplementedError('See the official repository.')
 
@@ -153,6 +184,11 @@ class SGMsde(SDE):
 
     def cond_latent_sample(self, t_, T, x, eps=None):
         return self.sample(torch.ones_like(t_) * T, x, eps=eps)
+
+    @property
+    def logvar_mean_T(self):
+        """SDEs.py:171-175."""
+        return torch.zeros(1), torch.zeros(1)
 
     def log_normal(self, x, mean, log_var, eps=0.00001):
         """SDEs.py:213-215."""
@@ -231,6 +267,17 @@ class MSGMsde(SDE):
 
     def IJK(self):
         return (self.G_I, self.G_J, self.G_K) if self.sparseTensor else (None, None, None)
+
+    def sparse_G_full(self, n):
+        """Dense (n,n,n) image of the sparse nearest-neighbour rotation tensor (SDEs.py:343-367), for checks."""
+        k = torch.arange(n)
+        kp = (k + 1) % n
+        c = 0.5 * math.sqrt(2.0)
+        G = torch.zeros(n, n, n, device=self.device)
+        G[k, kp, k] = c
+        G[kp, k, k] = -c
+        self.G = G
+        return G
 
     # -- accessors (API compatibility) ----------------------------------------
     def f(self, t, y):
@@ -361,6 +408,31 @@ class PluginReverseSDE(nn.Module):
 
     def sigma(self, t, y, lmbd=0., sparse=False):
         return (1. - lmbd) ** 0.5 * self.base_sde.g(self.T - t, y, sparse)
+
+    def ga(self, s, y):
+        """g(s, y) . a(y, s) with a per-row forward time s (SDEs.py:563-580).  Accessor-level (the integrators use
+        the fused stage kernel through ``mu`` / ``mu_Strato`` instead, which takes a batch-uniform time)."""
+        base = self.base_sde
+        a = self.a(y, s.reshape(-1))
+        if base.kind == L.SDE_SGM:
+            return base.g(s, y) * a
+        if base.sparseTensor:
+            I, _, K = base.IJK()
+            return torch.zeros_like(y).scatter_add_(1, I.unsqueeze(0).expand(y.shape[0], -1), base.g(s, y, True) * a[:, K])
+        return torch.einsum('bij, bj -> bi', base.g(s, y), a)
+
+    def ga_m_drift(self, s, y, lmbd=0.):
+        """Drift of the reverse generative SDE at forward time s (SDEs.py:560-561); mu(t) = ga_m_drift(T - t)."""
+        base = self.base_sde
+        return (1. - 0.5 * lmbd) * self.ga(s, y) - base.f(s, y) + (1. - lmbd) * base.div_Sigma(s, y)
+
+    def sample_t_linspace(self, x):
+        """Gridded t in (0, T] with the entries <= t_epsilon dropped (SDEs.py:695-706); returns (t, mask)."""
+        nsf = self.base_sde.num_steps_forward
+        T = self.base_sde.T_float()
+        t_ = torch.linspace(T / nsf, T, nsf).to(x.device)
+        mask_le_t_eps = (t_ <= self.base_sde.t_epsilon)
+        return t_[~mask_le_t_eps], mask_le_t_eps
 
     # ---- SSM loss -------------------------------------------------------------
     def sample_t(self, x, u=None):

@@ -472,3 +472,54 @@ def test_elbo_and_evaluate_golden():
     mean, se = evaluate(gen, g["elbo_x"].to(DEV))
     assert mean.dim() == 0 and se.dim() == 0 and torch.isfinite(mean) and float(se) > 0
     assert gen.training
+
+
+def test_reference_api_surface_wrappers():
+    """Names the reference exposes next to the hot path and that a driver may call (SDEs.py:78-146,171-175,343-367,
+    560-580,695-706): thin wrappers over the same kernels — checked against the accessor-level formulas."""
+    from sdeflow_light_amd.NN import MLP
+    torch.manual_seed(5)
+    gen = make_gen("sgm", MLP(2))
+    base = gen.base_sde
+    B = 64
+    x = torch.randn(B, 2, device=DEV)
+    t = torch.rand(B, 1, device=DEV).clamp_min(1e-3)
+    eps = torch.randn(B, 2, device=DEV)
+    y, e, std, g = base.sample_Song_et_al(t, x, return_noise=True, eps=eps)
+    assert torch.equal(e, eps) and rel_l2(y.cpu(), base.sample(t, x, eps=eps).cpu()) == 0.0
+    assert rel_l2(std.cpu(), (base.var(t) ** 0.5).cpu()) == 0.0 and g.shape == y.shape
+    assert rel_l2(y.cpu(), (base.mean_weight(t) * x + std * eps).cpu()) <= 1e-6
+    lv, mn = base.logvar_mean_T
+    assert float(lv) == 0.0 and float(mn) == 0.0
+    # reverse drift pieces: mu(t) = ga_m_drift(T - t); ga = g . a
+    s = torch.rand(B, 1, device=DEV) * 0.8 + 0.1
+    yy = torch.randn(B, 2, device=DEV)
+    a = gen.a(yy, s.reshape(-1))
+    assert rel_l2(gen.ga(s, yy).cpu(), (base.g(s, yy) * a).cpu()) <= 1e-5
+    lm = 0.3
+    ref = (1 - 0.5 * lm) * base.g(s, yy) * a - base.f(s, yy) + (1 - lm) * base.div_Sigma(s, yy)
+    assert rel_l2(gen.ga_m_drift(s, yy, lm).cpu(), ref.cpu()) <= 1e-5
+    su = torch.full((B, 1), 0.37, device=DEV)                        # uniform time: the fused stage kernel agrees
+    assert rel_l2(gen.mu(1.0 - su, yy, lm).cpu(), gen.ga_m_drift(su, yy, lm).cpu()) <= 1e-5
+    tl, mask = gen.sample_t_linspace(x)
+    nsf = base.num_steps_forward
+    full = torch.linspace(1.0 / nsf, 1.0, nsf)
+    assert torch.equal(mask.cpu(), full <= base.t_epsilon) and rel_l2(tl.cpu(), full[full > base.t_epsilon]) <= 1e-7
+    # multiplicative SDE: sample_scheme is the device-resident forward perturbation, sample_scheme_allt the RK4 path
+    gm = make_gen("sparse", MLP(6, premodule="NormalizeLogRadius"), n=6, nsf=4)
+    bm = gm.base_sde
+    x6 = torch.randn(10, 6, device=DEV)
+    t6 = torch.tensor([[0.05], [0.3], [0.5], [0.26], [0.76], [1.0], [0.1], [0.9], [0.25], [0.6]], device=DEV)
+    st = bm.philox(DEV).state.clone()
+    ya = bm.sample_scheme(t6, x6, keep_all_samples=False)
+    bm.rng.state.copy_(st)
+    yb = bm.sample(t6, x6)
+    assert torch.equal(ya, yb)
+    traj = bm.sample_scheme_allt(x6, include_t0=True, keep_all_samples=True)
+    assert tuple(traj.shape) == (5, 10, 6) and rel_l2(traj[0], x6.cpu()) == 0.0
+    Gd = bm.sparse_G_full(6)
+    dense = torch.einsum("ijk,bj->bik", Gd, x6)                       # g with beta = 1
+    v = torch.randn(10, 6, device=DEV)
+    I, J, K = bm.IJK()
+    sp = torch.zeros(10, 6, device=DEV).scatter_add_(1, I.unsqueeze(0).expand(10, -1), (bm.G_V * x6[:, J]) * v[:, K])
+    assert rel_l2(torch.einsum("bik,bk->bi", dense, v).cpu(), sp.cpu()) <= 1e-6
