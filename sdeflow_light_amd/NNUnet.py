@@ -34,6 +34,20 @@ SILU = ops.ACT_SILU
 scale_image = 5          # NNUnet.py:19
 
 
+def flat_to_img(x: torch.Tensor, H: int, W: int, order: Literal["C", "F"] = "C") -> torch.Tensor:
+    """x (B, H*W) / scale_image -> (B, 1, H, W), C or F (column-major) ordering (NNUnet.py:26-51) — one kernel."""
+    B, d = x.shape
+    assert d == H * W, f"Expected d={H * W}, got {d}"
+    return ops.flat_to_image(x.contiguous().float(), B, 1, H, W, order == "F", 1.0 / scale_image).view(B, 1, H, W)
+
+
+def img_to_flat(y: torch.Tensor, order: Literal["C", "F"] = "C") -> torch.Tensor:
+    """y (B, 1, H, W) * scale_image -> (B, H*W) (NNUnet.py:53-77)."""
+    B, C, H, W = y.shape
+    assert C == 1, f"Expected 1 channel, got {C}"
+    return ops.image_to_flat(y.contiguous().float().view(-1), B, 1, H, W, order == "F", float(scale_image))
+
+
 def zero_module(m):
     for p in m.parameters():
         p.detach().zero_()

@@ -415,3 +415,17 @@ def test_bmm_dual_output_shares_the_big_operand():
     o = dq.view(2 * Bn, T, ld).cpu()
     assert rel_l2(o[:Bn, :, C:2 * C], k_ref) <= 1e-5 and rel_l2(o[Bn:, :, C:2 * C], kd_ref) <= 1e-5
     assert float(o[:, :, :C].abs().max()) == 0.0 and float(o[:, :, 2 * C:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("order", ["C", "F"])
+def test_flat_img_helpers_match_reference_semantics(order):
+    """flat_to_img / img_to_flat (NNUnet.py:26-77): /5 and view (C) or view(B,1,W,H).transpose (F); inverse x5."""
+    from sdeflow_light_amd.NNUnet import flat_to_img, img_to_flat
+    torch.manual_seed(2)
+    B, H, W = 3, 6, 10
+    x = torch.randn(B, H * W)
+    ref = (x / 5).view(B, 1, H, W) if order == "C" else (x / 5).view(B, 1, W, H).transpose(2, 3).contiguous()
+    img = flat_to_img(x.to(DEV), H, W, order)
+    assert img.shape == (B, 1, H, W) and rel_l2(img.cpu(), ref) <= 1e-7
+    back = img_to_flat(img, order)
+    assert back.shape == (B, H * W) and rel_l2(back.cpu(), x) <= 1e-6
