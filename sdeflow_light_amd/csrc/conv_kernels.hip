@@ -245,7 +245,11 @@ __global__ void __launch_bounds__(256) k_conv_gemm(ConvArgs A) {
 #define CT_P 36
 // KS = kernel size (1 or 3; the 1-D variants have KH = 1): compile-time, so the halo index arithmetic of the staging
 // (hp / HW per staged 16 B) is multiplications by constants instead of integer divisions.
-template <int TH, int TW, int NCO, int KS>
+// PT = 16-pixel tiles per wave (TH*TW = 64*PT pixels per workgroup), DB = two LDS buffers + register prefetch of the
+// next item.  <PT=2, DB> is the small-image / 1x1 form; 3-tap kernels on images that have 256-pixel tiles run
+// <PT=4, !DB>: twice the pixels per wave give each weight fragment 4 MFMAs instead of 2 and halve the halo overhead,
+// and the bigger halo is single-buffered so that three workgroups still share a CU (their MFMAs cover the staging).
+template <int TH, int TW, int NCO, int KS, int PT = 2, bool DB = true>
 #ifndef CT_MINWG
 #define CT_MINWG 1
 #endif
@@ -262,14 +266,15 @@ __global__ void __launch_bounds__(256, CT_MINWG) k_conv_tile(ConvArgs A, int fli
   // item, so the halo of the NEXT tile is in flight during the MFMAs of this one even when Cin fits one chunk.
   const int t_beg = blockIdx.x * tiles_per_wg, t_end = min(t_beg + tiles_per_wg, n_tiles);
   if (t_beg >= t_end) return;
-  // this lane's two output pixels inside a tile
-  int pty[2], ptx[2];
+  static_assert(TH * TW == 64 * PT, "tile = 4 waves x PT MFMA column tiles");
+  // this lane's PT output pixels inside a tile
+  int pty[PT], ptx[PT];
 #pragma unroll
-  for (int pt = 0; pt < 2; ++pt) {
-    const int p = 32 * w + 16 * pt + il;
+  for (int pt = 0; pt < PT; ++pt) {
+    const int p = 16 * PT * w + 16 * pt + il;
     pty[pt] = p / TW; ptx[pt] = p - pty[pt] * TW;
   }
-  f32x4 acc[NCO][2];
+  f32x4 acc[NCO][PT];
 
   // chunk list: (source, channel offset), flattened
   int nch[CONV_MAX_SRC];
@@ -358,12 +363,12 @@ __global__ void __launch_bounds__(256, CT_MINWG) k_conv_tile(ConvArgs A, int fli
     const bool last_chunk = ns >= A.nsrc || nch[ns] == 0;
     if (last_chunk) { ntile = tile + 1; ns = 0; nc = 0; }
     const bool more = ntile < t_end;
-#ifndef CT_SINGLE
-    if (more) stage_load(ntile, ns, nc * CT_KC);
-#endif
+    if (DB && more) stage_load(ntile, ns, nc * CT_KC);
     if (cs == 0 && cc == 0) {
 #pragma unroll
-      for (int c = 0; c < NCO; ++c) { acc[c][0] = f32x4{0, 0, 0, 0}; acc[c][1] = f32x4{0, 0, 0, 0}; }
+      for (int c = 0; c < NCO; ++c)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) acc[c][pt] = f32x4{0, 0, 0, 0};
     }
     // ---- MFMAs of this chunk: (tap, 16-channel group) pairs, weight fragments one pair ahead
     const int C = A.C[cs];
@@ -416,28 +421,28 @@ __global__ void __launch_bounds__(256, CT_MINWG) k_conv_tile(ConvArgs A, int fli
 #endif
       const int kh = tap / KW, kw = tap - kh * KW;
       const int oy = flip ? (KH - 1 - kh) : kh, ox = flip ? (KW - 1 - kw) : kw;
-      f32x4 b[2];
+      f32x4 b[PT];
 #ifndef CT_EXP_NOLDS    // diagnostic: -DCT_EXP_NOLDS feeds the MFMAs from registers (no activation reads)
 #pragma unroll
-      for (int pt = 0; pt < 2; ++pt)
+      for (int pt = 0; pt < PT; ++pt)
         b[pt] = *reinterpret_cast<const f32x4*>(cur + ((pty[pt] + oy) * HW + ptx[pt] + ox) * CT_P + 16 * grp + 4 * q);
 #else
-      b[0] = a[0]; b[1] = a[NCO - 1];
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) b[pt] = a[pt % NCO];
       (void)oy; (void)ox;
 #endif
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int c = 0; c < NCO; ++c) {
-          acc[c][0] = mfma16c(a[c][r], b[0][r], acc[c][0]);
-          acc[c][1] = mfma16c(a[c][r], b[1][r], acc[c][1]);
-        }
+        for (int c = 0; c < NCO; ++c)
+#pragma unroll
+          for (int pt = 0; pt < PT; ++pt) acc[c][pt] = mfma16c(a[c][r], b[pt][r], acc[c][pt]);
       tap = ntap; grp = ngr;
     }
 
     // ---- epilogue of a finished tile (same contract as k_conv_gemm)
 #ifdef CT_EXP_NOEPI      // diagnostic: one lane stores one value
-    if (last_chunk && tid == 0 && tile == t_beg) A.out[0] = acc[0][0][0] + acc[NCO - 1][1][3];
+    if (last_chunk && tid == 0 && tile == t_beg) A.out[0] = acc[0][0][0] + acc[NCO - 1][PT - 1][3];
     if (false) {
 #else
     if (last_chunk) {
@@ -467,7 +472,7 @@ __global__ void __launch_bounds__(256, CT_MINWG) k_conv_tile(ConvArgs A, int fli
             for (int r = 0; r < 4; ++r) if (co + r < A.Cout) add[r] += sbp[r];
         }
 #pragma unroll
-        for (int pt = 0; pt < 2; ++pt) {
+        for (int pt = 0; pt < PT; ++pt) {
           if (!((y0 + pty[pt] < g.Ho) && (x0 + ptx[pt] < g.Wo))) continue;
           const size_t m = ((size_t)n * g.Ho + y0 + pty[pt]) * g.Wo + x0 + ptx[pt];
           f32x4 v = acc[c][pt] + add;
@@ -485,14 +490,14 @@ __global__ void __launch_bounds__(256, CT_MINWG) k_conv_tile(ConvArgs A, int fli
       }
     }
     if (!more) break;
-#ifdef CT_SINGLE        // diagnostic: one LDS buffer, the next item is fetched after this one's MFMAs
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    stage_load(ntile, ns, nc * CT_KC);
-    stage_store(cur);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    tile = ntile; cs = ns; cc = nc;
-    continue;
-#endif
+    if (!DB) {             // one LDS buffer: the next item is fetched after this one's MFMAs (other workgroups cover it)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      stage_load(ntile, ns, nc * CT_KC);
+      stage_store(cur);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      tile = ntile; cs = ns; cc = nc;
+      continue;
+    }
     stage_store(nxt);
     // LDS hand-off only: __syncthreads() would also drain vmcnt, i.e. wait for this tile's output stores to land
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -990,15 +995,16 @@ int msgm_conv_forward_fused(const msgm_conv_geom_t* geom, const float* src0, int
   // stride-1 "same" convolution (or its dgrad) on a big enough image: halo-tile kernel
   if (conv_tile_eligible(geom, C0, src1, C1, CoutP)) {
     const bool two_d = geom->Ho > 1;
-    const int TH = two_d ? 8 : 1, TW = two_d ? 16 : 128;
+    const int nco = (CoutP % 64 == 0) ? 4 : 2;
+    // 3-tap / 3x3 kernels: 256-pixel tiles (4 MFMA column tiles per wave, one LDS buffer) when the image has them —
+    // measured +10..27 % in 2-D and +3..8 % in 1-D over the 128-pixel double-buffered form (tools/exp_wide.py);
+    // 1x1 kernels (no tap reuse, HBM-bound) stay on the 128-pixel form, which measured equal or better
+    const bool no_wide = getenv("MSGM_NO_CONV_WIDE") != nullptr;            // diagnostic A/B
+    const bool wide = geom->KW == 3 && !no_wide && (two_d ? (geom->Ho >= 16 && geom->Wo >= 16) : geom->Wo >= 256);
+    const int TH = two_d ? (wide ? 16 : 8) : 1, TW = two_d ? 16 : (wide ? 256 : 128);
     const int tiles_x = (geom->Wo + TW - 1) / TW, tiles_y = (geom->Ho + TH - 1) / TH;
     const int halo = (TH + geom->KH - 1) * (TW + geom->KW - 1);
-#ifdef CT_SINGLE
-    const size_t lds = (size_t)1 * halo * CT_P * sizeof(float);
-#else
-    const size_t lds = (size_t)2 * halo * CT_P * sizeof(float);
-#endif
-    const int nco = (CoutP % 64 == 0) ? 4 : 2;
+    const size_t lds = (size_t)(wide ? 1 : 2) * halo * CT_P * sizeof(float);
     const int n_tiles = tiles_x * tiles_y * geom->N, gy = CoutP / (16 * nco);
     // several consecutive tiles per workgroup (the next tile's halo loads overlap this tile's MFMAs) — but only
     // while >= 8 rounds of resident workgroups (3 per CU) remain: below that the tail of the last round costs more
@@ -1009,15 +1015,17 @@ int msgm_conv_forward_fused(const msgm_conv_geom_t* geom, const float* src0, int
     if (per < 1) per = 1;
     dim3 grid((unsigned)((n_tiles + per - 1) / per), (unsigned)gy);
     const int flip = geom->mode;
-#define CT_LAUNCH(TH_, TW_, NCO_, KS_) \
-  hipLaunchKernelGGL((k_conv_tile<TH_, TW_, NCO_, KS_>), grid, dim3(256), lds, S(stream), A, flip, tiles_x, tiles_y, per, n_tiles)
+#define CT_LAUNCH(TH_, TW_, NCO_, KS_, PT_, DB_) \
+  hipLaunchKernelGGL((k_conv_tile<TH_, TW_, NCO_, KS_, PT_, DB_>), grid, dim3(256), lds, S(stream), A, flip, tiles_x, tiles_y, per, n_tiles)
     const bool k3 = geom->KW == 3;
     if (two_d) {
-      if (nco == 4) { if (k3) CT_LAUNCH(8, 16, 4, 3); else CT_LAUNCH(8, 16, 4, 1); }
-      else { if (k3) CT_LAUNCH(8, 16, 2, 3); else CT_LAUNCH(8, 16, 2, 1); }
+      if (wide) { if (nco == 4) CT_LAUNCH(16, 16, 4, 3, 4, false); else CT_LAUNCH(16, 16, 2, 3, 4, false); }
+      else if (nco == 4) { if (k3) CT_LAUNCH(8, 16, 4, 3, 2, true); else CT_LAUNCH(8, 16, 4, 1, 2, true); }
+      else { if (k3) CT_LAUNCH(8, 16, 2, 3, 2, true); else CT_LAUNCH(8, 16, 2, 1, 2, true); }
     } else {
-      if (nco == 4) { if (k3) CT_LAUNCH(1, 128, 4, 3); else CT_LAUNCH(1, 128, 4, 1); }
-      else { if (k3) CT_LAUNCH(1, 128, 2, 3); else CT_LAUNCH(1, 128, 2, 1); }
+      if (wide) { if (nco == 4) CT_LAUNCH(1, 256, 4, 3, 4, false); else CT_LAUNCH(1, 256, 2, 3, 4, false); }
+      else if (nco == 4) { if (k3) CT_LAUNCH(1, 128, 4, 3, 2, true); else CT_LAUNCH(1, 128, 4, 1, 2, true); }
+      else { if (k3) CT_LAUNCH(1, 128, 2, 3, 2, true); else CT_LAUNCH(1, 128, 2, 1, 2, true); }
     }
 #undef CT_LAUNCH
     return msgm_check_launch();

@@ -35,7 +35,8 @@ def mk(weight, bias, kind, k, stride, pad, srcC, embC=0, ups=False):
 
 @pytest.mark.parametrize("N,Cin,Cout,L,k,s,p", [(3, 32, 32, 100, 3, 1, 1), (2, 1, 32, 64, 3, 1, 1), (2, 64, 128, 37, 3, 1, 1),
                                                  (2, 32, 32, 101, 4, 2, 1), (2, 128, 128, 64, 4, 2, 1), (2, 32, 1, 50, 1, 1, 0),
-                                                 (5, 96, 48, 33, 3, 1, 1), (2, 3, 32, 40, 3, 1, 1)])
+                                                 (5, 96, 48, 33, 3, 1, 1), (2, 3, 32, 40, 3, 1, 1),
+                                                 (2, 32, 32, 300, 3, 1, 1), (3, 64, 64, 513, 3, 1, 1)])   # 256-pixel tiles, ragged
 def test_conv1d_fwd_bwd(N, Cin, Cout, L, k, s, p):
     torch.manual_seed(N * 100 + Cin)
     x = torch.randn(N, Cin, L, requires_grad=True)
@@ -111,7 +112,9 @@ def test_conv1d_concat_and_embedding_channels():
 
 
 @pytest.mark.parametrize("N,Cin,Cout,H,W_,k,s,p", [(2, 3, 32, 16, 16, 3, 1, 1), (2, 32, 32, 16, 12, 3, 2, 1), (1, 96, 64, 8, 8, 3, 1, 1),
-                                                    (2, 64, 128, 8, 8, 1, 1, 0), (2, 192, 64, 4, 4, 3, 1, 1), (1, 32, 3, 10, 10, 3, 1, 1)])
+                                                    (2, 64, 128, 8, 8, 1, 1, 0), (2, 192, 64, 4, 4, 3, 1, 1), (1, 32, 3, 10, 10, 3, 1, 1),
+                                                    (3, 32, 32, 20, 23, 3, 1, 1), (2, 96, 64, 17, 32, 3, 1, 1),   # 16x16 tiles, ragged
+                                                    (2, 64, 32, 28, 28, 3, 1, 1)])
 def test_conv2d_fwd_bwd(N, Cin, Cout, H, W_, k, s, p):
     torch.manual_seed(Cin + H)
     x = torch.randn(N, Cin, H, W_, requires_grad=True)
