@@ -249,11 +249,16 @@ __global__ void __launch_bounds__(256) k_conv_gemm(ConvArgs A) {
 // next item.  <PT=2, DB> is the small-image / 1x1 form; 3-tap kernels on images that have 256-pixel tiles run
 // <PT=4, !DB>: twice the pixels per wave give each weight fragment 4 MFMAs instead of 2 and halve the halo overhead,
 // and the bigger halo is single-buffered so that three workgroups still share a CU (their MFMAs cover the staging).
+// 1x1 kernels stay at ~0.3 of the MFMA peak / 3 TB/s whatever the tiles per workgroup; two attempts at their memory
+// pipeline measured no gain and were removed: two items in flight in registers, and the weight chunk staged through
+// LDS with the activations (so that no vmcnt wait for a weight fragment also waits for the next item's loads) —
+// the second costs the third resident workgroup (55 KB of LDS) and was 5-10 % slower.
 template <int TH, int TW, int NCO, int KS, int PT = 2, bool DB = true>
 #ifndef CT_MINWG
 #define CT_MINWG 1
 #endif
-__global__ void __launch_bounds__(256, CT_MINWG) k_conv_tile(ConvArgs A, int flip, int tiles_x, int tiles_y, int tiles_per_wg, int n_tiles) {
+__global__ void __launch_bounds__(256, CT_MINWG) k_conv_tile(ConvArgs A, int flip, int tiles_x, int tiles_y, int tiles_per_wg, int n_tiles,
+                                                             int n_cob, int n_tgrp) {
   extern __shared__ __attribute__((aligned(16))) float ct_lds[];
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, il = lane & 15, q = lane >> 4;
   const ConvGeom g = A.g;
@@ -261,10 +266,22 @@ __global__ void __launch_bounds__(256, CT_MINWG) k_conv_tile(ConvArgs A, int fli
   constexpr int HH = TH + KH - 1, HW = TW + KW - 1, halo = HH * HW;
   float* cur = ct_lds;
   float* nxt = ct_lds + halo * CT_P;
-  const int co0 = blockIdx.y * (NCO * 16);
+  // XCD-aware 1-D grid: workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2), so the n_cob
+  // output-channel blocks that read the SAME input tiles are given ids 8 apart — same XCD, dispatched back to back —
+  // and the re-reads of the input hit that L2 instead of HBM (matters for the 1x1 convolutions, which are HBM-bound).
+  int cob, tgrp;
+  if (n_cob > 0) {
+    const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+    cob = loc % n_cob; tgrp = (loc / n_cob) * 8 + xcd;
+  } else {                       // diagnostic (MSGM_CONV_NO_XCD): tile-fastest order, channel blocks far apart
+    const int ntp = 8 * ((n_tgrp + 7) / 8);
+    cob = blockIdx.x / ntp; tgrp = blockIdx.x - cob * ntp;
+  }
+  if (tgrp >= n_tgrp) return;
+  const int co0 = cob * (NCO * 16);
   // A workgroup walks over tiles_per_wg consecutive spatial tiles; the pipeline unit is a (tile, channel chunk)
   // item, so the halo of the NEXT tile is in flight during the MFMAs of this one even when Cin fits one chunk.
-  const int t_beg = blockIdx.x * tiles_per_wg, t_end = min(t_beg + tiles_per_wg, n_tiles);
+  const int t_beg = tgrp * tiles_per_wg, t_end = min(t_beg + tiles_per_wg, n_tiles);
   if (t_beg >= t_end) return;
   static_assert(TH * TW == 64 * PT, "tile = 4 waves x PT MFMA column tiles");
   // this lane's PT output pixels inside a tile
@@ -302,7 +319,7 @@ __global__ void __launch_bounds__(256, CT_MINWG) k_conv_tile(ConvArgs A, int fli
     const int hy = hp / HW;
     hyx[k] = (hy << 16) | (hp - hy * HW);
   }
-  auto stage_load = [&](int t, int s, int c0) {
+  auto stage_load = [&](f32x4* dst, int t, int s, int c0) {
     int n, y0, x0;
     tile_origin(t, n, y0, x0);
     const int C = A.C[s];
@@ -340,8 +357,16 @@ __global__ void __launch_bounds__(256, CT_MINWG) k_conv_tile(ConvArgs A, int fli
           }
         }
       }
-      st[k] = v;
+      dst[k] = v;
     }
+  };
+  // item after (t_, s_, c_); returns whether (t_, s_, c_) is the last chunk of its tile
+  auto advance = [&](int t_, int s_, int c_, int& nt, int& ns_, int& nc_) {
+    nt = t_; ns_ = s_; nc_ = c_ + 1;
+    if (nc_ == (s_ ? nch[1] : nch[0])) { ns_ = s_ + 1; nc_ = 0; }   // selects, not a dynamically indexed array (scratch)
+    const bool last = ns_ >= A.nsrc || (ns_ ? nch[1] : nch[0]) == 0;
+    if (last) { nt = t_ + 1; ns_ = 0; nc_ = 0; }
+    return last;
   };
   auto stage_store = [&](float* buf) {
 #pragma unroll
@@ -351,19 +376,35 @@ __global__ void __launch_bounds__(256, CT_MINWG) k_conv_tile(ConvArgs A, int fli
     }
   };
 
+  const size_t a_co_stride = (size_t)16 * A.Ktot;
+  f32x4 an[NCO];                         // the next (tap, group) pair's weight fragments
+  auto fetch_w = [&](const float* wp) {
+#pragma unroll
+    for (int c = 0; c < NCO; ++c) an[c] = *reinterpret_cast<const f32x4*>(wp + c * a_co_stride);
+  };
+  auto wptr = [&](int s_, int c_) { return A.Wp + (size_t)(co0 + il) * A.Ktot + A.koff[s_] + c_ * CT_KC + 4 * q; };
+  auto chunk_mask = [&](int s_, int c_) {
+    unsigned tm = (1u << taps) - 1u;
+    const int chunk_flat = (s_ ? nch[0] : 0) + c_;
+    const unsigned mi = chunk_flat < 16 ? A.tapmask_in[chunk_flat] : 0u, mo = cob < 8 ? A.tapmask_out[cob] : 0u;
+    if (mi) tm &= mi;
+    if (mo) tm &= mo;
+    return tm;
+  };
+  {
+    const unsigned tm0 = chunk_mask(0, 0);
+    if (tm0) fetch_w(wptr(0, 0) + (size_t)(__ffs(tm0) - 1) * A.CoutP * A.Ktot);
+  }
   int tile = t_beg, cs = 0, cc = 0;      // current item: tile, source cs, chunk index cc within it
-  stage_load(tile, 0, 0);
+  stage_load(st, tile, 0, 0);
   stage_store(cur);
   __syncthreads();
-  const size_t a_co_stride = (size_t)16 * A.Ktot;
   for (;;) {
     // next item
-    int ntile = tile, ns = cs, nc = cc + 1;
-    if (nc == nch[cs]) { ns = cs + 1; nc = 0; }
-    const bool last_chunk = ns >= A.nsrc || nch[ns] == 0;
-    if (last_chunk) { ntile = tile + 1; ns = 0; nc = 0; }
+    int ntile, ns, nc;
+    const bool last_chunk = advance(tile, cs, cc, ntile, ns, nc);
     const bool more = ntile < t_end;
-    if (DB && more) stage_load(ntile, ns, nc * CT_KC);
+    if (DB && more) stage_load(st, ntile, ns, nc * CT_KC);
     if (cs == 0 && cc == 0) {
 #pragma unroll
       for (int c = 0; c < NCO; ++c)
@@ -374,51 +415,35 @@ __global__ void __launch_bounds__(256, CT_MINWG) k_conv_tile(ConvArgs A, int fli
     const int C = A.C[cs];
     const int c0 = cc * CT_KC;
     const int ngrp = (C - c0 >= CT_KC) ? 2 : ((C - c0 + 15) >> 4);
-    const float* wbase = A.Wp + (size_t)(co0 + il) * A.Ktot + A.koff[cs] + c0 + 4 * q;
+    const float* wbase = wptr(cs, cc);
     // taps whose weight block is structurally zero for this (input chunk, output block) are skipped (Stride2PairOp)
-    unsigned tmask = (1u << taps) - 1u;
-    {
-      const int chunk_flat = (cs ? nch[0] : 0) + cc;
-      const unsigned mi = chunk_flat < 16 ? A.tapmask_in[chunk_flat] : 0u, mo = blockIdx.y < 8 ? A.tapmask_out[blockIdx.y] : 0u;
-      if (mi) tmask &= mi;
-      if (mo) tmask &= mo;
-    }
+    const unsigned tmask = chunk_mask(cs, cc);
     auto next_tap = [&](int t) { const unsigned rem = tmask & ~((2u << t) - 1u); return rem ? __ffs(rem) - 1 : taps; };
     const int tap0 = tmask ? __ffs(tmask) - 1 : taps;
     const int npairs = __popc(tmask) * ngrp;
-    // weight fragments are fetched WD (tap, group) pairs ahead (one pair = 8*NCO MFMAs = 256*NCO cycles of matrix
-    // pipe).  WD = 2 for the narrow variant measured no gain (3-4 resident waves per SIMD already cover the L2 hit).
-    constexpr int WD = 1;
-    f32x4 an[WD][NCO];
-    int ftap = tap0, fgrp = 0;             // next pair to fetch
-#pragma unroll
-    for (int d = 0; d < WD; ++d) {
-      if (d < npairs) {
-        const float* wp = wbase + (size_t)ftap * A.CoutP * A.Ktot + 16 * fgrp;
-#pragma unroll
-        for (int c = 0; c < NCO; ++c) an[d][c] = *reinterpret_cast<const f32x4*>(wp + c * a_co_stride);
-        if (++fgrp == ngrp) { fgrp = 0; ftap = next_tap(ftap); }
-      }
-    }
+    // Weight fragments are fetched one (tap, group) pair ahead (one pair = 4*PT*NCO MFMAs); `an` already holds this
+    // item's first pair — it was requested during the LAST pair of the previous item, so that no item starts by
+    // waiting for an L2 round trip (for 1x1 kernels an item is only two pairs long).
+    int ftap = tap0, fgrp = 1;             // next pair to fetch
+    if (fgrp == ngrp) { fgrp = 0; ftap = next_tap(tap0); }
+    auto fetch_next_item = [&]() {
+      const unsigned ntm = chunk_mask(ns, nc);
+      if (ntm) fetch_w(wptr(ns, nc) + (size_t)(__ffs(ntm) - 1) * A.CoutP * A.Ktot);
+    };
+    if (npairs == 0 && more) fetch_next_item();
     int tap = tap0, grp = 0;
     for (int pr = 0; pr < npairs; ++pr) {
       f32x4 a[NCO];
 #pragma unroll
-      for (int c = 0; c < NCO; ++c) a[c] = an[0][c];
-#pragma unroll
-      for (int d = 0; d + 1 < WD; ++d)
-#pragma unroll
-        for (int c = 0; c < NCO; ++c) an[d][c] = an[d + 1][c];
+      for (int c = 0; c < NCO; ++c) a[c] = an[c];
       int ntap = tap, ngr = grp + 1;
       if (ngr == ngrp) { ngr = 0; ntap = next_tap(tap); }
-#ifndef CT_EXP_NOW      // diagnostic: -DCT_EXP_NOW keeps the first weight fragment (no further weight loads)
-      if (pr + WD < npairs) {
-        const float* wp = wbase + (size_t)ftap * A.CoutP * A.Ktot + 16 * fgrp;
-#pragma unroll
-        for (int c = 0; c < NCO; ++c) an[WD - 1][c] = *reinterpret_cast<const f32x4*>(wp + c * a_co_stride);
+      if (pr + 1 < npairs) {
+        fetch_w(wbase + (size_t)ftap * A.CoutP * A.Ktot + 16 * fgrp);
         if (++fgrp == ngrp) { fgrp = 0; ftap = next_tap(ftap); }
+      } else if (more) {
+        fetch_next_item();
       }
-#endif
       const int kh = tap / KW, kw = tap - kh * KW;
       const int oy = flip ? (KH - 1 - kh) : kh, ox = flip ? (KW - 1 - kw) : kw;
       f32x4 b[PT];
@@ -492,7 +517,7 @@ __global__ void __launch_bounds__(256, CT_MINWG) k_conv_tile(ConvArgs A, int fli
     if (!more) break;
     if (!DB) {             // one LDS buffer: the next item is fetched after this one's MFMAs (other workgroups cover it)
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      stage_load(ntile, ns, nc * CT_KC);
+      stage_load(st, ntile, ns, nc * CT_KC);
       stage_store(cur);
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       tile = ntile; cs = ns; cc = nc;
@@ -1009,14 +1034,16 @@ int msgm_conv_forward_fused(const msgm_conv_geom_t* geom, const float* src0, int
     // several consecutive tiles per workgroup (the next tile's halo loads overlap this tile's MFMAs) — but only
     // while >= 8 rounds of resident workgroups (3 per CU) remain: below that the tail of the last round costs more
     // than the hidden prologues gain (measured, tools/bench_conv.py)
-    static const int max_per = getenv("MSGM_CONV_TILES") ? atoi(getenv("MSGM_CONV_TILES")) : 4;
-    int per = (int)(((int64_t)n_tiles * gy) / 6144);
+    const int max_per = getenv("MSGM_CONV_TILES") ? atoi(getenv("MSGM_CONV_TILES")) : 4;
+    const int rounds = getenv("MSGM_CONV_ROUNDS") ? atoi(getenv("MSGM_CONV_ROUNDS")) : 8;
+    int per = (int)(((int64_t)n_tiles * gy) / (768 * rounds));
     if (per > max_per) per = max_per;
     if (per < 1) per = 1;
-    dim3 grid((unsigned)((n_tiles + per - 1) / per), (unsigned)gy);
+    const int n_tgrp = (n_tiles + per - 1) / per;
+    dim3 grid((unsigned)(8 * gy * ((n_tgrp + 7) / 8)));
     const int flip = geom->mode;
 #define CT_LAUNCH(TH_, TW_, NCO_, KS_, PT_, DB_) \
-  hipLaunchKernelGGL((k_conv_tile<TH_, TW_, NCO_, KS_, PT_, DB_>), grid, dim3(256), lds, S(stream), A, flip, tiles_x, tiles_y, per, n_tiles)
+  hipLaunchKernelGGL((k_conv_tile<TH_, TW_, NCO_, KS_, PT_, DB_>), grid, dim3(256), lds, S(stream), A, flip, tiles_x, tiles_y, per, n_tiles, getenv("MSGM_CONV_NO_XCD") ? -gy : gy, n_tgrp)
     const bool k3 = geom->KW == 3;
     if (two_d) {
       if (wide) { if (nco == 4) CT_LAUNCH(16, 16, 4, 3, 4, false); else CT_LAUNCH(16, 16, 2, 3, 4, false); }

@@ -50,3 +50,23 @@ for (L, Ci, Co) in ((1024, 32, 32), (1024, 64, 32), (512, 64, 64), (512, 128, 64
     out = torch.empty(N * L * Co, device=dev)
     geom = ops.conv_geom(N, 1, L, 1, L, 1, 3, 1, 1)
     ab(f"L={L} {Ci:3d}->{Co}", geom, x, Ci, Wp, Co, out, N, 2 * 3 * Ci * Co * N * L)
+
+print("XCD-aware grid (MSGM_CONV_NO_XCD = old order), N=512:")
+for (H, Ci, Co, K) in ((32, 64, 192, 1), (32, 64, 64, 1), (16, 128, 384, 1), (16, 256, 128, 1), (16, 256, 128, 3), (32, 192, 64, 3), (16, 128, 128, 3)):
+    N = 512
+    x = torch.randn(N * H * H * Ci, device=dev)
+    Wp = torch.randn(K * K * ops.pad16(Co) * ops.pad16(Ci), device=dev) * 0.05
+    out = torch.empty(N * H * H * Co, device=dev)
+    geom = ops.conv_geom(N, H, H, H, H, K, K, 1, (K - 1) // 2)
+    fl = 2 * K * K * Ci * Co * N * H * H
+    r = []
+    for off in (True, False):
+        if off:
+            os.environ["MSGM_CONV_NO_XCD"] = "1"
+        else:
+            os.environ.pop("MSGM_CONV_NO_XCD", None)
+        t = timeit(lambda: ops.conv_forward(geom, x, Ci, Wp, Co, out, n_bias=N // 2))
+        r.append((t, out.clone()))
+    gb = (x.numel() + out.numel()) * 4 / 1e9
+    print(f"  {H}x{H} k{K} {Ci:3d}->{Co:3d}: old {fl / r[0][0] / 1e12:5.1f} TF/s {gb / r[0][0]:6.0f} GB/s | xcd {fl / r[1][0] / 1e12:5.1f} TF/s {gb / r[1][0]:6.0f} GB/s"
+          f" | identical {torch.equal(r[0][1], r[1][1])}", flush=True)
