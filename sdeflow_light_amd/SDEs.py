@@ -494,7 +494,14 @@ class PluginReverseSDE(nn.Module):
             ops.mlp_ssm_grad(net.kernel_params(), y, t.reshape(-1), v, st, 1.0 / B, gtmp, self._ws, loss_per=per, u=uu, cst=cst)
         else:
             # U-Nets: dual-number forward + hand-written backward; the net writes its flat .grad bucket
+            # (what was accumulated so far is put back afterwards; a parameter whose .grad is None — zero_grad() —
+            # has accumulated nothing, whatever its slice of the bucket still holds)
             keep = gflat.clone()
+            off = 0
+            for p_ in net.parameters():
+                if p_.grad is None:
+                    keep[off:off + p_.numel()].zero_()
+                off += p_.numel()
             per = net.ssm_grad(y, t.reshape(-1), v, uu, cst, 1.0 / B)
             flat, gflat = net.flat_parameters()
             gtmp = gflat.clone()

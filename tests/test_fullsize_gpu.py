@@ -1,0 +1,73 @@
+"""BASELINE full sizes of the U-Net configurations (C3, C4 shard, C5 chunk) on the GPU.  The CPU oracle needs minutes
+per sample at these sizes, so the checks are the size-independent properties the path has:
+rows never interact (GroupNorm is per sample, attention is per sample), so
+  (i)  the per-sample losses of a batch are those of its two halves, and the mean gradient of the batch is the average
+       of the two half-batch gradients — exactly the data-parallel equivalence the multi-GPU path relies on;
+  (ii) the score of a row does not depend on which other rows share the launch.
+Per-row values are compared BIT FOR BIT: no kernel on the path lets the batch size choose the order of a row's
+arithmetic (the GroupNorm statistics are reduced over per-sample chunks of a fixed size and combined in double).
+Gradients: 1e-4 rel-L2 (weight gradients are float atomics over the batch).
+Small-size parity against the oracle and the golden vectors of the same code paths: test_host_gpu.py (1-D),
+test_unet2d_gpu.py (2-D)."""
+import pytest
+import torch
+
+from conftest import rel_l2
+from test_host_gpu import make_gen, _unet1d
+from test_unet2d_gpu import _vunet
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _ssm(gen, x, u, eps, uv, sl):
+    gen.zero_grad()
+    per = gen.ssm(x[sl].contiguous().to(DEV), u=u[sl].contiguous().to(DEV), eps=eps[sl].contiguous().to(DEV),
+                  u_v=uv[sl].contiguous().to(DEV))
+    per.mean().backward()
+    g = torch.cat([p.grad.reshape(-1) for _, p in gen.a.named_parameters()]).cpu()
+    return per.detach().cpu(), g
+
+
+def _shard_equivalence(gen, B, d, scale):
+    torch.manual_seed(11)
+    x, u, eps, uv = torch.randn(B, d) * scale, torch.rand(B), torch.randn(B, d), torch.rand(B, d)
+    pf, gf = _ssm(gen, x, u, eps, uv, slice(0, B))
+    p0, g0 = _ssm(gen, x, u, eps, uv, slice(0, B // 2))
+    p1, g1 = _ssm(gen, x, u, eps, uv, slice(B // 2, B))
+    assert torch.isfinite(pf).all() and torch.isfinite(gf).all() and float(gf.abs().max()) > 0
+    assert torch.equal(torch.cat([p0, p1]), pf), rel_l2(torch.cat([p0, p1]), pf)
+    assert rel_l2(0.5 * (g0 + g1), gf) <= 1e-4, rel_l2(0.5 * (g0 + g1), gf)
+    # and the halves really are different problems
+    assert rel_l2(g0, g1) > 1e-3
+
+
+def test_c3_full_size_shard_equivalence():
+    """C3: UNet1D L = 1024, B = 4096 (the per-GPU batch of BASELINE configs[2])."""
+    gen = make_gen("sgm", _unet1d(1024))
+    _shard_equivalence(gen, 4096, 1024, 1.0)
+
+
+def test_c4_shard_size_equivalence():
+    """C4: VorticityUNet 64x64x3 (d = 12 288) at the per-GPU shard of the global batch 256 over 8 GPUs (B = 32)."""
+    gen = make_gen("sgm", _vunet(64, "F", channels=3))
+    _shard_equivalence(gen, 32, 3 * 64 * 64, 1.0)
+
+
+def test_c5_chunk_rows_are_independent():
+    """C5: one score evaluation of the sampler at its per-GPU set (1024 rows of d = 12 288): a row's score is the same
+    in the full launch, in a half-size launch, and when every other row of the launch is replaced."""
+    net = _vunet(64, "F", channels=3)
+    torch.manual_seed(5)
+    B, d = 1024, 3 * 64 * 64
+    x = torch.randn(B, d, device=DEV)
+    s = torch.rand(B, device=DEV) * 0.9 + 0.05
+    full = net(x, s)
+    assert full.shape == (B, d) and torch.isfinite(full).all()
+    h0, h1 = net(x[: B // 2].contiguous(), s[: B // 2].contiguous()), net(x[B // 2:].contiguous(), s[B // 2:].contiguous())
+    assert torch.equal(torch.cat([h0, h1]), full)
+    x2 = x.clone()
+    x2[1:] = torch.randn(B - 1, d, device=DEV) * 2.0
+    other = net(x2, s)
+    assert torch.equal(other[:1], full[:1])
+    assert rel_l2(other[1:].cpu(), full[1:].cpu()) > 1e-2

@@ -322,6 +322,29 @@ def test_unet1d_ssm_golden():
     _check_digest(g, "u1d", grads, "a.", 5e-4)
 
 
+def test_unet_ssm_backward_respects_zero_grad_and_accumulation():
+    """The reference loop is zero_grad(); ssm(x).mean().backward(); step() (MSGM_higherDim.py:803-809): a second
+    iteration must start from zero after zero_grad() (set_to_none), and accumulate when zero_grad() is not called."""
+    torch.manual_seed(3)
+    net = _unet1d(64)
+    gen = make_gen("sgm", net)
+    B, d = 3, 64
+    x, u, eps, uv = torch.randn(B, d).to(DEV), torch.rand(B).to(DEV), torch.randn(B, d).to(DEV), torch.rand(B, d).to(DEV)
+
+    def grads():
+        return torch.cat([p.grad.reshape(-1) for p in gen.a.parameters()]).cpu().clone()
+
+    gen.zero_grad()
+    gen.ssm(x, u=u, eps=eps, u_v=uv).mean().backward()
+    g1 = grads()
+    gen.zero_grad()
+    gen.ssm(x, u=u, eps=eps, u_v=uv).mean().backward()
+    g2 = grads()
+    assert float(g1.abs().max()) > 0 and rel_l2(g2, g1) <= 1e-5, rel_l2(g2, g1)
+    gen.ssm(x, u=u, eps=eps, u_v=uv).mean().backward()          # no zero_grad: accumulates
+    assert rel_l2(grads(), 2.0 * g1) <= 1e-5
+
+
 def test_unet1d_sampler_runs_and_matches_oracle():
     from sdeflow_light_amd import sde_scheme as SS
     from oracle import sde_ref as S, nets_ref as N
