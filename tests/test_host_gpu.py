@@ -345,6 +345,43 @@ def test_unet_ssm_backward_respects_zero_grad_and_accumulation():
     assert rel_l2(grads(), 2.0 * g1) <= 1e-5
 
 
+def test_unet1d_reference_loop_adam_steps_vs_oracle():
+    """The reference's loop body (MSGM_higherDim.py:803-809) through the mirror API with torch.optim.Adam, three
+    iterations on a 1-D U-Net, against the oracle doing the same on the CPU: the loss of iteration k+1 only matches if
+    the kernels see the parameters the optimizer just wrote (weight images are re-packed per forward)."""
+    from oracle import sde_ref as S, nets_ref as N, ssm_ref as LR
+    torch.manual_seed(21)
+    L_, B = 64, 4
+    net = _unet1d(L_)
+    gen = make_gen("sgm", net)
+    opt = torch.optim.Adam(gen.a.parameters(), lr=1e-3)
+    ref = {k: v.detach().cpu().clone() for k, v in net.named_parameters()}
+    m = {k: torch.zeros_like(v) for k, v in ref.items()}
+    vv = {k: torch.zeros_like(v) for k, v in ref.items()}
+    sp = S.SdeSpec()
+    score = lambda prm, yy, tt: N.unet1d_forward(prm, yy, tt)
+    losses, losses_ref = [], []
+    for it in range(3):
+        x, u, eps, uv = torch.randn(B, L_), torch.rand(B), torch.randn(B, L_), torch.rand(B, L_)
+        gen.zero_grad()
+        loss = gen.ssm(x.to(DEV), u=u.to(DEV), eps=eps.to(DEV), u_v=uv.to(DEV)).mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+        t = S.clamp_time(sp, u.reshape(B, 1)); y = S.vp_perturb(sp, t, x, eps); v = S.rademacher_from_uniform(uv)
+        lref, _, gref = LR.ssm_mean_and_grads(sp, score, ref, t, y, v)
+        losses_ref.append(float(lref))
+        for k in ref:
+            ref[k], m[k], vv[k] = LR.adam_step(ref[k], gref[k], m[k], vv[k], it + 1)
+    for a_, b_ in zip(losses, losses_ref):
+        assert a_ == pytest.approx(b_, rel=2e-3), (losses, losses_ref)
+    # the iterations are different problems, so matching losses 2 and 3 needs the updated parameters
+    assert abs(losses_ref[1] - losses_ref[0]) > 1e-2 * abs(losses_ref[0])
+    flat = torch.cat([p_.detach().reshape(-1).cpu() for _, p_ in net.named_parameters()])
+    flat_ref = torch.cat([ref[k].reshape(-1) for k, _ in net.named_parameters()])
+    assert rel_l2(flat, flat_ref) <= 2e-3, rel_l2(flat, flat_ref)
+
+
 def test_unet1d_sampler_runs_and_matches_oracle():
     from sdeflow_light_amd import sde_scheme as SS
     from oracle import sde_ref as S, nets_ref as N
