@@ -34,12 +34,13 @@ __device__ __forceinline__ void silu012u(float z, float& s0, float& s1, float& s
 struct GnArgs {
   const float* x; const float* gamma; const float* beta;
   float* out; double* acc; float* stats;
-  int P, C, G, Bp, dual, silu, chunk;
+  int P, C, G, Bp, dual, silu, chunk;   // chunk: pixels per workgroup (a multiple of sub in the reduce kernels)
   float eps;
   // backward
   const float* gout; float* gx; float* dgamma; float* dbeta;
   // forward statistics over the channel concatenation of two tensors (x: C0 channels, x1: C - C0), no tangent
   const float* x1; int C0;
+  int sub;      // reduce kernels: pixels per fp32 partial sum — fixed per sample, whatever the batch size
 };
 
 // V values per thread (channels V*cv .. V*cv+V-1 of pixel lane pl): LDS image [pl][C], then one thread per group sums
@@ -62,10 +63,31 @@ __device__ __forceinline__ void gn_group_atomic_v(float* red, const float (&v)[V
   __syncthreads();
 }
 
+// the same with double partials (the reduce kernels): per-thread fp32 sums over one sub-chunk are widened and from
+// there on everything is added in double — exact for sums of a few thousand floats of comparable size, so the result
+// does not depend on how the sub-chunks are dealt to workgroups.
+template <int V>
+__device__ __forceinline__ void gn_group_atomic_d(double* red, const double (&v)[V], bool live, int cv, int pl, int C, int PL,
+                                                  int G, int cpg, double* dst, int stride) {
+  if (live) {
+#pragma unroll
+    for (int k = 0; k < V; ++k) red[pl * C + V * cv + k] = v[k];
+  }
+  __syncthreads();
+  const int tid = threadIdx.x;
+  if (tid < G) {
+    double s = 0.0;
+    for (int p = 0; p < PL; ++p)
+      for (int cc = 0; cc < cpg; ++cc) s += red[p * C + tid * cpg + cc];
+    atomicAdd(dst + (size_t)tid * stride, s);
+  }
+  __syncthreads();
+}
+
 template <bool VEC>
 __global__ void __launch_bounds__(256) k_gn_fwd_reduce(GnArgs A) {
   constexpr int V = VEC ? 4 : 1;
-  __shared__ float red[1024];
+  __shared__ double red[1024];
   const int tid = threadIdx.x, b = blockIdx.x;
   const int C = A.C, P = A.P, G = A.G, cpg = C / G;
   const int CV = C / V, PL = 256 / CV;
@@ -78,11 +100,16 @@ __global__ void __launch_bounds__(256) k_gn_fwd_reduce(GnArgs A) {
   const float* xp = (second ? A.x1 : A.x) + (size_t)b * P * pitch + coff;
   const float* xt = (second ? A.x1 : A.x) + (size_t)(b + A.Bp) * P * pitch + coff;
   const int p0 = blockIdx.y * A.chunk, p1 = min(p0 + A.chunk, P);
-  float s0[V], s1[V], s2[V], s3[V];
+  double d0[V], d1[V], d2[V], d3[V];
 #pragma unroll
-  for (int k = 0; k < V; ++k) { s0[k] = 0.f; s1[k] = 0.f; s2[k] = 0.f; s3[k] = 0.f; }
+  for (int k = 0; k < V; ++k) { d0[k] = 0.0; d1[k] = 0.0; d2[k] = 0.0; d3[k] = 0.0; }
   if (live)
-    for (int p = p0 + pl; p < p1; p += PL) {
+   for (int ps = p0; ps < p1; ps += max(A.sub, 1)) {
+    const int pe = min(ps + max(A.sub, 1), p1);
+    float s0[V], s1[V], s2[V], s3[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) { s0[k] = 0.f; s1[k] = 0.f; s2[k] = 0.f; s3[k] = 0.f; }
+    for (int p = ps + pl; p < pe; p += PL) {
       float xv[V], dv[V];
       if (VEC) {
         const f32x4 t = *reinterpret_cast<const f32x4*>(xp + (size_t)p * pitch);
@@ -103,12 +130,15 @@ __global__ void __launch_bounds__(256) k_gn_fwd_reduce(GnArgs A) {
         if (A.dual) { s2[k] += dv[k]; s3[k] += xv[k] * dv[k]; }
       }
     }
+#pragma unroll
+    for (int k = 0; k < V; ++k) { d0[k] += (double)s0[k]; d1[k] += (double)s1[k]; d2[k] += (double)s2[k]; d3[k] += (double)s3[k]; }
+   }
   double* dst = A.acc + (size_t)b * G * 8;
-  gn_group_atomic_v<V>(red, s0, live, cv, pl, C, PL, G, cpg, dst + 0, 8);
-  gn_group_atomic_v<V>(red, s1, live, cv, pl, C, PL, G, cpg, dst + 1, 8);
+  gn_group_atomic_d<V>(red, d0, live, cv, pl, C, PL, G, cpg, dst + 0, 8);
+  gn_group_atomic_d<V>(red, d1, live, cv, pl, C, PL, G, cpg, dst + 1, 8);
   if (A.dual) {
-    gn_group_atomic_v<V>(red, s2, live, cv, pl, C, PL, G, cpg, dst + 2, 8);
-    gn_group_atomic_v<V>(red, s3, live, cv, pl, C, PL, G, cpg, dst + 3, 8);
+    gn_group_atomic_d<V>(red, d2, live, cv, pl, C, PL, G, cpg, dst + 2, 8);
+    gn_group_atomic_d<V>(red, d3, live, cv, pl, C, PL, G, cpg, dst + 3, 8);
   }
 }
 
@@ -221,7 +251,8 @@ __global__ void __launch_bounds__(256) k_gn_fwd_apply(GnArgs A, const float* __r
 template <bool VEC>
 __global__ void __launch_bounds__(256) k_gn_bwd_reduce(GnArgs A) {
   constexpr int V = VEC ? 4 : 1;
-  __shared__ float red[1024];
+  __shared__ double redd[1024];
+  float* red = reinterpret_cast<float*>(redd);
   const int tid = threadIdx.x, b = blockIdx.x;
   const int C = A.C, P = A.P, G = A.G, cpg = C / G;
   const int CV = C / V, PL = 256 / CV;
@@ -237,11 +268,17 @@ __global__ void __launch_bounds__(256) k_gn_bwd_reduce(GnArgs A) {
     ga[k] = A.gamma[c]; be[k] = A.beta[c];
   }
   const int p0 = blockIdx.y * A.chunk, p1 = min(p0 + A.chunk, P);
-  float sX[V], sXx[V], sW[V], sWx[V], sWw[V], dga[V], dbe[V];
+  double dX[V], dXx[V], dW[V], dWx[V], dWw[V];
+  float dga[V], dbe[V];
 #pragma unroll
-  for (int k = 0; k < V; ++k) { sX[k] = sXx[k] = sW[k] = sWx[k] = sWw[k] = dga[k] = dbe[k] = 0.f; }
+  for (int k = 0; k < V; ++k) { dX[k] = dXx[k] = dW[k] = dWx[k] = dWw[k] = 0.0; dga[k] = dbe[k] = 0.f; }
   if (live)
-    for (int p = p0 + pl; p < p1; p += PL) {
+   for (int ps = p0; ps < p1; ps += max(A.sub, 1)) {
+    const int pe = min(ps + max(A.sub, 1), p1);
+    float sX[V], sXx[V], sW[V], sWx[V], sWw[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) { sX[k] = sXx[k] = sW[k] = sWx[k] = sWw[k] = 0.f; }
+    for (int p = ps + pl; p < pe; p += PL) {
       const long e = ((long)b * P + p) * C + V * cv;
       float x[V], xd[V], zb[V], zdb[V];
       if (VEC) {
@@ -270,12 +307,17 @@ __global__ void __launch_bounds__(256) k_gn_bwd_reduce(GnArgs A) {
         dga[k] += zbk * xh + zdbk * wh; dbe[k] += zbk;
       }
     }
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      dX[k] += (double)sX[k]; dXx[k] += (double)sXx[k]; dW[k] += (double)sW[k]; dWx[k] += (double)sWx[k]; dWw[k] += (double)sWw[k];
+    }
+   }
   double* dst = A.acc + (size_t)b * G * 8;
-  gn_group_atomic_v<V>(red, sX, live, cv, pl, C, PL, G, cpg, dst + 0, 8);
-  gn_group_atomic_v<V>(red, sXx, live, cv, pl, C, PL, G, cpg, dst + 1, 8);
-  gn_group_atomic_v<V>(red, sW, live, cv, pl, C, PL, G, cpg, dst + 2, 8);
-  gn_group_atomic_v<V>(red, sWx, live, cv, pl, C, PL, G, cpg, dst + 3, 8);
-  gn_group_atomic_v<V>(red, sWw, live, cv, pl, C, PL, G, cpg, dst + 4, 8);
+  gn_group_atomic_d<V>(redd, dX, live, cv, pl, C, PL, G, cpg, dst + 0, 8);
+  gn_group_atomic_d<V>(redd, dXx, live, cv, pl, C, PL, G, cpg, dst + 1, 8);
+  gn_group_atomic_d<V>(redd, dW, live, cv, pl, C, PL, G, cpg, dst + 2, 8);
+  gn_group_atomic_d<V>(redd, dWx, live, cv, pl, C, PL, G, cpg, dst + 3, 8);
+  gn_group_atomic_d<V>(redd, dWw, live, cv, pl, C, PL, G, cpg, dst + 4, 8);
   // per-channel parameter gradients: sum the pixel lanes, one atomic per channel per block
   if (live) {
 #pragma unroll
@@ -672,12 +714,30 @@ static inline hipStream_t S(msgm_stream_t s) { return reinterpret_cast<hipStream
 
 extern "C" {
 
-static int gn_chunks(int Bp, int P, int* chunk) {
-  // A sample's pixels are split into the SAME chunks whatever the batch size (32 per sample, >= 64 pixels each): the
-  // partial sums of a row — hence its statistics, bit for bit — do not depend on how many other rows share the
-  // launch, so a row's result is the same in a 32-row shard and in the 256-row batch (tests/test_fullsize_gpu.py).
-  (void)Bp;
+static int gn_chunks(int Bp, int P, int* chunk, int* sub) {
+  // fp32 partial sums run over the SAME sub-chunks of a sample whatever the batch size (32 per sample, >= 64 pixels
+  // each) and are combined in double: a row's statistics — bit for bit — do not depend on how many other rows share
+  // the launch, so a row's result is the same in a 32-row shard and in the 256-row batch (tests/test_fullsize_gpu.py).
+  // How many consecutive sub-chunks one workgroup takes is free: enough workgroups to fill 256 CUs a few times over.
   int c = (P + 31) / 32;
+  if (c < 64) c = 64;
+  if (c > P) c = P;
+  *sub = c;
+  const int nsub = (P + c - 1) / c;
+  int want = (1024 + Bp - 1) / Bp;            // workgroups per sample
+  if (want < 1) want = 1;
+  int m = nsub / want;
+  if (m < 1) m = 1;
+  *chunk = m * c;
+  return (P + m * c - 1) / (m * c);
+}
+
+// the elementwise passes have no summation order to protect: enough (sample, chunk) workgroups to fill 256 CUs a few
+// times over, >= 64 pixels per chunk
+static int gn_chunks_apply(int Bp, int P, int* chunk) {
+  int n = (1024 + Bp - 1) / Bp;
+  if (n < 1) n = 1;
+  int c = (P + n - 1) / n;
   if (c < 64) c = 64;
   if (c > P) c = P;
   *chunk = c;
@@ -697,12 +757,13 @@ int msgm_groupnorm_dual_forward(const float* x, const float* gamma, const float*
   GnArgs A{x, gamma, beta, out, reinterpret_cast<double*>(workspace), stats, P, C, G, Bp, dual, silu, 0, eps,
            nullptr, nullptr, nullptr, nullptr};
   float* wstats = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + gn_acc_bytes(Bp, G));
-  const int nch = gn_chunks(Bp, P, &A.chunk);
+  const int nch = gn_chunks(Bp, P, &A.chunk, &A.sub);
   if (C % 4 == 0) hipLaunchKernelGGL(k_gn_fwd_reduce<true>, dim3(Bp, nch), dim3(256), 0, S(stream), A);
   else hipLaunchKernelGGL(k_gn_fwd_reduce<false>, dim3(Bp, nch), dim3(256), 0, S(stream), A);
   hipLaunchKernelGGL(k_gn_finalize, dim3((Bp * G + 255) / 256), dim3(256), 0, S(stream), A, wstats);
-  if (C % 4 == 0) hipLaunchKernelGGL(k_gn_fwd_apply<true>, dim3(nch, Bp), dim3(256), 0, S(stream), A, (const float*)wstats);
-  else hipLaunchKernelGGL(k_gn_fwd_apply<false>, dim3(nch, Bp), dim3(256), 0, S(stream), A, (const float*)wstats);
+  const int nap = gn_chunks_apply(Bp, P, &A.chunk);
+  if (C % 4 == 0) hipLaunchKernelGGL(k_gn_fwd_apply<true>, dim3(nap, Bp), dim3(256), 0, S(stream), A, (const float*)wstats);
+  else hipLaunchKernelGGL(k_gn_fwd_apply<false>, dim3(nap, Bp), dim3(256), 0, S(stream), A, (const float*)wstats);
   return msgm_check_launch();
 }
 
@@ -716,7 +777,7 @@ int msgm_groupnorm_affine(const float* x0, int32_t C0, const float* x1, int32_t 
   if (workspace_bytes < msgm_groupnorm_workspace(Bp, G)) return MSGM_E_WORKSPACE;
   GnArgs A{x0, gamma, beta, nullptr, reinterpret_cast<double*>(workspace), nullptr, P, C, G, Bp, 0, 0, 0, eps,
            nullptr, nullptr, nullptr, nullptr, x1, C0};
-  const int nch = gn_chunks(Bp, P, &A.chunk);
+  const int nch = gn_chunks(Bp, P, &A.chunk, &A.sub);
   if (C % 4 == 0 && C0 % 4 == 0) hipLaunchKernelGGL(k_gn_fwd_reduce<true>, dim3(Bp, nch), dim3(256), 0, S(stream), A);
   else hipLaunchKernelGGL(k_gn_fwd_reduce<false>, dim3(Bp, nch), dim3(256), 0, S(stream), A);
   hipLaunchKernelGGL(k_gn_affine, dim3(Bp), dim3(256), 0, S(stream), A, scale, shift);
@@ -732,11 +793,12 @@ int msgm_groupnorm_dual_backward(const float* x, const float* gamma, const float
   if (workspace_bytes < msgm_groupnorm_workspace(Bp, G)) return MSGM_E_WORKSPACE;
   GnArgs A{x, gamma, beta, nullptr, reinterpret_cast<double*>(workspace), const_cast<float*>(stats), P, C, G, Bp, 1, silu, 0,
            eps, gout, gx, dgamma, dbeta};
-  const int nch = gn_chunks(Bp, P, &A.chunk);
+  const int nch = gn_chunks(Bp, P, &A.chunk, &A.sub);
   if (C % 4 == 0) hipLaunchKernelGGL(k_gn_bwd_reduce<true>, dim3(Bp, nch), dim3(256), 0, S(stream), A);
   else hipLaunchKernelGGL(k_gn_bwd_reduce<false>, dim3(Bp, nch), dim3(256), 0, S(stream), A);
-  if (C % 4 == 0) hipLaunchKernelGGL(k_gn_bwd_apply<true>, dim3(nch, Bp), dim3(256), 0, S(stream), A);
-  else hipLaunchKernelGGL(k_gn_bwd_apply<false>, dim3(nch, Bp), dim3(256), 0, S(stream), A);
+  const int nap = gn_chunks_apply(Bp, P, &A.chunk);
+  if (C % 4 == 0) hipLaunchKernelGGL(k_gn_bwd_apply<true>, dim3(nap, Bp), dim3(256), 0, S(stream), A);
+  else hipLaunchKernelGGL(k_gn_bwd_apply<false>, dim3(nap, Bp), dim3(256), 0, S(stream), A);
   if (hipMemsetAsync(workspace, 0, gn_acc_bytes(Bp, G), S(stream)) != hipSuccess) return MSGM_E_LAUNCH;   // zero on exit
   return msgm_check_launch();
 }
