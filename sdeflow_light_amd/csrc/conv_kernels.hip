@@ -253,6 +253,8 @@ __global__ void __launch_bounds__(256) k_conv_gemm(ConvArgs A) {
 // pipeline measured no gain and were removed: two items in flight in registers, and the weight chunk staged through
 // LDS with the activations (so that no vmcnt wait for a weight fragment also waits for the next item's loads) —
 // the second costs the third resident workgroup (55 KB of LDS) and was 5-10 % slower.
+// Also measured and removed: requesting the next item's halo two pairs before the end of the single-buffered 1-D
+// NCO = 4 form (36 more registers, still two waves per SIMD) — 4-8 % slower (C3 106.6 -> 109 ms).
 template <int TH, int TW, int NCO, int KS, int PT = 2, bool DB = true>
 #ifndef CT_MINWG
 #define CT_MINWG 1
