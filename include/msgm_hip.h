@@ -18,9 +18,13 @@
  *
  * Randomness: kernels that draw noise take either an explicit noise buffer
  * (parity mode: the oracle is fed the same numbers) or, when that pointer is
- * NULL, a device-resident Philox state `rng` = {seed, offset} (uint64[2]).
- * Draws are counter-based: value = philox(seed, offset + stream_id, element),
- * so they do not depend on the launch geometry.  msgm_rng_advance bumps
+ * NULL, a device-resident Philox state `rng` = {seed, offset, row_base,
+ * elem_base} (uint64[4]).  Draws are counter-based: value = philox(seed,
+ * offset + stream_id, GLOBAL element), so they do not depend on the launch
+ * geometry; row_base / elem_base (= row_base * n, a multiple of 4) are the
+ * first global row / element of this rank's shard in a data-parallel run, so a
+ * sharded run draws what the single-GPU run draws for the same rows (streams
+ * 0 and 4 are indexed by row, all others by element).  msgm_rng_advance bumps
  * `offset` on the stream (graph-safe).
  */
 #ifndef MSGM_HIP_H

@@ -49,7 +49,10 @@ class FlatParamMixin:
         n = sum(p.numel() for p in params)
         dev = params[0].device
         flat = torch.empty(n, dtype=torch.float32, device=dev)
-        gflat = torch.zeros(n, dtype=torch.float32, device=dev)
+        # the gradient bucket carries ONE spare slot (the mean loss): [grads | loss] is then the buffer the RCCL
+        # all-reduce works on in place — no staging copy of the 16 MB bucket per step
+        self._gbucket = torch.zeros(n + 1, dtype=torch.float32, device=dev)
+        gflat = self._gbucket[:n]
         off = 0
         with torch.no_grad():
             for p in params:
@@ -68,6 +71,11 @@ class FlatParamMixin:
                 first.data_ptr() != self._flat.data_ptr():
             self._flatten_parameters()
         return self._flat, self._gflat
+
+    def grad_bucket(self):
+        """[flat gradients | one spare slot] — the collective buffer of the data-parallel trainers."""
+        self.flat_parameters()
+        return self._gbucket
 
 
 class MLP(nn.Module, FlatParamMixin):
@@ -117,16 +125,35 @@ class MLP(nn.Module, FlatParamMixin):
         return ops.mlp_forward(self.kernel_params(), x, t).view(*sz)
 
 
+def _philox_owners(gen_sde, optim):
+    """Every object on the training path that owns a device Philox stream: the base SDE (perturbation / probe / sampler
+    draws of ``ssm`` and the integrators) and, for the graph-replayed trainers, the trainer itself."""
+    owners = {}
+    base = getattr(gen_sde, "base_sde", None)
+    if base is not None and getattr(base, "rng", None) is not None:
+        owners["base_sde"] = base.rng
+    if getattr(optim, "rng", None) is not None:
+        owners["trainer"] = optim.rng
+    return owners
+
+
 def save_checkpoint(path, gen_sde, optim, iteration):
-    """Same dictionary layout as the reference (NN.py:13-22)."""
+    """Same dictionary layout as the reference (NN.py:13-22) plus ONE extra key the reference's loader ignores:
+    ``msgm_hip`` = the device Philox state {seed, offset, row_base, elem_base} of every stream owner.  All training
+    noise of this build comes from those streams (the torch / numpy / python generator states upstream saves are kept
+    for wire compatibility), so a resumed run continues the same noise sequence instead of replaying iteration 0.
+    ``optim`` is a ``torch.optim.Adam`` / ``FusedAdam`` or one of the graph-replayed trainers
+    (``train.MLPScoreTrainer`` / ``UNetScoreTrainer``: Adam state in the same layout, device step counter included)."""
     torch.save({"iteration": iteration, "model": gen_sde.state_dict(), "optimizer": optim.state_dict(),
                 "torch_rng": torch.get_rng_state().cpu(), "numpy_rng": np.random.get_state(),
-                "python_rng": random.getstate()}, path)
+                "python_rng": random.getstate(),
+                "msgm_hip": {"philox": {k: r.state_dict() for k, r in _philox_owners(gen_sde, optim).items()}}}, path)
 
 
 def load_checkpoint(path, gen_sde, optim, device):
     """Counterpart of NN.py:24-42.  Only load checkpoints you wrote yourself:
-    like upstream this unpickles optimizer / RNG objects."""
+    like upstream this unpickles optimizer / RNG objects.  Checkpoints written by the reference (no ``msgm_hip``
+    key) load too; the Philox streams then keep their current state."""
     ck = torch.load(path, map_location=device, weights_only=False)
     gen_sde.load_state_dict(ck["model"])
     optim.load_state_dict(ck["optimizer"])
@@ -134,6 +161,11 @@ def load_checkpoint(path, gen_sde, optim, device):
     torch.set_rng_state((rng if rng.dtype == torch.uint8 else rng.to(torch.uint8)).cpu())
     np.random.set_state(ck["numpy_rng"])
     random.setstate(ck["python_rng"])
+    saved = ck.get("msgm_hip", {}).get("philox", {})
+    if "base_sde" in saved:
+        gen_sde.base_sde.philox(device).load_state_dict(saved["base_sde"])
+    if "trainer" in saved and getattr(optim, "rng", None) is not None:
+        optim.rng.load_state_dict(saved["trainer"])
     return ck["iteration"]
 
 

@@ -64,6 +64,7 @@ class SDE(nn.Module):
         self.norm_correction = False
         self.sparseTensor = False
         self.rng: Optional[PhiloxState] = None
+        self._shard = None           # (first global row, n) of this rank's rows in a data-parallel run
 
     def to(self, device):
         new = super().to(device)
@@ -86,8 +87,24 @@ class SDE(nn.Module):
         if device.type == "cuda" and device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
         if self.rng is None or self.rng.state.device != device:
-            self.rng = PhiloxState(int(torch.initial_seed()) ^ 0x5DE5, device)
+            seed = int(torch.initial_seed()) ^ 0x5DE5
+            if self._shard is None:
+                # no shard placement given: at least give every rank of a distributed run its own stream
+                import torch.distributed as dist
+                if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                    seed = (seed + 0x9E3779B97F4A7C15 * dist.get_rank()) & 0x7FFFFFFFFFFFFFFF
+            self.rng = PhiloxState(seed, device)
+            if self._shard is not None:
+                self.rng.set_shard(*self._shard)
         return self.rng
+
+    def set_shard(self, row_base: int, n: int) -> None:
+        """Place this rank's rows at [row_base, ...) of the GLOBAL batch / sample set: with the same seed on every
+        rank the sharded run then draws (t, eps, v, dW, latent) exactly as the single-GPU run does for those rows
+        (``parallel.shard_rows`` gives row_base).  Without it, ranks of a distributed run get decorrelated seeds."""
+        self._shard = (int(row_base), int(n))
+        if self.rng is not None:
+            self.rng.set_shard(*self._shard)
 
     def beta(self, t):
         return self.beta_min + (self.beta_max - self.beta_min) * t
@@ -311,7 +328,7 @@ class MSGMsde(SDE):
         if u is None:
             u = torch.empty(num_samples, dtype=torch.float32, device=self.device)
             rng = self.philox(self.device)
-            ops.fill_uniform(u, rng, L.RNG_STREAM_USER)
+            ops.fill_uniform(u, rng, L.RNG_STREAM_ROWS)
             rng.advance(1)
         r = torch.quantile(self.r_T, u).reshape(num_samples, 1)                # SDEs.py:442
         if self.norm_map == "log":
@@ -457,17 +474,20 @@ class PluginReverseSDE(nn.Module):
         y, t = ops.perturb_vp(x.contiguous(), base.struct(), u=u, eps=eps, rng=rng)
         return t.reshape(-1, 1), x, y
 
-    def ssm(self, x, u=None, eps=None, u_v=None, y=None, t_given=None):
+    def ssm(self, x, u=None, eps=None, u_v=None, y=None, t_given=None, v=None):
         """Per-sample SSM loss (B,), gradients of its mean accumulated into the
         score net's ``.grad`` (see class docstring).  ``u``/``eps``/``u_v``
-        inject the three draws of SDEs.py:688,141,515 (parity tests)."""
+        inject the three draws of SDEs.py:688,141,515 (parity tests); ``v`` injects
+        the probe itself (any ``vtype``).  ``vtype`` 'gaussian' / 'uniform' (sphere)
+        probes (SDEs.py:517-536) are drawn from the Philox stream and go through the
+        general form of the loss (u = (dmu/da)^T v, cst = v^T (d(-f)/dy) v)."""
         from .NN import MLP
         base = self.base_sde
         net = self.a
         if not (isinstance(net, MLP) or hasattr(net, "ssm_grad")):
             raise MsgmError(f"no HIP SSM path for score net {type(net).__name__}")
-        if self.vtype != 'rademacher' and u_v is None:
-            raise MsgmError("fused SSM draws Rademacher probes")
+        if self.vtype not in ('rademacher', 'normal', 'gaussian', 'uniform'):
+            raise MsgmError(f'vtype {self.vtype} not supported')
         x = x.contiguous().float()
         B, d = x.shape
         dev = x.device
@@ -477,12 +497,19 @@ class PluginReverseSDE(nn.Module):
         else:                                        # (t, y) given: the ssm_loss(t_, x, y) entry of the reference
             t = t_given.reshape(-1, 1).contiguous().float()
             y = y.contiguous().float()
-        v = ops.rademacher((B, d), dev, u=u_v, rng=None if u_v is not None else rng)
-        if u_v is None or (t_given is None and (u is None or eps is None)):
+        pm1 = v is None and self.vtype == 'rademacher'          # probe entries are +-1: |v|^2 = d is baked into the fused kernel
+        drew_v = v is None and not (pm1 and u_v is not None)
+        if v is not None:
+            v = v.contiguous().float()
+        elif pm1:
+            v = ops.rademacher((B, d), dev, u=u_v, rng=None if u_v is not None else rng)
+        else:
+            v = sample_v((B, d), dev, self.vtype, rng=rng).contiguous()
+        if drew_v or (t_given is None and (u is None or eps is None)):
             rng.advance(1)
         st = base.struct()
         uu = cst = None
-        if base.kind != L.SDE_SGM or not isinstance(net, MLP):
+        if base.kind != L.SDE_SGM or not isinstance(net, MLP) or not pm1:
             # general form of the loss: loss_b = adot.u + cst + |a|^2/2 (u = G(y)^T v for the multiplicative SDE)
             uu, cst = ops.ssm_terms(y, v, t.reshape(-1).contiguous(), st)
         flat, gflat = net.flat_parameters()

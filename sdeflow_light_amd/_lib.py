@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libmsgm_hip.so")
 MSGM_OK = 0
 SDE_SGM, SDE_MSGM_SPARSE, SDE_MSGM_DENSE = 0, 1, 2
 PROC_REVERSE, PROC_FORWARD = 0, 1
-RNG_STREAM_T, RNG_STREAM_EPS, RNG_STREAM_V, RNG_STREAM_DW, RNG_STREAM_USER = 0, 1, 2, 3, 16
+RNG_STREAM_T, RNG_STREAM_EPS, RNG_STREAM_V, RNG_STREAM_DW, RNG_STREAM_ROWS, RNG_STREAM_USER = 0, 1, 2, 3, 4, 16
 
 
 class MsgmError(RuntimeError):
@@ -178,14 +178,31 @@ def sde_struct(kind: int, beta_min: float, beta_max: float, T: float, t_epsilon:
 
 
 class PhiloxState:
-    """Device-resident {seed, offset} pair consumed by kernels that draw noise."""
+    """Device-resident Philox state consumed by kernels that draw noise: uint64[4] = {seed, offset, row_base,
+    elem_base}.  ``set_shard(row_base, n)`` places this rank's rows inside the global index space of a data-parallel
+    run (csrc/common.h), so a sharded run draws the numbers the single-GPU run draws for the same rows."""
 
-    def __init__(self, seed: int, device, offset: int = 0):
+    def __init__(self, seed: int, device, offset: int = 0, row_base: int = 0, n: int = 0):
         # int64 storage, reinterpreted as uint64 by the kernels
-        self.state = torch.tensor([seed & 0x7FFFFFFFFFFFFFFF, offset], dtype=torch.int64, device=device)
+        self.state = torch.tensor([seed & 0x7FFFFFFFFFFFFFFF, offset, 0, 0], dtype=torch.int64, device=device)
+        if row_base:
+            self.set_shard(row_base, n)
 
     def ptr(self):
         return self.state.data_ptr()
 
+    def set_shard(self, row_base: int, n: int) -> None:
+        if (row_base * n) % 4:
+            raise MsgmError("shard base: row_base * n must be a multiple of 4 (Philox draws are addressed by quads)")
+        self.state[2:].copy_(torch.tensor([row_base, row_base * n], dtype=torch.int64))
+
     def advance(self, n: int = 1) -> None:
         check(lib().msgm_rng_advance(self.ptr(), n, stream()), "msgm_rng_advance")
+
+    def state_dict(self) -> dict:
+        seed, offset, row_base, elem_base = (int(v) for v in self.state.tolist())
+        return {"seed": seed, "offset": offset, "row_base": row_base, "elem_base": elem_base}
+
+    def load_state_dict(self, sd: dict) -> None:
+        self.state.copy_(torch.tensor([sd["seed"], sd["offset"], sd.get("row_base", 0), sd.get("elem_base", 0)],
+                                      dtype=torch.int64))

@@ -33,7 +33,16 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint3
   return Philox4{c0, c1, c2, c3};
 }
 
-// One 128-bit block for element-quad `quad` of draw-stream `stream`.
+// Philox state = uint64[4]: {seed, offset, row_base, elem_base}.  The two bases place a rank's shard inside the GLOBAL
+// index space of a data-parallel run (row_base = first global row of the shard, elem_base = row_base * n, a multiple of
+// 4), so a sharded run draws exactly the numbers the single-GPU run draws for the same rows.  Streams indexed by ROW
+// (the per-sample time draw and RNG_STREAM_ROWS) use row_base, every other stream is indexed by element.
+enum { RNG_STREAM_T = 0, RNG_STREAM_EPS = 1, RNG_STREAM_V = 2, RNG_STREAM_DW = 3, RNG_STREAM_ROWS = 4, RNG_STREAM_USER = 16 };
+__device__ __forceinline__ uint64_t msgm_rng_base(const uint64_t* rng, uint32_t stream) {
+  return (stream == RNG_STREAM_T || stream == RNG_STREAM_ROWS) ? rng[2] : rng[3];
+}
+
+// One 128-bit block for element-quad `quad` (GLOBAL index) of draw-stream `stream`.
 __device__ __forceinline__ Philox4 msgm_philox(const uint64_t* rng, uint64_t extra_offset, uint32_t stream, uint64_t quad) {
   uint64_t seed = rng[0], off = rng[1] + extra_offset;
   return philox4x32_10((uint32_t)quad, (uint32_t)(quad >> 32), stream, (uint32_t)off,
@@ -54,11 +63,11 @@ __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, fl
   n0 = r * c; n1 = r * s;
 }
 __device__ __forceinline__ f32x4 philox_uniform4(const uint64_t* rng, uint64_t extra, uint32_t stream, uint64_t quad) {
-  Philox4 p = msgm_philox(rng, extra, stream, quad);
+  Philox4 p = msgm_philox(rng, extra, stream, quad + (msgm_rng_base(rng, stream) >> 2));
   return f32x4{u01(p.x), u01(p.y), u01(p.z), u01(p.w)};
 }
 __device__ __forceinline__ f32x4 philox_normal4(const uint64_t* rng, uint64_t extra, uint32_t stream, uint64_t quad) {
-  Philox4 p = msgm_philox(rng, extra, stream, quad);
+  Philox4 p = msgm_philox(rng, extra, stream, quad + (msgm_rng_base(rng, stream) >> 2));
   f32x4 r;
   float a, b, c, d;
   box_muller(p.x, p.y, a, b);
@@ -68,17 +77,20 @@ __device__ __forceinline__ f32x4 philox_normal4(const uint64_t* rng, uint64_t ex
 }
 // scalar access to element e of a stream (e>>2 selects the quad)
 __device__ __forceinline__ float philox_uniform1(const uint64_t* rng, uint64_t extra, uint32_t stream, uint64_t e) {
-  f32x4 q = philox_uniform4(rng, extra, stream, e >> 2);
+  e += msgm_rng_base(rng, stream);
+  Philox4 p = msgm_philox(rng, extra, stream, e >> 2);
+  f32x4 q = f32x4{u01(p.x), u01(p.y), u01(p.z), u01(p.w)};
   int k = (int)(e & 3);
   return k == 0 ? q[0] : k == 1 ? q[1] : k == 2 ? q[2] : q[3];
 }
 __device__ __forceinline__ float philox_normal1(const uint64_t* rng, uint64_t extra, uint32_t stream, uint64_t e) {
-  f32x4 q = philox_normal4(rng, extra, stream, e >> 2);
+  e += msgm_rng_base(rng, stream);
+  Philox4 p = msgm_philox(rng, extra, stream, e >> 2);
+  f32x4 q;
+  { float a, b, c, d; box_muller(p.x, p.y, a, b); box_muller(p.z, p.w, c, d); q[0] = a; q[1] = b; q[2] = c; q[3] = d; }
   int k = (int)(e & 3);
   return k == 0 ? q[0] : k == 1 ? q[1] : k == 2 ? q[2] : q[3];
 }
-
-enum { RNG_STREAM_T = 0, RNG_STREAM_EPS = 1, RNG_STREAM_V = 2, RNG_STREAM_DW = 3, RNG_STREAM_USER = 16 };
 
 // ------------------------------------------------------------ SDE schedule
 // beta(t) = b0 + (b1-b0) t                                    SDEs.py:72-73

@@ -18,10 +18,11 @@ from . import ops
 
 
 class _Run:
-    __slots__ = ("params", "numel", "m", "v")
+    __slots__ = ("params", "numel", "m", "v", "group")
 
-    def __init__(self, params):
+    def __init__(self, params, group):
         self.params: List[torch.nn.Parameter] = params
+        self.group = group                     # the param_group whose lr / betas / eps this run is updated with
         self.numel = sum(p.numel() for p in params)
         dev = params[0].device
         self.m = torch.zeros(self.numel, dtype=torch.float32, device=dev)
@@ -41,8 +42,9 @@ class FusedAdam(torch.optim.Optimizer):
         self._step_host = 0
 
     def _build_runs(self):
-        runs, cur = [], []
-        for group in self.param_groups:
+        runs = []
+        for group in self.param_groups:        # a run never spans two groups: each keeps its own hyper-parameters
+            cur = []
             for p in group["params"]:
                 if not p.requires_grad:
                     continue      # e.g. the horizon T, an nn.Parameter(requires_grad=False) upstream
@@ -50,10 +52,12 @@ class FusedAdam(torch.optim.Optimizer):
                     cur.append(p)
                 else:
                     if cur:
-                        runs.append(_Run(cur))
+                        runs.append(_Run(cur, group))
                     cur = [p]
-        if cur:
-            runs.append(_Run(cur))
+            if cur:
+                runs.append(_Run(cur, group))
+        if not runs:
+            raise ValueError("FusedAdam got no trainable parameters")
         self._runs = runs
         dev = runs[0].params[0].device
         self._step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -70,11 +74,11 @@ class FusedAdam(torch.optim.Optimizer):
     def step(self, closure=None):
         if self._runs is None:
             self._build_runs()
-        g = self.param_groups[0]
-        lr, (b1, b2), eps = g["lr"], g["betas"], g["eps"]
         ops.counter_inc(self._step_dev)
         self._step_host += 1
         for r in self._runs:
+            g = r.group
+            lr, (b1, b2), eps = g["lr"], g["betas"], g["eps"]
             p0 = r.params[0]
             contiguous = p0.grad is not None
             if contiguous:
@@ -108,8 +112,12 @@ class FusedAdam(torch.optim.Optimizer):
         step = 0
         for p, (m, v) in views.items():
             st = self.state[p]
-            m.copy_(st["exp_avg"]); v.copy_(st["exp_avg_sq"])
-            step = int(float(st["step"]))
+            if "exp_avg" not in st:            # checkpoint of a never-stepped optimizer: empty state
+                m.zero_(); v.zero_()
+                st["step"] = torch.tensor(0.0)
+            else:
+                m.copy_(st["exp_avg"]); v.copy_(st["exp_avg_sq"])
+                step = int(float(st["step"]))
             st["exp_avg"], st["exp_avg_sq"] = m, v
         self._step_host = step
         self._step_dev.fill_(step)

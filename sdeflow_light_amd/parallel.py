@@ -35,9 +35,15 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
         if backend is None:
             # MSGM_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal of the N>1 path on a 1-GPU box)
             backend = os.environ.get("MSGM_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        kw = {}
         if torch.cuda.is_available():
-            torch.cuda.set_device(local % torch.cuda.device_count())
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dev = local % torch.cuda.device_count()
+            torch.cuda.set_device(dev)
+            if backend == "nccl":
+                # bind the communicator to this rank's GPU up front (eager RCCL init on the right device, no lazy
+                # device guess at the first collective)
+                kw["device_id"] = torch.device("cuda", dev)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, local, world
 
 

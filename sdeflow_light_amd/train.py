@@ -4,6 +4,11 @@ forward/tangent/loss/backward (K5) -> [RCCL all-reduce of the flat gradient
 bucket] -> fused Adam (K13).  Everything is enqueued on one stream with no
 host synchronisation, so a step can be captured once and replayed as a hipGraph
 (single-GPU) — the Philox offset and the Adam step count live on the device.
+
+Both trainers expose ``state_dict()`` / ``load_state_dict()`` in the layout of ``torch.optim.Adam`` (``state`` =
+{index: step / exp_avg / exp_avg_sq}, ``param_groups``) plus a ``philox`` entry, so the fast path goes through
+``NN.save_checkpoint`` / ``load_checkpoint`` like the reference loop does (MSGM_higherDim.py:794-826, NN.py:13-42)
+and a resumed run continues the SAME noise stream.
 """
 from __future__ import annotations
 
@@ -17,12 +22,49 @@ from . import parallel
 from ._lib import MsgmError
 
 
-class MLPScoreTrainer:
+class _TrainerState:
+    """Checkpoint surface shared by the trainers (Adam layout of torch.optim.Adam + the device Philox state)."""
+
+    def state_dict(self) -> dict:
+        step = float(self.step_dev.item())
+        st, off = {}, 0
+        for i, p in enumerate(self.net.parameters()):
+            k = p.numel()
+            st[i] = {"step": torch.tensor(step), "exp_avg": self.m[off:off + k].view(p.shape).clone(),
+                     "exp_avg_sq": self.v[off:off + k].view(p.shape).clone()}
+            off += k
+        group = {"lr": self.lr, "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(st)))}
+        return {"state": st, "param_groups": [group], "philox": self.rng.state_dict()}
+
+    def load_state_dict(self, sd: dict) -> None:
+        off, step = 0, 0
+        for i, p in enumerate(self.net.parameters()):
+            k = p.numel()
+            e = sd["state"].get(i)
+            if e is None:                       # never-stepped checkpoint: empty Adam state
+                self.m[off:off + k].zero_(); self.v[off:off + k].zero_()
+            else:
+                self.m[off:off + k].copy_(e["exp_avg"].reshape(-1)); self.v[off:off + k].copy_(e["exp_avg_sq"].reshape(-1))
+                step = int(float(e["step"]))
+            off += k
+        self.step_dev.fill_(step)
+        if sd.get("param_groups"):
+            lr = float(sd["param_groups"][0]["lr"])
+            if lr != self.lr and self.graph is not None:
+                raise MsgmError("the captured step has the learning rate baked in; build a new trainer for another lr")
+            self.lr = lr
+        if "philox" in sd:                      # absent in checkpoints written by torch.optim.Adam: keep the stream
+            self.rng.load_state_dict(sd["philox"])
+
+
+class MLPScoreTrainer(_TrainerState):
     """SGM + MLP (configs C1/C2).  ``x`` is this rank's shard (B_local, d) and
     stays resident; each ``step()`` draws fresh (t, eps, v) on the device."""
 
     def __init__(self, gen_sde, batch_local: int, lr: float = 1e-3, world: int = 1, use_graph: bool = True,
-                 seed: int = 0):
+                 seed: int = 0, row_base: int = 0):
         from .NN import MLP
         net, base = gen_sde.a, gen_sde.base_sde
         if not (isinstance(net, MLP) and base.kind == L.SDE_SGM):
@@ -35,11 +77,12 @@ class MLPScoreTrainer:
         self.m = torch.zeros_like(self.flat)
         self.v = torch.zeros_like(self.flat)
         self.step_dev = torch.zeros(1, dtype=torch.int64, device=self.dev)
-        self.rng = L.PhiloxState(seed * 1000003 + 17, self.dev)
+        # same seed on every rank + the shard's first global row: the N-rank run draws what the 1-rank run draws
+        self.rng = L.PhiloxState(seed * 1000003 + 17, self.dev, row_base=row_base, n=self.d)
         self.ws = ops.mlp_ssm_workspace(self.d, net.pre is not None, self.dev)
-        # ONE all-reduce bucket per step: [flat gradient | mean loss]
-        self.gbuf = torch.zeros(self.n + 1, dtype=torch.float32, device=self.dev)
-        self.gflat, self.loss = self.gbuf[: self.n], self.gbuf[self.n:]
+        # ONE all-reduce bucket per step: [flat gradient | mean loss] = the net's own gradient bucket
+        self.gbuf = net.grad_bucket()
+        self.loss = self.gbuf[self.n:]
         self.x = torch.zeros(batch_local, self.d, dtype=torch.float32, device=self.dev)
         self.y = torch.empty_like(self.x)
         self.t = torch.empty(batch_local, dtype=torch.float32, device=self.dev)
@@ -77,6 +120,8 @@ class MLPScoreTrainer:
             self.rng.advance(1)
 
     def capture(self):
+        """One ordinary step on a side stream (loads code objects; it is a REAL training step: parameters, Adam state,
+        Philox offset and step counter all live on the device), then the capture — which records and executes nothing."""
         s = torch.cuda.Stream(device=self.dev)
         s.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(s):
@@ -93,14 +138,15 @@ class MLPScoreTrainer:
     def step(self):
         if self.use_graph:
             if self.graph is None:
-                self.capture()
+                self.capture()           # its warm-up IS this call's training step (one update per call)
+                return self.loss
             self.graph.replay()
         else:
             self._body()
         return self.loss
 
 
-class UNetScoreTrainer:
+class UNetScoreTrainer(_TrainerState):
     """SGM + a U-Net score net exposing ``ssm_grad`` (configs C3/C4): prep kernel
     (K1 + probe) -> dual-number forward / hand-written backward -> [RCCL all-reduce
     of the flat gradient bucket] -> fused Adam on the flat parameter bucket.
@@ -111,7 +157,7 @@ class UNetScoreTrainer:
     with one rank the Adam update and the Philox advance are inside the graph too."""
 
     def __init__(self, gen_sde, batch_local: int, dim: int, lr: float = 1e-4, world: int = 1, seed: int = 0,
-                 use_graph: Optional[bool] = None):
+                 use_graph: Optional[bool] = None, row_base: int = 0):
         net, base = gen_sde.a, gen_sde.base_sde
         if not hasattr(net, "ssm_grad") or base.kind != L.SDE_SGM:
             raise MsgmError("UNetScoreTrainer needs a HIP U-Net score net and an SGMsde")
@@ -121,18 +167,19 @@ class UNetScoreTrainer:
         self.flat, self.gflat = net.flat_parameters()
         self.n = self.flat.numel()
         self.m, self.v = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
-        self.gbuf = torch.zeros(self.n + 1, dtype=torch.float32, device=self.dev)   # ONE bucket: [grads | mean loss]
-        self.loss = self.gbuf[self.n:]
+        self.gbuf = net.grad_bucket()            # ONE bucket [grads | mean loss]: the net's gradient bucket IS the
+        self.loss = self.gbuf[self.n:]           # collective buffer (no 16 MB staging copy per step)
         self.step_dev = torch.zeros(1, dtype=torch.int64, device=self.dev)
-        self.rng = L.PhiloxState(seed * 1000003 + 29, self.dev)
+        self.rng = L.PhiloxState(seed * 1000003 + 29, self.dev, row_base=row_base, n=dim)
         self.x = torch.zeros(batch_local, dim, dtype=torch.float32, device=self.dev)
         self.y, self.vp = torch.empty_like(self.x), torch.empty_like(self.x)
         self.t = torch.empty(batch_local, dtype=torch.float32, device=self.dev)
         self.st = base.struct()
         self.inv_batch = 1.0 / (batch_local * world)
-        # default: graph on one rank only — the step is GPU-bound either way (the host runs ahead of ~2000 launches),
-        # and capturing next to a live RCCL communicator is not something a 1-GPU box can rehearse
-        self.use_graph = (world == 1) if use_graph is None else bool(use_graph)
+        # default: graph everywhere.  With N ranks the graph ends before the collective (capture_error_mode
+        # "thread_local": the process group's watchdog thread may touch the runtime during the capture), the
+        # all-reduce and Adam follow eagerly on the same stream
+        self.use_graph = True if use_graph is None else bool(use_graph)
         self.graph = None
 
     def set_data(self, x):
@@ -146,10 +193,9 @@ class UNetScoreTrainer:
         u, cst = ops.ssm_terms(self.y, self.vp, self.t, self.st)
         per = self.net.ssm_grad(self.y, self.t, self.vp, u, cst, self.inv_batch)
         flat, gflat = self.net.flat_parameters()
-        if flat.data_ptr() != self.flat.data_ptr() or gflat.data_ptr() != self.gflat.data_ptr():
+        if flat.data_ptr() != self.flat.data_ptr() or gflat.data_ptr() != self.gbuf.data_ptr():
             raise MsgmError("the flat parameter bucket moved; rebuild the trainer")
-        self.gbuf[: self.n].copy_(gflat)
-        self.gbuf[self.n:].copy_((per.sum() * self.inv_batch).reshape(1))
+        self.loss.copy_((per.sum() * self.inv_batch).reshape(1))
 
     def _update(self):
         ops.adam_step(self.flat, self.gbuf[: self.n], self.m, self.v, step=0, lr=self.lr, step_dev=self.step_dev)

@@ -97,9 +97,13 @@ def test_trainer_graph_equals_eager():
         tr.set_data(gaussian_mixture_2d(4096, device=DEV))
         losses = [float(tr.step()) for _ in range(6)]
         outs.append((losses, tr.flat.clone()))
-    # the graphed run spends one extra (warm-up) step inside capture(): compare 6 eager vs steps 2..6 graphed + ...
-    assert all(abs(l) < 1e6 for l in outs[0][0]) and all(abs(l) < 1e6 for l in outs[1][0])
-    assert outs[0][0][1:] == pytest.approx(outs[1][0][:5], rel=1e-5)
+    # ONE optimizer update per step() call in both modes (capture()'s warm-up is the first call's step): the two runs
+    # match step for step, and end with the same parameters
+    assert all(abs(l) < 1e6 for l in outs[0][0])
+    assert outs[0][0] == pytest.approx(outs[1][0], rel=1e-6)
+    e = rel_l2(outs[1][1], outs[0][1])
+    print(f"graph vs eager parameters after 6 steps: rel-L2 {e:.2e}")
+    assert e <= 1e-6
 
 
 def _mlp_gen(g, prefix, d, pre, kind, **kw):
@@ -291,7 +295,7 @@ def _unet1d(L, dev=DEV):
 
 
 def test_unet1d_state_dict_keys_match_reference_layout():
-    from test_oracle_golden import unet1d_shapes
+    from oracle.shapes import unet1d_shapes
     net = _unet1d(64, "cpu")
     want = unet1d_shapes(64, None)
     got = {k: tuple(v.shape) for k, v in net.state_dict().items()}
@@ -310,7 +314,7 @@ def test_unet1d_forward_golden(tag, L):
 
 def test_unet1d_ssm_golden():
     """Per-sample SSM loss and every parameter gradient (digest) vs the reference's double-backward (g10)."""
-    from test_oracle_golden import _check_digest
+    from conftest import check_digest as _check_digest
     g = load_golden("g10_ssm_unets")
     net = _unet1d(256)
     gen = make_gen("sgm", net)
@@ -432,7 +436,7 @@ def test_ssm_msgm_end_to_end_runs():
 
 def test_ssm_unet1d_msgm_sparse_vs_oracle():
     """U-Net + multiplicative SDE through the general (u, cst) loss form, against the CPU oracle."""
-    from test_oracle_golden import unet1d_shapes
+    from oracle.shapes import unet1d_shapes
     from oracle import sde_ref as S, nets_ref as N, ssm_ref as LR
     from oracle.det_params import det_state_dict
     torch.manual_seed(0)
@@ -475,7 +479,7 @@ def test_checkpoint_roundtrip_and_torch_adam_compat(tmp_path):
     path = str(tmp_path / "ck.pt")
     save_checkpoint(path, gen, opt, 1)
     ck = torch.load(path, map_location="cpu", weights_only=False)
-    assert set(ck) == {"iteration", "model", "optimizer", "torch_rng", "numpy_rng", "python_rng"}
+    assert set(ck) == {"iteration", "model", "optimizer", "torch_rng", "numpy_rng", "python_rng", "msgm_hip"}   # reference keys + ONE
     assert {"T", "base_sde.T", "a.main.0.weight", "a.main.6.bias"} <= set(ck["model"])
     # the optimizer state is torch.optim.Adam's: it loads into a stock Adam over same-shaped parameters
     ref_params = [torch.nn.Parameter(p_.detach().cpu().clone(), requires_grad=p_.requires_grad) for p_ in gen.parameters()]

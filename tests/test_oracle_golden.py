@@ -6,11 +6,12 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, rel_l2
+from conftest import load_golden, rel_l2, check_digest as _check_digest
 from oracle import sde_ref as S
 from oracle import nets_ref as N
 from oracle import ssm_ref as L
 from oracle.det_params import det_state_dict, det_tensor
+from oracle.shapes import unet1d_shapes, unet2d_shapes
 
 TOL = 2e-6   # fp32 re-association slack between two CPU statements of the same formula
 
@@ -141,29 +142,6 @@ def test_g09_mlp(tag, pre):
     close(N.mlp_forward(g.sub(tag + "::"), g[tag + "_x"], g[tag + "_t"], pre), g[tag + "_out"], 2e-6)
 
 
-def unet1d_shapes(L, pre, base=32, mults=(1, 2, 4), emb=128):
-    """state_dict shapes of UNet1D (NNUnet1D.py:53-107)."""
-    sh = {"time_mlp.0.weight": (emb, 1), "time_mlp.0.bias": (emb,), "time_mlp.2.weight": (emb, emb), "time_mlp.2.bias": (emb,)}
-    if pre:
-        sh.update({"scale_embed.0.weight": (emb, 1), "scale_embed.0.bias": (emb,), "scale_embed.2.weight": (emb, emb), "scale_embed.2.bias": (emb,)})
-    chs = [base * m for m in mults]
-    cin = 1
-    for i, c in enumerate(chs):
-        sh.update({f"enc_blocks.{i}.net.0.weight": (c, cin + emb, 3), f"enc_blocks.{i}.net.0.bias": (c,),
-                   f"enc_blocks.{i}.net.2.weight": (c, c, 3), f"enc_blocks.{i}.net.2.bias": (c,),
-                   f"downs.{i}.weight": (c, c, 4), f"downs.{i}.bias": (c,)})
-        cin = c
-    sh.update({"middle.net.0.weight": (cin, cin + emb, 3), "middle.net.0.bias": (cin,),
-               "middle.net.2.weight": (cin, cin, 3), "middle.net.2.bias": (cin,)})
-    for i, c in enumerate(reversed(chs)):
-        sh.update({f"up_convs.{i}.weight": (cin, c, 4), f"up_convs.{i}.bias": (c,),
-                   f"dec_blocks.{i}.net.0.weight": (c, 2 * c + emb, 3), f"dec_blocks.{i}.net.0.bias": (c,),
-                   f"dec_blocks.{i}.net.2.weight": (c, c, 3), f"dec_blocks.{i}.net.2.bias": (c,)})
-        cin = c
-    sh.update({"final.weight": (1, cin, 1), "final.bias": (1,)})
-    return sh
-
-
 @pytest.mark.parametrize("tag,L,pre", [("u1d", 1024, None), ("u1dn", 1024, "NormalizeLogRadius"), ("u1d_odd", 1001, None), ("u1d_small", 64, None)])
 def test_g09_unet1d(tag, L, pre):
     g = load_golden("g09_unet1d")
@@ -171,66 +149,6 @@ def test_g09_unet1d(tag, L, pre):
     with torch.no_grad():
         y = N.unet1d_forward(p, g[tag + "_x"], g[tag + "_t"], pre)
     close(y, g[tag + "_out"], 1e-5)
-
-
-def unet2d_shapes(cfg: N.UNet2DConfig, prefix=""):
-    """state_dict shapes of UNetModel(+LogNorm) (model/unet.py:338-446)."""
-    mc, ted = cfg.model_channels, cfg.model_channels * 4
-    sh = {}
-
-    def lin(k, o, i):
-        sh[k + ".weight"], sh[k + ".bias"] = (o, i), (o,)
-
-    def conv(k, o, i, ks):
-        sh[k + ".weight"], sh[k + ".bias"] = (o, i, ks, ks), (o,)
-
-    def res(k, cin, cout):
-        sh[k + ".in_layers.0.weight"], sh[k + ".in_layers.0.bias"] = (cin,), (cin,)
-        conv(k + ".in_layers.2", cout, cin, 3)
-        lin(k + ".emb_layers.1", cout, ted)
-        sh[k + ".out_layers.0.weight"], sh[k + ".out_layers.0.bias"] = (cout,), (cout,)
-        conv(k + ".out_layers.3", cout, cout, 3)
-        if cin != cout:
-            conv(k + ".skip_connection", cout, cin, 1)
-
-    def attn(k, c):
-        sh[k + ".norm.weight"], sh[k + ".norm.bias"] = (c,), (c,)
-        sh[k + ".qkv.weight"], sh[k + ".qkv.bias"] = (3 * c, c, 1), (3 * c,)
-        sh[k + ".proj_out.weight"], sh[k + ".proj_out.bias"] = (c, c, 1), (c,)
-
-    lin("time_embed.0", ted, mc); lin("time_embed.2", ted, ted)
-    if cfg.use_log_norm:
-        lin("scale_embed.0", ted, mc); lin("scale_embed.2", ted, ted)
-    inp, mid, out = N.unet2d_plan(cfg)
-    ch = mc * cfg.channel_mult[0]
-    conv("input_blocks.0.0", ch, cfg.in_channels, 3)
-    chans = [ch]
-    level = 0
-    bi = 1
-    for level, mult in enumerate(cfg.channel_mult):
-        for _ in range(cfg.num_res_blocks):
-            kinds = inp[bi]
-            res(f"input_blocks.{bi}.0", ch, mult * mc); ch = mult * mc
-            if "attn" in kinds:
-                attn(f"input_blocks.{bi}.1", ch)
-            chans.append(ch); bi += 1
-        if level != len(cfg.channel_mult) - 1:
-            conv(f"input_blocks.{bi}.0.op", ch, ch, 3); chans.append(ch); bi += 1
-    res("middle_block.0", ch, ch); attn("middle_block.1", ch); res("middle_block.2", ch, ch)
-    bi = 0
-    for level, mult in list(enumerate(cfg.channel_mult))[::-1]:
-        for i in range(cfg.num_res_blocks + 1):
-            kinds = out[bi]
-            res(f"output_blocks.{bi}.0", ch + chans.pop(), mc * mult); ch = mc * mult
-            for j, kd in enumerate(kinds):
-                if kd == "attn":
-                    attn(f"output_blocks.{bi}.{j}", ch)
-                if kd == "up":
-                    conv(f"output_blocks.{bi}.{j}.conv", ch, ch, 3)
-            bi += 1
-    sh["out.0.weight"], sh["out.0.bias"] = (ch,), (ch,)
-    conv("out.2", cfg.out_channels, mc * cfg.channel_mult[0], 3)
-    return {prefix + k: v for k, v in sh.items()}
 
 
 def test_unet2d_param_count():
@@ -278,24 +196,6 @@ def test_g10_ssm_mlp(tag, pre, form):
     close(per, g[tag + "_per"], 5e-6)
     for k, gr in grads.items():
         close(gr, g[f"{tag}_grad::a.{k}"], 2e-5)
-
-
-def _check_digest(g, tag, grads, prefix, tol):
-    """Digest = per-tensor L2 norm + first 8 entries.  Tensors whose true
-    gradient is ~0 (conv/emb biases feeding a 1-channel-per-group GroupNorm)
-    hold only rounding noise, so the slack is floored at 1e-3 of the largest
-    tensor norm."""
-    names = [str(s) for s in g[f"{tag}_gd_names"]]
-    norms, heads = g[f"{tag}_gd_norms"], g[f"{tag}_gd_heads"]
-    assert set(names) == {prefix + k for k in grads}
-    floor = 1e-3 * float(norms.max())
-    for i, nm in enumerate(names):
-        gr = grads[nm[len(prefix):]]
-        slack = tol * max(float(norms[i]), floor)
-        assert abs(float(gr.double().norm()) - float(norms[i])) <= slack, nm
-        h = gr.reshape(-1)[:8]
-        ref = heads[i][: h.numel()]
-        assert float((h.double() - ref.double()).abs().max()) <= slack, nm
 
 
 def test_g10_ssm_unet1d():
@@ -389,3 +289,51 @@ def test_g15_log_latent_pdf_and_elbo():
     elbo = M.elbo_sgm(sp, score, p, g["elbo_x"], g["elbo_draw0_rand"], g["elbo_draw1_randn_like"], g["elbo_draw2_rand"],
                       g["elbo_draw5_randn_like"])
     close(elbo, g["elbo"], 1e-5)
+
+
+# ----------------------------------------------------------------------------- round 2 pins (g16)
+def _unet2d16_score():
+    cfg = N.UNet2DConfig(in_space=16)
+    p = det_state_dict(unet2d_shapes(cfg, "core."))
+    return lambda y, s: N.vorticity_unet_forward(p, y, s, cfg, None, "F")
+
+
+@pytest.mark.parametrize("tag,steps", [("em", 8), ("rk4", 4), ("heun", 4)])
+def test_g16_unet2d_reverse_sde_trajectories(tag, steps):
+    """The reference integrators driving VorticityUNet 16x16 F-order (sde_scheme.py:43-269 x NNUnet.py:195-245)."""
+    g = load_golden("g16_round2")
+    fn = {"em": S.euler_maruyama, "rk4": S.rk4_stratonovich, "heun": S.heun}[tag]
+    proc = S.ReverseProcess(spec(), _unet2d16_score())
+    with torch.no_grad():
+        tr = fn(proc, g["u2d_x0"], steps, g[f"u2d_{tag}_z"], keep_all=True, include_t0=True)
+    e = rel_l2(tr, g[f"u2d_{tag}_traj"])
+    print(f"oracle vs reference, U-Net {tag} trajectory: rel-L2 {e:.2e}")
+    assert e <= 2e-5
+
+
+def test_g16_mlp_em_256_steps():
+    """Error growth over a long reverse-SDE run: 256 EM steps, every 32nd state pinned."""
+    g = load_golden("g16_round2")
+    proc = S.ReverseProcess(spec(), _mlp_score(g.sub("mlp::")))
+    tr = S.euler_maruyama(proc, g["mlp_x0"], 256, g["mlp_em256_z"], keep_all=True, include_t0=True)
+    e = rel_l2(tr[::32], g["mlp_em256_every32"])
+    print(f"oracle vs reference, 256-step MLP EM: rel-L2 {e:.2e}")
+    assert e <= 2e-5
+
+
+@pytest.mark.parametrize("vt", ["gaussian", "uniform"])
+def test_g16_ssm_gaussian_and_sphere_probes(vt):
+    """SSM loss with the non-Rademacher probes (SDEs.py:517-536)."""
+    g = load_golden("g16_round2")
+    sp = spec()
+    p = {k[2:]: v for k, v in g.sub("mlp::").items() if k.startswith("a.")}
+    t = S.clamp_time(sp, g[f"ssm_{vt}_u_t"])
+    y = S.vp_perturb(sp, t, g[f"ssm_{vt}_x"], g[f"ssm_{vt}_eps"])
+    z = g[f"ssm_{vt}_zv"]
+    v = z if vt == "gaussian" else z / torch.linalg.norm(z, dim=1, keepdim=True)
+    score = lambda prm, yy, tt: N.mlp_forward(prm, yy, tt, None)
+    for form in ("jvp", "double_backward"):
+        loss, per, grads = L.ssm_mean_and_grads(sp, score, p, t, y, v, form=form)
+        close(per, g[f"ssm_{vt}_per"], 5e-6)
+        for k, gr in grads.items():
+            close(gr, g[f"ssm_{vt}_grad::a.{k}"], 2e-5)

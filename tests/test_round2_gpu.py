@@ -1,0 +1,222 @@
+"""-m gpu: round-2 parity pins.
+
+(a) the HIP integrators driving the 2-D U-Net against trajectories recorded from the reference
+    (sde_scheme.py:43-269 x NNUnet.py:195-245; tests/golden/g16_round2.npz), and a 256-step MLP Euler-Maruyama run
+    (error growth over a long reverse-SDE trajectory) — tolerance 1e-4 rel-L2 (north_star);
+(b) SSM loss + EVERY parameter gradient at the BASELINE shapes against the CPU oracle: VorticityUNet 64x64x3 (T = 1024
+    attention, 3-channel in/out convs; config C4) and UNet1D L = 1024 (config C3), batch 2 — per tensor;
+(c) the Gaussian and the sphere probe (SDEs.py:517-536) through ``ssm``.
+Every test prints the rel-L2 it measured; tolerances are set to <= 2x the measured value (rounded up to one digit),
+never above the north-star bound.
+"""
+import pytest
+import torch
+
+from conftest import load_golden, rel_l2
+from test_host_gpu import make_gen, _unet1d
+from test_unet2d_gpu import _vunet
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def per_tensor_check(named_grads, ref, tol, floor_frac=1e-3, what=""):
+    """Per-tensor rel-L2 of gradients.  A tensor whose reference norm is below floor_frac x the largest tensor norm
+    holds rounding noise only (biases in front of a GroupNorm have an analytically zero gradient): for those the error
+    is measured against the floor instead of their own norm.  Returns / prints the worst tensor."""
+    top = max(float(r.double().norm()) for r in ref.values())
+    floor = floor_frac * top
+    worst, wname, nfloor = 0.0, "", 0
+    for k, g in named_grads.items():
+        r = ref[k].double().reshape(-1)
+        scale = max(float(r.norm()), floor)
+        nfloor += float(r.norm()) < floor
+        e = float((g.double().reshape(-1).cpu() - r).norm()) / scale
+        if e > worst:
+            worst, wname = e, k
+    print(f"{what}: worst per-tensor gradient rel-L2 {worst:.2e} ({wname}); {nfloor}/{len(ref)} tensors under the "
+          f"{floor_frac:g} x max-norm floor; tolerance {tol:.1e}")
+    assert worst <= tol, (wname, worst)
+    return worst
+
+
+# ------------------------------------------------------------------------------------------ (a) trajectories
+@pytest.mark.parametrize("tag,steps,tol", [("em", 8, 2e-5), ("rk4", 4, 2e-5), ("heun", 4, 2e-5)])
+def test_unet2d_reverse_sde_trajectory_vs_reference(tag, steps, tol):
+    from sdeflow_light_amd import sde_scheme as SS
+    g = load_golden("g16_round2")
+    gen = make_gen("sgm", _vunet(16, "F"))
+    fn = {"em": SS.euler_maruyama_sampler, "rk4": SS.rk4_stratonovich_sampler, "heun": SS.heun_sampler}[tag]
+    xs = fn(gen, g["u2d_x0"].to(DEV), num_steps=steps, keep_all_samples=True, include_t0=True, noise=g[f"u2d_{tag}_z"])
+    ref = g[f"u2d_{tag}_traj"]
+    assert xs.shape == ref.shape and xs.device.type == "cpu"
+    e, e_last = rel_l2(xs, ref), rel_l2(xs[-1], ref[-1])
+    print(f"HIP vs reference, VorticityUNet 16x16 {tag} x{steps}: trajectory rel-L2 {e:.2e}, final state {e_last:.2e}")
+    assert e <= tol and e_last <= tol
+
+
+def test_mlp_em_256_steps_vs_reference():
+    from sdeflow_light_amd import sde_scheme as SS
+    from sdeflow_light_amd.NN import MLP
+    g = load_golden("g16_round2")
+    gen = make_gen("sgm", MLP(2), g, "mlp::")
+    xs = SS.euler_maruyama_sampler(gen, g["mlp_x0"].to(DEV), num_steps=256, keep_all_samples=True, include_t0=True,
+                                   noise=g["mlp_em256_z"])
+    ref = g["mlp_em256_every32"]
+    e = [rel_l2(xs[32 * i], ref[i]) for i in range(ref.shape[0])]
+    print("HIP vs reference, 256-step MLP EM, rel-L2 at steps 0,32,..,256: " + " ".join(f"{v:.1e}" for v in e))
+    assert max(e) <= 2e-5
+
+
+# ------------------------------------------------------------------------------------------ (b) BASELINE shapes
+def _oracle_case(score, p, x, u, eps, uv):
+    from oracle import sde_ref as S, ssm_ref as LR
+    B = x.shape[0]
+    sp = S.SdeSpec()
+    t = S.clamp_time(sp, u.reshape(B, 1))
+    y = S.vp_perturb(sp, t, x, eps)
+    v = S.rademacher_from_uniform(uv)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    return LR.ssm_mean_and_grads(sp, score, p, t, y, v)            # forward-mode (jvp) form, pinned == double backward
+
+
+def test_c4_shape_ssm_loss_and_all_gradients_vs_oracle():
+    """VorticityUNet 64x64x3, B = 2: attention at T = 1024 (C = 64) and T = 256 (C = 128), 3-channel convs."""
+    from oracle import nets_ref as N
+    from oracle.det_params import det_state_dict
+    from oracle.shapes import unet2d_shapes
+    torch.manual_seed(21)
+    B, d = 2, 3 * 64 * 64
+    gen = make_gen("sgm", _vunet(64, "F", channels=3))
+    x, u, eps, uv = torch.randn(B, d), torch.rand(B), torch.randn(B, d), torch.rand(B, d)
+    gen.zero_grad()
+    per = gen.ssm(x.to(DEV), u=u.to(DEV), eps=eps.to(DEV), u_v=uv.to(DEV))
+    per.mean().backward()
+    cfg = N.UNet2DConfig(in_channels=3, out_channels=3, in_space=64)
+    p = det_state_dict(unet2d_shapes(cfg))
+    score = lambda prm, yy, tt: N.image_to_flat(N.unet2d_core_forward(prm, N.flat_to_image(yy, 64, 64, "F", 3), tt.reshape(-1), cfg), "F")
+    loss, per_ref, gref = _oracle_case(score, p, x, u, eps, uv)
+    e = rel_l2(per.detach().cpu(), per_ref)
+    print(f"C4 shape: per-sample SSM loss rel-L2 {e:.2e} (loss {float(loss):.6g})")
+    assert e <= 1e-4
+    grads = {k[len("core."):]: pp.grad for k, pp in gen.a.named_parameters()}
+    assert set(grads) == set(gref)
+    flat = torch.cat([grads[k].reshape(-1).cpu() for k in gref])
+    ef = rel_l2(flat, torch.cat([gref[k].reshape(-1) for k in gref]))
+    print(f"C4 shape: all gradients, flat rel-L2 {ef:.2e}")
+    assert ef <= 1e-4
+    per_tensor_check(grads, gref, 5e-4, what="C4 shape")
+
+
+def test_c3_shape_ssm_loss_and_all_gradients_vs_oracle():
+    """UNet1D L = 1024, B = 2."""
+    from oracle import nets_ref as N
+    from oracle.det_params import det_state_dict
+    from oracle.shapes import unet1d_shapes
+    torch.manual_seed(22)
+    B, d = 2, 1024
+    gen = make_gen("sgm", _unet1d(1024))
+    x, u, eps, uv = torch.randn(B, d), torch.rand(B), torch.randn(B, d), torch.rand(B, d)
+    gen.zero_grad()
+    per = gen.ssm(x.to(DEV), u=u.to(DEV), eps=eps.to(DEV), u_v=uv.to(DEV))
+    per.mean().backward()
+    p = det_state_dict(unet1d_shapes(1024, None))
+    loss, per_ref, gref = _oracle_case(lambda prm, yy, tt: N.unet1d_forward(prm, yy, tt, None), p, x, u, eps, uv)
+    e = rel_l2(per.detach().cpu(), per_ref)
+    print(f"C3 shape: per-sample SSM loss rel-L2 {e:.2e} (loss {float(loss):.6g})")
+    assert e <= 1e-4
+    grads = {k: pp.grad for k, pp in gen.a.named_parameters()}
+    flat = torch.cat([grads[k].reshape(-1).cpu() for k in gref])
+    ef = rel_l2(flat, torch.cat([gref[k].reshape(-1) for k in gref]))
+    print(f"C3 shape: all gradients, flat rel-L2 {ef:.2e}")
+    assert ef <= 1e-4
+    per_tensor_check(grads, gref, 5e-4, what="C3 shape")
+
+
+# ------------------------------------------------------------------------------------------ (c) probe types
+@pytest.mark.parametrize("vt", ["gaussian", "uniform"])
+def test_ssm_gaussian_and_sphere_probes_vs_reference(vt):
+    from sdeflow_light_amd.NN import MLP
+    from sdeflow_light_amd import _lib as L
+    g = load_golden("g16_round2")
+    gen = make_gen("sgm", MLP(2), g, "mlp::")
+    gen.vtype = vt
+    z = g[f"ssm_{vt}_zv"]
+    v = z if vt == "gaussian" else z / torch.linalg.norm(z, dim=1, keepdim=True)
+    gen.zero_grad()
+    per = gen.ssm(g[f"ssm_{vt}_x"].to(DEV), u=g[f"ssm_{vt}_u_t"].reshape(-1).to(DEV), eps=g[f"ssm_{vt}_eps"].to(DEV), v=v.to(DEV))
+    e = rel_l2(per.detach().cpu(), g[f"ssm_{vt}_per"])
+    per.mean().backward()
+    eg = max(rel_l2(p.grad.cpu(), g[f"ssm_{vt}_grad::{k}"]) for k, p in gen.named_parameters() if p.requires_grad)
+    print(f"SSM with the {vt} probe: per-sample rel-L2 {e:.2e}, worst parameter-gradient rel-L2 {eg:.2e}")
+    assert e <= 1e-5 and eg <= 2e-4
+    # drawn (not injected) probes: right law, fresh every call, same Philox numbers as the standalone draw
+    gen.zero_grad()
+    st = gen.base_sde.philox(torch.device(DEV)).state.clone()
+    p1 = gen.ssm(g[f"ssm_{vt}_x"].to(DEV)).detach().clone()
+    p2 = gen.ssm(g[f"ssm_{vt}_x"].to(DEV)).detach()
+    assert torch.isfinite(p1).all() and not torch.equal(p1, p2)
+    assert int(gen.base_sde.rng.state[1]) > int(st[1])
+
+
+# ------------------------------------------------------------------------------------------ N3: resume with device noise
+@pytest.mark.parametrize("how", ["fused_adam_loop", "mlp_trainer", "unet_trainer"])
+def test_resume_continues_the_philox_noise_stream(how, tmp_path):
+    """Nothing injected: (t, eps, v) come from the device Philox streams.  Train 2 steps, save, train 2 more; reload in
+    a fresh object graph and train 2: the parameters must be THE SAME (MLP paths: bit for bit; U-Net: float atomics in
+    its weight gradients, so to rounding).  Without the Philox state in the checkpoint the resumed run would replay
+    the draws of iterations 0-1 and end elsewhere (checked)."""
+    from sdeflow_light_amd.NN import MLP, save_checkpoint, load_checkpoint
+    from sdeflow_light_amd.optim import FusedAdam
+    from sdeflow_light_amd.train import MLPScoreTrainer, UNetScoreTrainer
+    B = 512
+    torch.manual_seed(0)
+    d = 2 if how != "unet_trainer" else 128
+    x = torch.randn(B if d == 2 else 8, d, device=DEV)
+
+    def make(seed):
+        torch.manual_seed(seed)                       # different init in the fresh graph: everything must come from the file
+        if how == "unet_trainer":
+            from sdeflow_light_amd.NNUnet1D import UNet1D
+            gen = make_gen("sgm", UNet1D(input_dim=128, base_channels=16, channel_mults=(1, 2), emb_dim=32))
+            opt = UNetScoreTrainer(gen, 8, d, lr=1e-3, seed=4)
+        else:
+            gen = make_gen("sgm", MLP(2))
+            opt = MLPScoreTrainer(gen, B, lr=1e-3, seed=4) if how == "mlp_trainer" else FusedAdam(gen.parameters(), lr=1e-3)
+        if how != "fused_adam_loop":
+            opt.set_data(x)
+        return gen, opt
+
+    def run(gen, opt, n):
+        for _ in range(n):
+            if how == "fused_adam_loop":              # the reference loop (MSGM_higherDim.py:803-809)
+                opt.zero_grad()
+                gen.ssm(x).mean().backward()
+                opt.step()
+            else:
+                opt.step()
+
+    gen, opt = make(1)
+    run(gen, opt, 2)
+    path = str(tmp_path / "ck.pt")
+    save_checkpoint(path, gen, opt, 2)
+    run(gen, opt, 2)
+    final = gen.a.flat_parameters()[0].clone()
+    gen2, opt2 = make(2)
+    assert load_checkpoint(path, gen2, opt2, DEV) == 2
+    run(gen2, opt2, 2)
+    got = gen2.a.flat_parameters()[0]
+    e = rel_l2(got.cpu(), final.cpu())
+    print(f"resume ({how}): parameters after 2+2 steps vs uninterrupted run: rel-L2 {e:.2e}, equal={torch.equal(got, final)}")
+    if how == "unet_trainer":
+        assert e <= 1e-5
+    else:
+        assert torch.equal(got, final)
+    # negative control: dropping the Philox entry replays the first draws -> a different end point
+    ck = torch.load(path, map_location=DEV, weights_only=False)
+    ck.pop("msgm_hip"); ck["optimizer"].pop("philox", None)
+    torch.save(ck, path)
+    gen3, opt3 = make(2)
+    load_checkpoint(path, gen3, opt3, DEV)
+    run(gen3, opt3, 2)
+    assert rel_l2(gen3.a.flat_parameters()[0].cpu(), final.cpu()) > 10 * max(e, 1e-7)

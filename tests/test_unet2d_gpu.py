@@ -166,7 +166,7 @@ def _vunet(S_, order, channels=1):
 
 
 def test_unet2d_state_dict_matches_reference_layout():
-    from test_oracle_golden import unet2d_shapes
+    from oracle.shapes import unet2d_shapes
     from oracle import nets_ref as N
     net = _vunet(16, "C")
     want = unet2d_shapes(N.UNet2DConfig(in_space=16), "core.")
@@ -194,7 +194,7 @@ def test_unet2d_core64_three_channels_golden():
 
 def test_unet2d_ssm_golden():
     """SSM loss + all parameter gradients (digest) vs the reference's double backward (g10)."""
-    from test_oracle_golden import _check_digest
+    from conftest import check_digest as _check_digest
     from test_host_gpu import make_gen
     g = load_golden("g10_ssm_unets")
     net = _vunet(16, "F")
@@ -209,7 +209,7 @@ def test_unet2d_ssm_golden():
 
 def test_unet2d_ssm_vs_oracle_32():
     """Second size (32x32, both attention resolutions with T=256 / 64) against the CPU oracle's JVP form."""
-    from test_oracle_golden import unet2d_shapes
+    from oracle.shapes import unet2d_shapes
     from test_host_gpu import make_gen
     from oracle import sde_ref as S, nets_ref as N, ssm_ref as LR
     from oracle.det_params import det_state_dict
@@ -236,7 +236,7 @@ def test_unet2d_ssm_vs_oracle_32():
 def test_unet2d_reference_loop_adam_steps_vs_oracle():
     """zero_grad / ssm(x).mean() / backward / torch.optim.Adam.step (MSGM_higherDim.py:803-809) for two iterations on
     the 2-D U-Net (16x16, attention at T = 64 / 16) against the oracle doing the same on the CPU."""
-    from test_oracle_golden import unet2d_shapes
+    from oracle.shapes import unet2d_shapes
     from test_host_gpu import make_gen
     from oracle import sde_ref as S, nets_ref as N, ssm_ref as LR
     torch.manual_seed(4)
@@ -334,7 +334,7 @@ def test_unet_premodule_ssm_msgm_vs_oracle(which):
     tangent, so the embedding path itself runs on dual numbers."""
     from sdeflow_light_amd.NNUnet import VorticityUNet
     from sdeflow_light_amd.NNUnet1D import UNet1D
-    from test_oracle_golden import unet1d_shapes, unet2d_shapes
+    from oracle.shapes import unet1d_shapes, unet2d_shapes
     from test_host_gpu import make_gen
     from oracle import sde_ref as S, nets_ref as N, ssm_ref as LR
     from oracle.det_params import det_state_dict, load_det_

@@ -500,6 +500,50 @@ def g13_misc():
          lat_z=r.draws[1][1], lat_x0=x0)
 
 
+def g16_round2():
+    """Round-2 pins: (a) the reference integrators driving the 2-D U-Net (sde_scheme.py:43-99,174-269 x
+    NNUnet.py:195-245) with recorded noise; (b) a 256-step MLP Euler-Maruyama run (error growth over a long
+    reverse-SDE trajectory); (c) the SSM loss with the Gaussian and the sphere probe (SDEs.py:517-536)."""
+    torch.manual_seed(16)
+    out = {}
+    net = VorticityUNet(base_channels=32, channel_mults=(1, 2, 4), num_res_blocks=2, premodule=None, in_space=16,
+                        attention_resolutions=(2, 4), flatten_order="F")
+    load_det_(net)
+    rev = PluginReverseSDE(sgm(), net, Tparam())
+    x0 = torch.randn(4, 256)
+    out["u2d_x0"] = x0
+    with torch.no_grad():
+        xs, z = _run_sampler(euler_maruyama_sampler, rev, x0, 8, keep_all_samples=True, include_t0=True)
+        out["u2d_em_traj"], out["u2d_em_z"] = xs, z
+        xs, z = _run_sampler(rk4_stratonovich_sampler, rev, x0, 4, keep_all_samples=True, include_t0=True)
+        out["u2d_rk4_traj"], out["u2d_rk4_z"] = xs, z
+        xs, z = _run_sampler(heun_sampler, rev, x0, 4, keep_all_samples=True, include_t0=True)
+        out["u2d_heun_traj"], out["u2d_heun_z"] = xs, z
+    # (b) long MLP trajectory: every 32nd state of 256 EM steps
+    netm = MLP(2)
+    revm = PluginReverseSDE(sgm(), netm, Tparam())
+    out.update({"mlp::" + k: v for k, v in sd_np(revm.state_dict()).items()})
+    x0 = torch.randn(16, 2)
+    with torch.no_grad():
+        xs, z = _run_sampler(euler_maruyama_sampler, revm, x0, 256, keep_all_samples=True, include_t0=True)
+    out["mlp_x0"], out["mlp_em256_z"], out["mlp_em256_every32"] = x0, z, xs[::32]
+    # (c) SSM with the two non-Rademacher probes
+    B, d = 48, 2
+    for vt in ("gaussian", "uniform"):
+        revv = PluginReverseSDE(sgm(), netm, Tparam(), vtype=vt)
+        x = torch.randn(B, d) * 1.5
+        with Recorder() as r:
+            revv.zero_grad()
+            per = revv.ssm(x)
+            per.mean().backward()
+        kinds = [k for k, _ in r.draws]
+        assert kinds == ["rand", "randn_like", "randn"], kinds
+        u_t, eps, zv = (t for _, t in r.draws)
+        out.update({f"ssm_{vt}_x": x, f"ssm_{vt}_u_t": u_t, f"ssm_{vt}_eps": eps, f"ssm_{vt}_zv": zv, f"ssm_{vt}_per": per.detach()})
+        out.update({f"ssm_{vt}_grad::" + k: p.grad.detach().clone() for k, p in revv.named_parameters() if p.grad is not None})
+    save("g16_round2", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
