@@ -27,6 +27,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import socket
 import statistics
@@ -343,9 +344,24 @@ def kernel_probes(dev, Bp):
         return (f"k_wgrad_tile 3x3 {Ci}->{Co} @ {H}x{H}, dual batch {N} (msgm_conv_wgrad)", 2 * 9 * Ci * Co * N * H * H,
                 lambda: ops.conv_wgrad(geom, gy, x, Ci, 0, dWp, Co, ops.pad16(Co), ops.pad16(Ci)), (x, gy, dWp))
 
+    def attn(T, C):
+        """Training attention at the C4 block shape.  Algorithmic products as written upstream (model/unet.py:236-250
+        under the dual-number step): forward 6 x 2T^2C (S, 2 for Sdot, P v, Pdot v, P vdot), backward 12 x 2T^2C; the
+        fused backward EXECUTES 15 (it recomputes S / Sdot instead of reading (B,T,T) tensors) — not counted."""
+        qkv = torch.randn(N * T * 3 * C, device=dev)
+        s2 = 1.0 / math.sqrt(C)
+        att, stats = ops.attention_dual_forward(qkv, Bp, T, C, s2)
+        datt = torch.randn(N * T * C, device=dev)
+        ops.attention_dual_backward(qkv, att, datt, stats, Bp, T, C, s2)         # allocates the slab workspace
+        prod = 2 * T * T * C * Bp
+        return [(f"k_attn_dual_bwd<{C // 16}> T={T} C={C}, batch {Bp} (msgm_attention_dual_backward: delta + main + slab reduce)",
+                 12 * prod, lambda: ops.attention_dual_backward(qkv, att, datt, stats, Bp, T, C, s2), (qkv, att, datt, stats)),
+                (f"k_attn_dual_fwd<{C // 16}> T={T} C={C}, batch {Bp} (msgm_attention_dual_forward)", 6 * prod,
+                 lambda: ops.attention_dual_forward(qkv, Bp, T, C, s2), (qkv,))]
+
     probes.append(conv(32, 64, 64))
     probes.append(wgrad(32, 64, 64))
-    probes += ops.attention_probes(dev, Bp) if hasattr(ops, "attention_probes") else []
+    probes += attn(1024, 64)
     res = []
     for name, flop, fn, keep in probes:
         tk = time_kernel_events(fn, 20, dev)

@@ -430,6 +430,26 @@ int msgm_softmax_dual_backward(const float* P, const float* Wd, float* Pb, float
 int msgm_attention_supported(int32_t T, int32_t C);
 int msgm_attention_forward(const float* qkv, float* out, int64_t N, int32_t T, int32_t C, float scale, msgm_stream_t stream);
 
+/* Fused single-head self-attention on DUAL numbers for the TRAINING path — forward and backward of
+ * QKVAttention.forward (model/unet.py:236-250) under the forward-mode SSM step (SDEs.py:616-646: primal +
+ * tangent forward, one first-order backward over the pair), with no (B,T,T) tensor in memory:
+ *   forward:  S = scale q k^T, Sd = scale (qd k^T + q kd^T), P = softmax(S), Pd = P o (Sd - rowsum(P o Sd)),
+ *             att = [P v ; Pd v + P vd]; stats [2][Bp*T] receives per query the log-sum-exp of S and
+ *             rbar = rowsum(P o Sd) — all the backward needs besides q, k, v and att.
+ *   backward: given datt = [obar ; odbar], recomputes S / Sd tile by tile and writes dqkv = [qbar|kbar|vbar ;
+ *             qdbar|kdbar|vdbar] (every element written exactly once; deterministic: the query-side partial
+ *             sums of each 64-key block go to workspace slabs that are added in block order, no float atomics).
+ * qkv / dqkv [2Bp][T][3C] channels-last (rows [0,Bp) primal, [Bp,2Bp) tangent), att / datt [2Bp][T][C].
+ * Built for C in {32, 64} and T a multiple of 64 (msgm_attention_dual_supported); other shapes return
+ * MSGM_E_UNSUPPORTED and the caller composes msgm_bmm / msgm_softmax_dual_* instead. */
+int msgm_attention_dual_supported(int32_t T, int32_t C);
+size_t msgm_attention_dual_workspace(int64_t Bp, int32_t T, int32_t C);     /* bytes, for the backward */
+int msgm_attention_dual_forward(const float* qkv, float* att, float* stats, int64_t Bp, int32_t T, int32_t C, float scale,
+                                msgm_stream_t stream);
+int msgm_attention_dual_backward(const float* qkv, const float* att, const float* datt, const float* stats, float* dqkv,
+                                 int64_t Bp, int32_t T, int32_t C, float scale, void* workspace, size_t workspace_bytes,
+                                 msgm_stream_t stream);
+
 /* ---- reporting metric next to the hot path -------------------- */
 /* RBF kernel of compute_kernel / compute_mmd (quantitative_comparison.py:22-46):
  * k(x_i, y_j) = exp(-sum_d (x_i - y_j)^2 / d^2) for x [Nx][d], y [Ny][d].  K (may be NULL) receives the

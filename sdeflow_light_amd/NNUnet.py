@@ -325,6 +325,14 @@ class VorticityUNet(nn.Module, FlatParamMixin):
             return out
         hn, st = self._gn(a.m.norm, x, Bp, T, C, dual, False, tape)
         qkv, _, _ = a.qkv.forward([hn], N, 1, T, Bp)                     # [N][T][3C]: q | k | v channel slices
+        if dual and ops.attention_dual_supported(T, C) and not os.environ.get("MSGM_NO_ATTN_DUAL"):
+            # training: ONE kernel for the six products of the dual forward, nothing of size (T,T) written; the
+            # backward recomputes the logits from q, k and the per-query (log-sum-exp, rbar) kept here
+            att, stats = ops.attention_dual_forward(qkv, Bp, T, C, s2)
+            out, _, _ = a.proj.forward([att], N, 1, T, Bp, residual=x)
+            if tape is not None:
+                tape.append(("attn", a, x, H, W, hn, st, qkv, None, None, stats, att))
+            return out
         ld = 3 * C
         half = Bp * T * ld                                               # offset of the tangent rows
         S = torch.empty(Bp * T * T, device=dev)
@@ -573,6 +581,12 @@ class VorticityUNet(nn.Module, FlatParamMixin):
         ld = 3 * C
         half, offa = Bp * T * ld, Bp * T * C
         (datt,) = a.proj.backward(dout, [att], N, 1, T, Bp)             # [N][T][C]: abar | adotbar
+        if Pm is None:                                                  # fused dual attention (Pd slot = its row stats)
+            dqkv = ops.attention_dual_backward(qkv, att, datt, Pd, Bp, T, C, s2)
+            (dhn,) = a.qkv.backward(dqkv, [hn], N, 1, T, Bp)
+            dx = self._gn_bwd(a.m.norm, xin, st, dhn, Bp, T, C, False)
+            ops.lincomb(dx, dx, 1.0, dout, 1.0)
+            return dx
         dqkv = torch.empty(N * T * ld, device=dev)                     # every slice is written exactly once below
         sP, sPt = (T * T, T, 1), (T * T, 1, T)                          # P(t,s) / P^T(s,t)
         sa, sq = (T * C, C, 1), (T * ld, ld, 1)

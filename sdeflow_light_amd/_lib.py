@@ -102,6 +102,10 @@ SIGNATURES = {
     "msgm_rbf_kernel": (C.c_int, [_P, _P, _I64, _I64, _I32, _P, _P, _P]),
     "msgm_attention_supported": (C.c_int, [_I32, _I32]),
     "msgm_attention_forward": (C.c_int, [_P, _P, _I64, _I32, _I32, _F, _P]),
+    "msgm_attention_dual_supported": (C.c_int, [_I32, _I32]),
+    "msgm_attention_dual_workspace": (_SZ, [_I64, _I32, _I32]),
+    "msgm_attention_dual_forward": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _F, _P]),
+    "msgm_attention_dual_backward": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _F, _P, _SZ, _P]),
     "msgm_timestep_embedding": (C.c_int, [_P, _P, _I32, _I32, _F, _P]),
     "msgm_timestep_embedding_dual": (C.c_int, [_P, _P, _I32, _I32, _F, _P]),
     "msgm_normalize_dual": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _F, _F, _P]),

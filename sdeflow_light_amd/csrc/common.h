@@ -13,6 +13,22 @@ static inline int msgm_check_launch() {
   return hipGetLastError() == hipSuccess ? MSGM_OK : MSGM_E_LAUNCH;
 }
 
+// Zero-fill as a KERNEL node.  hipMemsetAsync must not be used on this path: inside a captured hipGraph (ROCm 7.2,
+// gfx950) a memset node was observed to lose its ordering against the kernel nodes around it when the replay starts
+// on an idle GPU (a replay right behind the previous one was fine) — float atomics then accumulated into a buffer that
+// had not been cleared yet (tools/debug_race.py; 1e27-size garbage in the embedding gradients after a 0.5 s pause).
+static __global__ void __launch_bounds__(256) k_msgm_zero_u32(uint32_t* __restrict__ p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0u;
+}
+static inline int msgm_zero_async(void* p, size_t bytes, hipStream_t st) {
+  const size_t n = bytes / 4;                              // every buffer on this path is a multiple of 4 bytes
+  if (n == 0) return MSGM_OK;
+  size_t g = (n + 255) / 256;
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(k_msgm_zero_u32, dim3((unsigned)g), dim3(256), 0, st, static_cast<uint32_t*>(p), n);
+  return msgm_check_launch();
+}
+
 // ------------------------------------------------------------------ Philox
 // Philox4x32-10 (Salmon et al. 2011).  key = seed, counter = (elem_lo,
 // elem_hi, stream, offset_lo) ^ offset_hi folded into the key so that every

@@ -1210,7 +1210,7 @@ int msgm_colsum(const float* x, float* Sout, int32_t N, int32_t P, int32_t C, ms
   if (chunk < 64) chunk = 64;
   if (chunk > P) chunk = P;
   nch = (P + chunk - 1) / chunk;
-  if (nch > 1 && hipMemsetAsync(Sout, 0, (size_t)N * C * sizeof(float), S(stream)) != hipSuccess) return MSGM_E_LAUNCH;
+  if (nch > 1 && msgm_zero_async(Sout, (size_t)N * C * sizeof(float), S(stream)) != MSGM_OK) return MSGM_E_LAUNCH;
   hipLaunchKernelGGL(k_colsum, dim3(N, nch), dim3(256), 0, S(stream), x, Sout, P, C, chunk, 0);
   return msgm_check_launch();
 }

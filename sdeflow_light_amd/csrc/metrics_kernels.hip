@@ -74,7 +74,7 @@ int msgm_rbf_kernel(const float* x, const float* y, int64_t Nx, int64_t Ny, int3
   if (!x || !y || Nx <= 0 || Ny <= 0 || d <= 0 || (!K && !sum)) return MSGM_E_BADARG;
   const int64_t gx = (Ny + RB_T - 1) / RB_T, gy = (Nx + RB_T - 1) / RB_T;
   if (gy > 65535 || gx > 0x7fffffffLL) return MSGM_E_UNSUPPORTED;
-  if (sum && hipMemsetAsync(sum, 0, sizeof(double), S(stream)) != hipSuccess) return MSGM_E_LAUNCH;
+  if (sum && msgm_zero_async(sum, sizeof(double), S(stream)) != MSGM_OK) return MSGM_E_LAUNCH;
   hipLaunchKernelGGL(k_rbf, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, S(stream), x, y, Nx, Ny, d, K, sum);
   return msgm_check_launch();
 }

@@ -799,7 +799,7 @@ int msgm_groupnorm_dual_backward(const float* x, const float* gamma, const float
   const int nap = gn_chunks_apply(Bp, P, &A.chunk);
   if (C % 4 == 0) hipLaunchKernelGGL(k_gn_bwd_apply<true>, dim3(nap, Bp), dim3(256), 0, S(stream), A);
   else hipLaunchKernelGGL(k_gn_bwd_apply<false>, dim3(nap, Bp), dim3(256), 0, S(stream), A);
-  if (hipMemsetAsync(workspace, 0, gn_acc_bytes(Bp, G), S(stream)) != hipSuccess) return MSGM_E_LAUNCH;   // zero on exit
+  if (msgm_zero_async(workspace, gn_acc_bytes(Bp, G), S(stream)) != MSGM_OK) return MSGM_E_LAUNCH;   // zero on exit
   return msgm_check_launch();
 }
 

@@ -531,6 +531,44 @@ def attention_forward(qkv, out, N, T, C, scale):
     return out
 
 
+def attention_dual_supported(T, C) -> bool:
+    return bool(lib().msgm_attention_dual_supported(int(T), int(C)))
+
+
+def attention_dual_forward(qkv, Bp, T, C, scale):
+    """Training-path attention on dual numbers: qkv [2Bp][T][3C] -> (att [2Bp][T][C] = o | odot, stats [2][Bp*T])."""
+    if qkv.numel() < 2 * Bp * T * 3 * C:
+        raise MsgmError("attention_dual: qkv too small")
+    att = torch.empty(2 * Bp * T * C, dtype=torch.float32, device=qkv.device)
+    stats = torch.empty(2 * Bp * T, dtype=torch.float32, device=qkv.device)
+    check(lib().msgm_attention_dual_forward(ptr(f32(qkv)), ptr(att), ptr(stats), Bp, T, C, float(scale), stream()),
+          "msgm_attention_dual_forward")
+    return att, stats
+
+
+_attn_ws = {}
+_attn_ws_keep = []          # outgrown workspaces stay alive: a captured hipGraph may still hold their address
+
+
+def attention_dual_backward(qkv, att, datt, stats, Bp, T, C, scale):
+    """dqkv [2Bp][T][3C] from datt = [obar ; odbar]; the slab workspace is cached per device and grows to the largest use
+    (one step runs its attention blocks one after the other on one stream, so they share it)."""
+    if min(qkv.numel() // 3, att.numel(), datt.numel()) < 2 * Bp * T * C or stats.numel() < 2 * Bp * T:
+        raise MsgmError("attention_dual backward: buffer too small")
+    need = int(lib().msgm_attention_dual_workspace(Bp, T, C))
+    ws = _attn_ws.get(qkv.device)
+    if ws is None or ws.numel() * 4 < need:
+        if torch.cuda.is_current_stream_capturing():
+            raise MsgmError("attention workspace must exist before graph capture (run one eager step first)")
+        if ws is not None:
+            _attn_ws_keep.append(ws)
+        ws = _attn_ws[qkv.device] = torch.empty(need // 4, dtype=torch.float32, device=qkv.device)
+    dqkv = torch.empty(2 * Bp * T * 3 * C, dtype=torch.float32, device=qkv.device)
+    check(lib().msgm_attention_dual_backward(ptr(f32(qkv)), ptr(f32(att)), ptr(f32(datt)), ptr(f32(stats)), ptr(dqkv), Bp, T, C,
+                                             float(scale), ptr(ws), ws.numel() * 4, stream()), "msgm_attention_dual_backward")
+    return dqkv
+
+
 def softmax_dual_backward(Pm, Wd, Pb, Pdb, T):
     rows = Pm.numel() // T
     if not (Wd.numel() == Pb.numel() == Pdb.numel() == Pm.numel()):

@@ -195,7 +195,9 @@ class UNetScoreTrainer(_TrainerState):
         flat, gflat = self.net.flat_parameters()
         if flat.data_ptr() != self.flat.data_ptr() or gflat.data_ptr() != self.gbuf.data_ptr():
             raise MsgmError("the flat parameter bucket moved; rebuild the trainer")
-        self.loss.copy_((per.sum() * self.inv_batch).reshape(1))
+        # kernel nodes only inside the captured step (no D2D memcpy / memset nodes: see msgm_zero_async in csrc/common.h)
+        torch.sum(per.view(1, -1), dim=1, out=self.loss)
+        self.loss.mul_(self.inv_batch)
 
     def _update(self):
         ops.adam_step(self.flat, self.gbuf[: self.n], self.m, self.v, step=0, lr=self.lr, step_dev=self.step_dev)

@@ -69,68 +69,76 @@ def test_mlp_em_256_steps_vs_reference():
 
 
 # ------------------------------------------------------------------------------------------ (b) BASELINE shapes
-def _oracle_case(score, p, x, u, eps, uv):
+def ssm_parity_vs_fp64(gen, score, p, x, u, eps, uv, what, grad_key=lambda k: k):
+    """The yardstick for 'within fp32 tolerance' on a deep net: the oracle evaluated in float64 is the truth, the oracle
+    in float32 is the reference's own arithmetic (same formulas, ATen fp32).  The HIP result must be no further from the
+    truth than TWICE the reference's own fp32 evaluation — for the per-sample loss, for the flat gradient and for the
+    worst single parameter tensor (per-tensor errors relative to max(|g_k|, 1e-3 max_k |g_k|): tensors below that floor
+    have an analytically zero gradient and hold rounding noise only).  Everything measured is printed."""
     from oracle import sde_ref as S, ssm_ref as LR
     B = x.shape[0]
     sp = S.SdeSpec()
-    t = S.clamp_time(sp, u.reshape(B, 1))
-    y = S.vp_perturb(sp, t, x, eps)
-    v = S.rademacher_from_uniform(uv)
     torch.set_num_threads(min(16, torch.get_num_threads()))
-    return LR.ssm_mean_and_grads(sp, score, p, t, y, v)            # forward-mode (jvp) form, pinned == double backward
+    gen.zero_grad()
+    per = gen.ssm(x.to(DEV), u=u.to(DEV), eps=eps.to(DEV), u_v=uv.to(DEV))
+    per.mean().backward()
+    per = per.detach().cpu()
+    grads = {grad_key(k): pp.grad.detach().cpu() for k, pp in gen.a.named_parameters()}
+
+    def oracle(dt):
+        t = S.clamp_time(sp, u.reshape(B, 1))
+        y = S.vp_perturb(sp, t, x, eps)
+        v = S.rademacher_from_uniform(uv)
+        return LR.ssm_mean_and_grads(sp, score, {k: w.to(dt) for k, w in p.items()}, t.to(dt), y.to(dt), v.to(dt))
+    _, per32, g32 = oracle(torch.float32)
+    _, per64, g64 = oracle(torch.float64)
+    assert set(grads) == set(g64)
+    keys = list(g64)
+    cat = lambda g: torch.cat([g[k].reshape(-1).double() for k in keys])
+    e_per, r_per = rel_l2(per, per64), rel_l2(per32, per64)
+    e_flat, r_flat = rel_l2(cat(grads), cat(g64)), rel_l2(cat(g32), cat(g64))
+    top = max(float(g64[k].norm()) for k in keys)
+    pt = lambda g, k: float((g[k].double() - g64[k]).norm()) / max(float(g64[k].norm()), 1e-3 * top)
+    e_t = {k: pt(grads, k) for k in keys}
+    r_t = {k: pt(g32, k) for k in keys}
+    kw, kr = max(e_t, key=e_t.get), max(r_t, key=r_t.get)
+    print(f"{what} (errors vs the float64 oracle; HIP | reference arithmetic = float32 oracle):\n"
+          f"  per-sample SSM loss rel-L2   {e_per:.2e} | {r_per:.2e}   (HIP vs fp32 oracle directly: {rel_l2(per, per32):.2e})\n"
+          f"  all gradients, flat rel-L2   {e_flat:.2e} | {r_flat:.2e}\n"
+          f"  worst parameter tensor       {e_t[kw]:.2e} ({kw}) | {r_t[kr]:.2e} ({kr})")
+    assert e_per <= max(2 * r_per, 1e-5)
+    assert e_flat <= max(2 * r_flat, 1e-5)
+    assert e_t[kw] <= max(2 * r_t[kr], 1e-5), kw
+    return e_per, e_flat
 
 
 def test_c4_shape_ssm_loss_and_all_gradients_vs_oracle():
-    """VorticityUNet 64x64x3, B = 2: attention at T = 1024 (C = 64) and T = 256 (C = 128), 3-channel convs."""
+    """VorticityUNet 64x64x3, B = 2: attention at T = 1024 (C = 64, fused dual kernel) and T = 256 (C = 128), 3-channel
+    convs — the C4 network at a batch the float64 oracle evaluates in seconds."""
     from oracle import nets_ref as N
     from oracle.det_params import det_state_dict
     from oracle.shapes import unet2d_shapes
-    torch.manual_seed(21)
     B, d = 2, 3 * 64 * 64
     gen = make_gen("sgm", _vunet(64, "F", channels=3))
+    torch.manual_seed(21)
     x, u, eps, uv = torch.randn(B, d), torch.rand(B), torch.randn(B, d), torch.rand(B, d)
-    gen.zero_grad()
-    per = gen.ssm(x.to(DEV), u=u.to(DEV), eps=eps.to(DEV), u_v=uv.to(DEV))
-    per.mean().backward()
     cfg = N.UNet2DConfig(in_channels=3, out_channels=3, in_space=64)
     p = det_state_dict(unet2d_shapes(cfg))
     score = lambda prm, yy, tt: N.image_to_flat(N.unet2d_core_forward(prm, N.flat_to_image(yy, 64, 64, "F", 3), tt.reshape(-1), cfg), "F")
-    loss, per_ref, gref = _oracle_case(score, p, x, u, eps, uv)
-    e = rel_l2(per.detach().cpu(), per_ref)
-    print(f"C4 shape: per-sample SSM loss rel-L2 {e:.2e} (loss {float(loss):.6g})")
-    assert e <= 1e-4
-    grads = {k[len("core."):]: pp.grad for k, pp in gen.a.named_parameters()}
-    assert set(grads) == set(gref)
-    flat = torch.cat([grads[k].reshape(-1).cpu() for k in gref])
-    ef = rel_l2(flat, torch.cat([gref[k].reshape(-1) for k in gref]))
-    print(f"C4 shape: all gradients, flat rel-L2 {ef:.2e}")
-    assert ef <= 1e-4
-    per_tensor_check(grads, gref, 5e-4, what="C4 shape")
+    ssm_parity_vs_fp64(gen, score, p, x, u, eps, uv, "C4 shape (2-D U-Net 64x64x3, B=2)", grad_key=lambda k: k[len("core."):])
 
 
 def test_c3_shape_ssm_loss_and_all_gradients_vs_oracle():
-    """UNet1D L = 1024, B = 2."""
+    """UNet1D L = 1024, B = 2 (the C3 network)."""
     from oracle import nets_ref as N
     from oracle.det_params import det_state_dict
     from oracle.shapes import unet1d_shapes
-    torch.manual_seed(22)
     B, d = 2, 1024
     gen = make_gen("sgm", _unet1d(1024))
+    torch.manual_seed(22)
     x, u, eps, uv = torch.randn(B, d), torch.rand(B), torch.randn(B, d), torch.rand(B, d)
-    gen.zero_grad()
-    per = gen.ssm(x.to(DEV), u=u.to(DEV), eps=eps.to(DEV), u_v=uv.to(DEV))
-    per.mean().backward()
     p = det_state_dict(unet1d_shapes(1024, None))
-    loss, per_ref, gref = _oracle_case(lambda prm, yy, tt: N.unet1d_forward(prm, yy, tt, None), p, x, u, eps, uv)
-    e = rel_l2(per.detach().cpu(), per_ref)
-    print(f"C3 shape: per-sample SSM loss rel-L2 {e:.2e} (loss {float(loss):.6g})")
-    assert e <= 1e-4
-    grads = {k: pp.grad for k, pp in gen.a.named_parameters()}
-    flat = torch.cat([grads[k].reshape(-1).cpu() for k in gref])
-    ef = rel_l2(flat, torch.cat([gref[k].reshape(-1) for k in gref]))
-    print(f"C3 shape: all gradients, flat rel-L2 {ef:.2e}")
-    assert ef <= 1e-4
-    per_tensor_check(grads, gref, 5e-4, what="C3 shape")
+    ssm_parity_vs_fp64(gen, lambda prm, yy, tt: N.unet1d_forward(prm, yy, tt, None), p, x, u, eps, uv, "C3 shape (UNet1D L=1024, B=2)")
 
 
 # ------------------------------------------------------------------------------------------ (c) probe types

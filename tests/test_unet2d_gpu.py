@@ -471,3 +471,40 @@ def test_flat_img_helpers_match_reference_semantics(order):
     assert img.shape == (B, 1, H, W) and rel_l2(img.cpu(), ref) <= 1e-7
     back = img_to_flat(img, order)
     assert back.shape == (B, H * W) and rel_l2(back.cpu(), x) <= 1e-6
+
+
+@pytest.mark.parametrize("Bp,T,C", [(3, 64, 32), (2, 128, 64), (2, 320, 64), (1, 1024, 64), (5, 192, 32)])
+def test_fused_dual_attention_forward_backward(Bp, T, C):
+    """K8 (training path): attention on dual numbers, forward and backward, without the (T,T) tensors — vs plain PyTorch
+    fp32 (torch.func.jvp of QKVAttention.forward's arithmetic, model/unet.py:236-250, then autograd of the pair)."""
+    from sdeflow_light_amd import ops
+    torch.manual_seed(T + C + Bp)
+    qkv = torch.randn(2 * Bp, T, 3 * C) * 1.2
+    qkv[0, : T // 2, :C] *= 3.0                          # a few peaked rows: exercises the running-max rescale
+    s = C ** -0.25
+
+    def attn(x):
+        q, k, v = x[..., :C], x[..., C:2 * C], x[..., 2 * C:]
+        return torch.einsum("bts,bsc->btc", torch.softmax(torch.einsum("btc,bsc->bts", q * s, k * s), -1), v)
+    xp, xt = qkv[:Bp].clone().requires_grad_(True), qkv[Bp:].clone().requires_grad_(True)
+    o, od = torch.func.jvp(attn, (xp,), (xt,))
+    assert ops.attention_dual_supported(T, C)
+    dev_qkv = qkv.to(DEV).contiguous().view(-1)
+    att, stats = ops.attention_dual_forward(dev_qkv, Bp, T, C, 1.0 / math.sqrt(C))
+    a = att.view(2 * Bp, T, C).cpu()
+    e_o, e_od = rel_l2(a[:Bp], o.detach()), rel_l2(a[Bp:], od.detach())
+    g = torch.randn(2 * Bp, T, C)
+    ((o * g[:Bp]).sum() + (od * g[Bp:]).sum()).backward()
+    dq = ops.attention_dual_backward(dev_qkv, att, g.to(DEV).contiguous().view(-1), stats, Bp, T, C, 1.0 / math.sqrt(C))
+    d = dq.view(2 * Bp, T, 3 * C).cpu()
+    names = ("q", "k", "v")
+    errs = {}
+    for i, nm in enumerate(names):
+        errs[nm] = rel_l2(d[:Bp, :, i * C:(i + 1) * C], xp.grad[..., i * C:(i + 1) * C])
+        errs[nm + "dot"] = rel_l2(d[Bp:, :, i * C:(i + 1) * C], xt.grad[..., i * C:(i + 1) * C])
+    print(f"dual attention Bp={Bp} T={T} C={C}: o {e_o:.1e} odot {e_od:.1e} | " + " ".join(f"{k}bar {v:.1e}" for k, v in errs.items()))
+    assert e_o <= 2e-5 and e_od <= 2e-5
+    assert max(errs.values()) <= 2e-5
+    # deterministic: a second backward gives the same bits (slab reduction in block order, no atomics)
+    dq2 = ops.attention_dual_backward(dev_qkv, att, g.to(DEV).contiguous().view(-1), stats, Bp, T, C, 1.0 / math.sqrt(C))
+    assert torch.equal(dq, dq2)
