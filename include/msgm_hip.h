@@ -142,6 +142,10 @@ int msgm_sde_stage(float* out, const float* base, float c_out,
  * replayed for every i; msgm_counter_inc(step) closes the step. */
 int msgm_time_tick(const float* ts, const int64_t* step, int64_t n_ts, float T, float* t_dev, float* s_out,
                    int64_t B, msgm_stream_t stream);
+/* The same clock for the later stages of Heun / RK4 (sde_scheme.py:150,233-247): t_dev[0] = ts[*step] + t_add in
+ * fp32 (t_add = delta/2 or delta as a float32, exactly as upstream adds them to a float32 tensor). */
+int msgm_time_tick_stage(const float* ts, const int64_t* step, int64_t n_ts, float T, float t_add, float* t_dev,
+                         float* s_out, int64_t B, msgm_stream_t stream);
 
 /* K12: SSM loss reduction for a score net evaluated on a (primal | tangent)
  * stacked batch, SGM case.  `out` is [2B][n] (a = out[:B], adot = J_a v = out[B:]):

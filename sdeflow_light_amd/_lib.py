@@ -70,6 +70,7 @@ SIGNATURES = {
     "msgm_sde_stage": (C.c_int, [_P, _P, _F, _P, _P, _P, _P, _F, _P, _U64, _P, _P, _I64, _I64, C.POINTER(SdeT), _I32,
                                  _I32, _F, _F, _F, _P, _P, _F, _P, _P, _P]),
     "msgm_time_tick": (C.c_int, [_P, _P, _I64, _F, _P, _P, _I64, _P]),
+    "msgm_time_tick_stage": (C.c_int, [_P, _P, _I64, _F, _F, _P, _P, _I64, _P]),
     "msgm_ssm_loss_diag": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, C.POINTER(SdeT), _F, _P]),
     "msgm_lincomb": (C.c_int, [_P, _P, _F, _P, _F, _P, _F, _I64, _P]),
     "msgm_rk4_combine": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P]),

@@ -26,10 +26,12 @@ __global__ void k_fill(float* __restrict__ out, int64_t n, const uint64_t* __res
 // reverse-time argument of the score net, SDEs.py:556-557).  The step counter itself is bumped by
 // msgm_counter_inc at the END of the step so every kernel of the step reads the same i.
 __global__ void k_time_tick(const float* __restrict__ ts, const int64_t* __restrict__ step, int64_t n_ts, float T,
-                            float* __restrict__ t_dev, float* __restrict__ s_out, int64_t B) {
+                            float* __restrict__ t_dev, float* __restrict__ s_out, int64_t B, float t_add) {
   int64_t i = step[0];
   if (i >= n_ts) i = n_ts - 1;
-  const float t = ts[i];
+  // stage time of Heun / RK4: fp32 t + fp32 offset, as upstream forms t + delta/2 and t + delta on a float32 tensor
+  // (sde_scheme.py:150,233-247); t_add = 0 for Euler-Maruyama and for the first stage
+  const float t = t_add != 0.f ? __fadd_rn(ts[i], t_add) : ts[i];
   if (blockIdx.x == 0 && threadIdx.x == 0) t_dev[0] = t;
   for (int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; b < B; b += (int64_t)gridDim.x * blockDim.x) s_out[b] = T - t;
 }
@@ -564,7 +566,14 @@ int msgm_rng_advance(uint64_t* rng, uint64_t n, msgm_stream_t stream) {
 int msgm_time_tick(const float* ts, const int64_t* step, int64_t n_ts, float T, float* t_dev, float* s_out, int64_t B,
                    msgm_stream_t stream) {
   if (!ts || !step || !t_dev || !s_out || n_ts <= 0 || B <= 0) return MSGM_E_BADARG;
-  hipLaunchKernelGGL(k_time_tick, dim3(grid_for(B, 256, 256)), dim3(256), 0, S(stream), ts, step, n_ts, T, t_dev, s_out, B);
+  hipLaunchKernelGGL(k_time_tick, dim3(grid_for(B, 256, 256)), dim3(256), 0, S(stream), ts, step, n_ts, T, t_dev, s_out, B, 0.f);
+  return msgm_check_launch();
+}
+
+int msgm_time_tick_stage(const float* ts, const int64_t* step, int64_t n_ts, float T, float t_add, float* t_dev, float* s_out,
+                         int64_t B, msgm_stream_t stream) {
+  if (!ts || !step || !t_dev || !s_out || n_ts <= 0 || B <= 0) return MSGM_E_BADARG;
+  hipLaunchKernelGGL(k_time_tick, dim3(grid_for(B, 256, 256)), dim3(256), 0, S(stream), ts, step, n_ts, T, t_dev, s_out, B, t_add);
   return msgm_check_launch();
 }
 

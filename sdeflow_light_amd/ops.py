@@ -150,9 +150,15 @@ def adam_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor
                                float(gscale), int(step), ptr(step_dev), stream()), "msgm_adam_step")
 
 
-def time_tick(ts: torch.Tensor, step: torch.Tensor, T: float, t_dev: torch.Tensor, s_out: torch.Tensor):
-    check(lib().msgm_time_tick(ptr(f32(ts)), ptr(step), ts.numel(), float(T), ptr(f32(t_dev)), ptr(f32(s_out)), s_out.numel(),
-                               stream()), "msgm_time_tick")
+def time_tick(ts: torch.Tensor, step: torch.Tensor, T: float, t_dev: torch.Tensor, s_out: torch.Tensor, t_add: float = 0.0):
+    """Device clock of a replayed sampler step: t_dev = ts[step] (+ t_add in fp32 for the later Heun / RK4 stages),
+    s_out[:] = T - t_dev."""
+    if t_add == 0.0:
+        check(lib().msgm_time_tick(ptr(f32(ts)), ptr(step), ts.numel(), float(T), ptr(f32(t_dev)), ptr(f32(s_out)),
+                                   s_out.numel(), stream()), "msgm_time_tick")
+    else:
+        check(lib().msgm_time_tick_stage(ptr(f32(ts)), ptr(step), ts.numel(), float(T), float(t_add), ptr(f32(t_dev)),
+                                         ptr(f32(s_out)), s_out.numel(), stream()), "msgm_time_tick_stage")
 
 
 def counter_inc(ctr: torch.Tensor):

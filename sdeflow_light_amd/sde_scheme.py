@@ -283,41 +283,81 @@ class GraphedEMSampler:
 
 
 class GraphedStepSampler:
-    """Euler–Maruyama with ANY HIP score net (U-Nets): ONE step — device clock tick, score-net forward (hundreds
-    of kernels), fused stage kernel, step-counter bump — is captured as a hipGraph and replayed num_steps times.
-    The time grid (fp32 ``linspace`` as upstream, sde_scheme.py:59) and the step index live on the device, so the
-    replays need no host scalar (the reference does ``ts[i].item()`` + ``fill_`` every step, sde_scheme.py:81)."""
+    """Euler-Maruyama, Heun or RK4-Stratonovich with ANY HIP score net (U-Nets): ONE step — device clock ticks, the
+    score-net forward(s) (hundreds of kernels each), the fused stage kernels, step-counter bump — is captured as a
+    hipGraph and replayed num_steps times.  The time grid (fp32 ``linspace`` as upstream, sde_scheme.py:59), the stage
+    times t + delta/2, t + delta (fp32 adds as upstream, sde_scheme.py:150,233-247) and the step index live on the
+    device, so the replays need no host scalar (the reference does ``ts[i].item()`` + ``fill_`` every step,
+    sde_scheme.py:81).  ``method='rk4'`` is what the driver generates with (MSGM_higherDim.py:903).  Only kernel nodes
+    are captured (no D2D memcpy / memset nodes — see msgm_zero_async in csrc/common.h)."""
 
-    def __init__(self, sde, B, n, num_steps, lmbd=0.0, norm_correction=False):
+    def __init__(self, sde, B, n, num_steps, lmbd=0.0, norm_correction=False, method="em"):
         from .SDEs import PluginReverseSDE
         if not isinstance(sde, PluginReverseSDE):
             raise MsgmError("GraphedStepSampler integrates a PluginReverseSDE")
+        if method not in ("em", "heun", "rk4"):
+            raise MsgmError(f"unknown integrator {method}")
         base = sde.base_sde
         dev = sde.T.device
-        self.sde, self.N, self.B, self.n = sde, num_steps, B, n
+        self.sde, self.N, self.B, self.n, self.method = sde, num_steps, B, n, method
         T = base.T_float()
         self.ts = (torch.linspace(0, 1, num_steps + 1) * T).to(dev)
         self.step = torch.zeros(1, dtype=torch.int64, device=dev)
-        self.t_dev = torch.zeros(1, device=dev)
-        self.s = torch.zeros(B, device=dev)
+        nstage = {"em": 1, "heun": 2, "rk4": 3}[method]                   # distinct stage times
+        self.t_dev = [torch.zeros(1, device=dev) for _ in range(nstage)]
+        self.s = [torch.zeros(B, device=dev) for _ in range(nstage)]
         self.x = torch.zeros(B, n, device=dev)
-        self.other = torch.zeros(B, n, device=dev) if base.kind != L.SDE_SGM else None
         self.norm0 = torch.zeros(B, device=dev) if norm_correction else None
         self.rng = base.philox(dev)
         st, delta = base.struct(), T / num_steps
         self._keep = st
         inplace = base.kind == L.SDE_SGM
+        buf = lambda: torch.zeros(B, n, device=dev)
+        if method == "em":
+            other = None if inplace else buf()
+        elif method == "heun":
+            dW, k1, xp, xn = buf(), buf(), buf(), buf()
+        else:
+            dW, k1, k2, k3, k4, xm, xn = (buf() for _ in range(7))
+        f32 = lambda v: float(torch.tensor(v, dtype=torch.float32))       # the fp32 value upstream adds to the fp32 t
+        R = L.PROC_REVERSE
+
+        def score(xx, k):
+            return sde.a(xx, self.s[k]).contiguous()
 
         def body():
-            ops.time_tick(self.ts, self.step, T, self.t_dev, self.s)
-            a = sde.a(self.x, self.s).contiguous()
-            out = self.x if inplace else self.other
-            ops.sde_stage(out, self.x, 1.0, self.x, a, st, L.PROC_REVERSE, False, 0.0, delta, lmbd, rng=self.rng,
-                          norm0=self.norm0, t_dev=self.t_dev, step_dev=self.step)
-            if not inplace:
-                self.x.copy_(out)
+            x = self.x
+            ops.time_tick(self.ts, self.step, T, self.t_dev[0], self.s[0])
+            if method == "em":
+                out = x if inplace else other
+                ops.sde_stage(out, x, 1.0, x, score(x, 0), st, R, False, 0.0, delta, lmbd, rng=self.rng, norm0=self.norm0,
+                              t_dev=self.t_dev[0], step_dev=self.step)
+                if not inplace:
+                    ops.lincomb(x, out, 1.0)
+            elif method == "heun":                                        # sde_scheme.py:101-172
+                ops.time_tick(self.ts, self.step, T, self.t_dev[1], self.s[1], t_add=f32(delta))
+                ops.sde_stage(xp, x, 1.0, x, score(x, 0), st, R, True, 0.0, delta, lmbd, rng=self.rng, dW_out=dW, inc_out=k1,
+                              t_dev=self.t_dev[0], step_dev=self.step)
+                ops.lincomb(xn, x, 1.0, k1, 0.5)
+                ops.sde_stage(xn, xn, 0.5, xp, score(xp, 1), st, R, True, 0.0, delta, lmbd, dW=dW, norm0=self.norm0,
+                              t_dev=self.t_dev[1])
+                ops.lincomb(x, xn, 1.0)
+            else:                                                         # sde_scheme.py:174-269
+                ops.time_tick(self.ts, self.step, T, self.t_dev[1], self.s[1], t_add=f32(delta / 2))
+                ops.time_tick(self.ts, self.step, T, self.t_dev[2], self.s[2], t_add=f32(delta))
+                ops.sde_stage(xm, x, 0.5, x, score(x, 0), st, R, True, 0.0, delta, lmbd, rng=self.rng, dW_out=dW, inc_out=k1,
+                              t_dev=self.t_dev[0], step_dev=self.step)
+                ops.sde_stage(xn, x, 0.5, xm, score(xm, 1), st, R, True, 0.0, delta, lmbd, dW=dW, inc_out=k2, t_dev=self.t_dev[1])
+                ops.sde_stage(xm, x, 1.0, xn, score(xn, 1), st, R, True, 0.0, delta, lmbd, dW=dW, inc_out=k3, t_dev=self.t_dev[1])
+                ops.sde_stage(k4, None, 1.0, xm, score(xm, 2), st, R, True, 0.0, delta, lmbd, dW=dW, t_dev=self.t_dev[2])
+                ops.rk4_combine(xn, x, k1, k2, k3, k4, norm0=self.norm0)
+                ops.lincomb(x, xn, 1.0)
             ops.counter_inc(self.step)
 
+        self._body = body
+        self.graph = None
+        if os.environ.get("MSGM_NO_GRAPH_SAMPLER"):          # diagnostic: the same step enqueued eagerly every time
+            return
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
@@ -330,11 +370,14 @@ class GraphedStepSampler:
 
     @torch.no_grad()
     def run(self, x_0):
-        self.x.copy_(x_0)
+        ops.lincomb(self.x, x_0.contiguous().float().view(self.B, self.n), 1.0)
         if self.norm0 is not None:
-            self.norm0.copy_(ops.row_norm(self.x))
+            ops.lincomb(self.norm0, ops.row_norm(self.x), 1.0)
         self.step.zero_()
         for _ in range(self.N):
-            self.graph.replay()
+            if self.graph is None:
+                self._body()
+            else:
+                self.graph.replay()
         self.rng.advance(self.N)
         return self.x

@@ -66,3 +66,82 @@ def test_two_rank_training_keeps_ranks_identical(kind):
     assert all(abs(a - b) <= 1e-6 * max(1.0, abs(a)) for a, b in zip(l0, l1)), (l0, l1)     # the all-reduced global mean
     assert f0 == f1 and len(f0) > 0                                                          # bitwise identical replicas
     assert m0 > 1e-5 and all(map(lambda v: v == v, l0))
+
+
+def _shard_worker(rank, world, port, q):
+    """Rank r of a 2-rank run with shard placement (same seed everywhere + first global row of the shard): the ranks
+    must draw / compute exactly what a single-rank run does for the same global rows."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), MSGM_DIST_BACKEND="gloo")
+    import torch.distributed as dist
+    from sdeflow_light_amd import parallel, sde_scheme as SS
+    from sdeflow_light_amd.NN import MLP
+    from sdeflow_light_amd.SDEs import SGMsde, PluginReverseSDE
+    from sdeflow_light_amd.train import MLPScoreTrainer
+    r, local, w = parallel.init_distributed()
+    dev = parallel.local_device(local)
+    torch.cuda.set_device(dev)
+    torch.manual_seed(0)
+    T = torch.nn.Parameter(torch.FloatTensor([1.0]), requires_grad=False)
+    gen = PluginReverseSDE(SGMsde(T=T, num_steps_forward=16, device=dev), MLP(2).to(dev), T, deviceReverseSDE=dev).to(dev)
+    rows, d, N = 256, 2, 6
+    b, e = parallel.shard_rows(rows, r, w)
+    gen.base_sde.set_shard(b, d)
+    x0 = gen.latent_sample(e - b, d)                                      # this rank's rows of the global latent draw
+    xs = SS.euler_maruyama_sampler(gen, x0, num_steps=N, keep_all_samples=False).to(dev)      # Philox dW, sharded
+    full = parallel.gather_rows(xs, rows)
+    # training with shard placement: same seed, row_base = first global row
+    torch.manual_seed(5)
+    data = torch.randn(rows, d, device=dev)
+    tr = MLPScoreTrainer(gen, e - b, lr=1e-3, world=w, seed=9, row_base=b, use_graph=False)
+    tr.set_data(data[b:e])
+    losses = [float(tr.step()) for _ in range(3)]
+    flat, _ = gen.a.flat_parameters()
+    q.put((r, full.cpu().numpy().tobytes(), losses, flat.detach().cpu().numpy().tobytes()))
+    parallel.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_sharded_run_draws_and_computes_what_the_single_gpu_run_does():
+    """the base SDE's Philox stream had no rank / row term, so every rank of a sharded sampler drew
+    the same latent and dW.  With ``set_shard`` / ``row_base`` the 2-rank run must EQUAL the 1-rank run row for row
+    (sampler: bit for bit; trainer: to the re-association of the gradient sum across ranks)."""
+    import numpy as np
+    from sdeflow_light_amd import sde_scheme as SS
+    from sdeflow_light_amd.NN import MLP
+    from sdeflow_light_amd.SDEs import SGMsde, PluginReverseSDE
+    from sdeflow_light_amd.train import MLPScoreTrainer
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_shard_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted([q.get(timeout=500) for _ in range(world)], key=lambda t: t[0])
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    dev = "cuda"
+    torch.manual_seed(0)
+    T = torch.nn.Parameter(torch.FloatTensor([1.0]), requires_grad=False)
+    gen = PluginReverseSDE(SGMsde(T=T, num_steps_forward=16, device=dev), MLP(2).to(dev), T, deviceReverseSDE=dev).to(dev)
+    rows, d, N = 256, 2, 6
+    x0 = gen.latent_sample(rows, d)
+    ref = SS.euler_maruyama_sampler(gen, x0, num_steps=N, keep_all_samples=False)
+    for r, full, _, _ in res:
+        got = torch.from_numpy(np.frombuffer(full, dtype=np.float32).reshape(rows, d).copy())
+        assert torch.equal(got, ref), float((got - ref).abs().max())
+    assert not torch.equal(ref[: rows // 2], ref[rows // 2:])                 # the two shards are different draws
+    torch.manual_seed(5)
+    data = torch.randn(rows, d, device=dev)
+    tr = MLPScoreTrainer(gen, rows, lr=1e-3, world=1, seed=9, use_graph=False)
+    tr.set_data(data)
+    losses = [float(tr.step()) for _ in range(3)]
+    flat = gen.a.flat_parameters()[0].detach().cpu()
+    for r, _, l2, f2 in res:
+        got = torch.from_numpy(np.frombuffer(f2, dtype=np.float32).copy())
+        e = float((got - flat).norm() / flat.norm())
+        print(f"rank {r}: 2-rank vs 1-rank parameters after 3 steps rel-L2 {e:.2e}; losses {l2} vs {losses}")
+        assert e <= 1e-6
+        assert all(abs(a - b) <= 1e-5 * max(1.0, abs(b)) for a, b in zip(l2, losses))

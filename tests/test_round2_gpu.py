@@ -228,3 +228,43 @@ def test_resume_continues_the_philox_noise_stream(how, tmp_path):
     load_checkpoint(path, gen3, opt3, DEV)
     run(gen3, opt3, 2)
     assert rel_l2(gen3.a.flat_parameters()[0].cpu(), final.cpu()) > 10 * max(e, 1e-7)
+
+
+# ------------------------------------------------------------------------------------------ graph-captured Heun / RK4 step
+@pytest.mark.parametrize("method", ["em", "heun", "rk4"])
+@pytest.mark.parametrize("base_kind", ["sgm", "sparse"])
+def test_graphed_step_sampler_equals_eager_integrator(method, base_kind):
+    """One hipGraph-captured step with device-side stage clocks (t, t + delta/2, t + delta), replayed N times, must give
+    what the eager integrator gives from the same Philox state (the eager integrators are pinned against the reference's
+    trajectories above and in test_host_gpu.py).  RK4 is what the driver generates with (MSGM_higherDim.py:903)."""
+    from sdeflow_light_amd import sde_scheme as SS
+    torch.manual_seed(0)
+    if base_kind == "sgm":
+        gen, n = make_gen("sgm", _vunet(16, "F")), 256
+    else:                                                  # multiplicative SDE, sparse tensor, norm correction
+        from sdeflow_light_amd.NNUnet1D import UNet1D
+        from oracle.det_params import load_det_
+        net = UNet1D(input_dim=64, premodule="NormalizeLogRadius")
+        load_det_(net)
+        gen, n = make_gen("sparse", net, n=64, nsf=4), 64
+    nc = base_kind != "sgm"
+    B, N = 6, 5
+    x0 = torch.randn(B, n, device=DEV)
+    gs = SS.GraphedStepSampler(gen, B, n, N, method=method, norm_correction=nc)
+    st = gen.base_sde.rng.state.clone()
+    a = gs.run(x0).clone()
+    gen.base_sde.rng.state.copy_(st)
+    fn = {"em": SS.euler_maruyama_sampler, "heun": SS.heun_sampler, "rk4": SS.rk4_stratonovich_sampler}[method]
+    b = fn(gen, x0, num_steps=N, keep_all_samples=False, norm_correction=nc)
+    e = rel_l2(a.cpu(), b)
+    print(f"graphed {method} ({base_kind}) vs eager integrator after {N} steps: rel-L2 {e:.2e}")
+    if e > 2e-6:                                           # diagnosis: which of the two is not reproducible?
+        gen.base_sde.rng.state.copy_(st)
+        a2 = gs.run(x0).clone()
+        gen.base_sde.rng.state.copy_(st)
+        b2 = fn(gen, x0, num_steps=N, keep_all_samples=False, norm_correction=nc)
+        print(f"  rerun: graph vs graph {rel_l2(a2.cpu(), a.cpu()):.2e}, eager vs eager {rel_l2(b2, b):.2e}, "
+              f"graph2 vs eager2 {rel_l2(a2.cpu(), b2):.2e}")
+    assert e <= 2e-6
+    c = gs.run(x0).clone()                                 # the stream advanced: a second run is a fresh sample
+    assert not torch.equal(a, c) and torch.isfinite(c).all()
