@@ -329,6 +329,16 @@ int msgm_conv_forward_fused(const msgm_conv_geom_t* geom, const float* src0, int
 int msgm_conv_wgrad(const msgm_conv_geom_t* geom, const float* gy, const float* src, int32_t C, int32_t koff,
                     float* dWp, int32_t Cout, int32_t CoutP, int32_t Ktot, float* dbias, int32_t n_bias,
                     const uint16_t* tapmask_c32, const uint16_t* tapmask_co32, msgm_stream_t stream);
+/* The same gradients WITHOUT float atomics (bitwise reproducible from run to run): every workgroup column stores its
+ * partial [taps][CoutP][C] block (+ bias partials) into its own slab of the workspace and a second kernel adds the
+ * slabs in slot order; `dWp` / `dbias` are accumulated into exactly as above.  Workspace bytes from
+ * msgm_conv_wgrad_workspace (n_bias = 0 when dbias is NULL); ~37 MB per call at the C4 shapes, i.e. ~20 us of HBM
+ * time — the trainers use this entry by default. */
+size_t msgm_conv_wgrad_workspace(const msgm_conv_geom_t* geom, int32_t C, int32_t Cout, int32_t CoutP, int32_t n_bias);
+int msgm_conv_wgrad_det(const msgm_conv_geom_t* geom, const float* gy, const float* src, int32_t C, int32_t koff,
+                        float* dWp, int32_t Cout, int32_t CoutP, int32_t Ktot, float* dbias, int32_t n_bias,
+                        const uint16_t* tapmask_c32, const uint16_t* tapmask_co32, void* workspace, size_t workspace_bytes,
+                        msgm_stream_t stream);
 
 /* Wp[t][r][kp_off + c] = W[r*sr + (col_off + c)*sc + t*st] for r < rows, c < ncols
  * (strides in elements: any of the PyTorch layouts (Cout,Cin,k), (Cin,Cout,k) and
@@ -360,6 +370,10 @@ int msgm_act_dual_backward(int32_t act, const float* z, float* g, int64_t half, 
 
 /* S[n][c] = sum_pos x[n][pos][c]; out[n][c] = x[n][pos][c]; x[n][pos][c] += sgn*E[n][c]. */
 int msgm_colsum(const float* x, float* S, int32_t N, int32_t P, int32_t C, msgm_stream_t stream);
+/* msgm_colsum without float atomics: per-chunk partials in the workspace, added in chunk order. */
+size_t msgm_colsum_workspace(int32_t N, int32_t P, int32_t C);
+int msgm_colsum_det(const float* x, float* S, int32_t N, int32_t P, int32_t C, void* workspace, size_t workspace_bytes,
+                    msgm_stream_t stream);
 int msgm_gather_row(const float* x, float* out, int32_t N, int32_t P, int32_t C, int32_t pos, msgm_stream_t stream);
 int msgm_add_row(float* x, const float* E, int32_t N, int32_t P, int32_t C, int32_t pos, float sgn, msgm_stream_t stream);
 

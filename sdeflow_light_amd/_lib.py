@@ -84,6 +84,11 @@ SIGNATURES = {
     "msgm_groupnorm_affine": (C.c_int, [_P, _I32, _P, _I32, _P, _P, _P, _P, _I32, _I32, _I32, _F, _P, C.c_size_t, _P]),
     "msgm_conv_wgrad": (C.c_int, [C.POINTER(ConvGeomT), _P, _P, _I32, _I32, _P, _I32, _I32, _I32, _P, _I32,
                                   C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), _P]),
+    "msgm_conv_wgrad_workspace": (_SZ, [C.POINTER(ConvGeomT), _I32, _I32, _I32, _I32]),
+    "msgm_conv_wgrad_det": (C.c_int, [C.POINTER(ConvGeomT), _P, _P, _I32, _I32, _P, _I32, _I32, _I32, _P, _I32,
+                                      C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), _P, _SZ, _P]),
+    "msgm_colsum_workspace": (_SZ, [_I32, _I32, _I32]),
+    "msgm_colsum_det": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _SZ, _P]),
     "msgm_pack_weight": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I32, _I32, _I32, _P]),
     "msgm_unpack_weight": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I32, _I32, _I32, _I32, _P]),
     "msgm_act_dual_forward": (C.c_int, [_I32, _P, _P, _I64, _I32, _P]),

@@ -546,6 +546,10 @@ struct WgradArgs {
   int n_bias;
   // structurally-zero weight blocks (tile kernel): bit t = tap t present, 0 = all; per 32-channel block of c / of co
   unsigned short tm_c[16], tm_o[16];
+  // deterministic mode (msgm_conv_wgrad_det): instead of float atomics into dWp / dbias every workgroup column
+  // blockIdx.x STORES its partial block into its own slab [taps][CoutP][C] (+ [CoutP] bias partials) and
+  // k_wgrad_slab_reduce adds the slabs in slot order.  slab == nullptr: atomics.
+  float* slab; long slab_stride;
 };
 
 // One workgroup = one (position chunk, tap, co block of 16*MT, c block of 16*KT).
@@ -624,7 +628,10 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(WgradArgs A) {
           const int idx = ((mt * KT + kt) * 4 + r) * 64 + lane;
           const float s = (red[0][idx] + red[1][idx]) + (red[2][idx] + red[3][idx]);
           const int co = co0 + 16 * mt + 4 * q + r, c = c0 + 16 * kt + il;
-          if (co < A.Cout && c < A.C) atomicAdd(A.dWp + ((size_t)(tap * A.CoutP + co) * A.Ktot + A.koff + c), s);
+          if (co < A.Cout && c < A.C) {
+            if (A.slab) A.slab[(size_t)blockIdx.x * A.slab_stride + (size_t)(tap * A.CoutP + co) * A.C + c] = s;
+            else atomicAdd(A.dWp + ((size_t)(tap * A.CoutP + co) * A.Ktot + A.koff + c), s);
+          }
         }
   }
 }
@@ -789,14 +796,19 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_tile(WgradArgs A, int tiles_x,
     bsum += __shfl_xor(bsum, 2, 64);
     bsum += __shfl_xor(bsum, 4, 64);
     const int co = co0 + (tid >> 3);
-    if ((tid & 7) == 0 && co < A.Cout) atomicAdd(A.dbias + co, bsum);
+    if ((tid & 7) == 0 && co < A.Cout) {
+      if (A.slab) A.slab[(size_t)blockIdx.x * A.slab_stride + (size_t)TAPS * A.CoutP * A.C + co] = bsum;
+      else atomicAdd(A.dbias + co, bsum);
+    }
   }
   // cross-wave reduction through LDS (reuse the staging area), then atomics
   float* red = wt_lds;
   __syncthreads();
 #pragma unroll
   for (int t = 0; t < TAPS; ++t) {
-    if (!((tmask >> t) & 1u)) continue;                     // workgroup-uniform: the barriers below stay matched
+    // workgroup-uniform: the barriers below stay matched.  With slabs a skipped block still stores its zeros (the
+    // slab reduction reads every slot of every element)
+    if (!((tmask >> t) & 1u) && !A.slab) continue;
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -814,7 +826,10 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_tile(WgradArgs A, int tiles_x,
             const int idx = ((m * 2 + kt) * 4 + r) * 64 + lane;
             const float sum = (red[idx] + red[1024 + idx]) + (red[2048 + idx] + red[3072 + idx]);
             const int co = co0 + 16 * m + 4 * q + r, c = c0 + 16 * kt + il;
-            if (co < A.Cout && c < A.C) atomicAdd(A.dWp + ((size_t)(t * A.CoutP + co) * A.Ktot + A.koff + c), sum);
+            if (co < A.Cout && c < A.C) {
+              if (A.slab) A.slab[(size_t)blockIdx.x * A.slab_stride + (size_t)(t * A.CoutP + co) * A.C + c] = sum;
+              else atomicAdd(A.dWp + ((size_t)(t * A.CoutP + co) * A.Ktot + A.koff + c), sum);
+            }
           }
     }
     __syncthreads();
@@ -907,6 +922,32 @@ __global__ void k_act_dual_bwd(const float* __restrict__ z, float* __restrict__ 
 // S[n][c] (+)= sum over positions of x[n][pos][c]  (bias / embedding gradients).  Grid (n, position
 // chunk): threads along channels, LDS across pixel lanes, one float atomic per (n, c) per block into a
 // zeroed S (a per-sample workgroup would leave the chip idle at small batch).
+// 32 elements x 8 slot slices per workgroup: every slice adds its slots in order, the slices are added in order.
+// out[map(e)] (+)= sum_slot part[slot * stride + e] — the deterministic replacement of float atomics (no run-to-run
+// difference in the weight / bias gradients).  map: wgrad image element e = (tap*CoutP + co)*C + c ->
+// dWp[(tap*CoutP + co)*Ktot + koff + c] when Ktot > 0, identity otherwise.
+__global__ void __launch_bounds__(256) k_slot_reduce(const float* __restrict__ part, int nslots, long stride, long n_elem,
+                                                      float* __restrict__ out, int C, int Ktot, int koff, int accumulate,
+                                                      int rowsP, int rows) {
+  __shared__ float red[8][32];
+  const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const long e = (long)blockIdx.x * 32 + el;
+  // padding rows (co >= Cout of a [taps][CoutP][C] image) are never written by the producers
+  const bool ok = e < n_elem && (rowsP == 0 || (int)((e / C) % rowsP) < rows);
+  float t = 0.f;
+  if (ok)
+    for (int s = sl; s < nslots; s += 8) t += part[(size_t)s * stride + e];
+  red[sl][el] = t;
+  __syncthreads();
+  if (sl == 0 && ok) {
+    float r = red[0][el];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) r += red[k][el];
+    const long o = Ktot > 0 ? (e / C) * Ktot + koff + (e % C) : e;
+    out[o] = accumulate ? out[o] + r : r;
+  }
+}
+
 __global__ void __launch_bounds__(256) k_colsum(const float* __restrict__ x, float* __restrict__ S, int P, int C, int chunk, int acc) {
   __shared__ float red[256];
   const int n = blockIdx.x;
@@ -924,7 +965,8 @@ __global__ void __launch_bounds__(256) k_colsum(const float* __restrict__ x, flo
     if (pr == 0) {
       float t = 0.f;
       for (int r = 0; r < rows; ++r) t += red[r * lanes_c + c];
-      if (gridDim.y == 1 && !acc) S[(size_t)n * C + cb + c] = t;
+      if (acc == 2) S[((size_t)blockIdx.y * gridDim.x + n) * C + cb + c] = t;     // slot mode: S = [chunk][n][C] partials
+      else if (gridDim.y == 1 && !acc) S[(size_t)n * C + cb + c] = t;
       else atomicAdd(S + (size_t)n * C + cb + c, t);
     }
     __syncthreads();
@@ -1075,36 +1117,111 @@ int msgm_conv_forward_fused(const msgm_conv_geom_t* geom, const float* src0, int
   return msgm_check_launch();
 }
 
-int msgm_conv_wgrad(const msgm_conv_geom_t* geom, const float* gy, const float* src, int32_t C, int32_t koff,
-                    float* dWp, int32_t Cout, int32_t CoutP, int32_t Ktot, float* dbias, int32_t n_bias,
-                    const uint16_t* tapmask_c32, const uint16_t* tapmask_co32, msgm_stream_t stream) {
-  int rc = check_geom(geom);
-  if (rc) return rc;
-  if (!gy || !src || !dWp || C <= 0 || Cout <= 0 || koff < 0 || koff + C > Ktot || (dbias && n_bias <= 0)) return MSGM_E_BADARG;
-  WgradArgs A{to_geom(geom), gy, src, C, koff, dWp, Cout, CoutP, Ktot, 0, dbias, n_bias, {0}, {0}};
-  for (int i = 0; i < 16; ++i) {
-    A.tm_c[i] = (tapmask_c32 && i < (C + 31) / 32) ? tapmask_c32[i] : 0;
-    A.tm_o[i] = (tapmask_co32 && i < (Cout + 31) / 32) ? tapmask_co32[i] : 0;
-  }
+// launch geometry shared by the launcher and the workspace query
+struct WgradPlan { bool tile; int wgs, per, tiles_x, tiles_y, n_tiles, yblocks; int64_t nchunks, chunk; int64_t bias_slots, bias_chunk; };
+static WgradPlan wgrad_plan(const msgm_conv_geom_t* geom, int C, int Cout, int n_bias) {
+  WgradPlan p{};
   const int64_t Mtot = (int64_t)geom->N * geom->Ho * geom->Wo;
   const int taps = geom->KH * geom->KW;
   const int ups_sh = geom->ups ? 1 : 0;
   const bool same = geom->mode == 0 && geom->strideH == 1 && geom->strideW == 1 && (geom->Hi << ups_sh) == geom->Ho &&
                     (geom->Wi << ups_sh) == geom->Wo && (geom->KH & 1) && (geom->KW & 1) && geom->padH == (geom->KH - 1) / 2 &&
                     geom->padW == (geom->KW - 1) / 2 && geom->KH <= 3 && geom->KW <= 3;
-  if (same && C % 4 == 0 && Cout % 4 == 0 && (int64_t)geom->Ho * geom->Wo >= 64 && (taps == 1 || taps == 3 || (taps == 9 && geom->Ho > 1)) &&
-      (geom->Ho > 1 || geom->KH == 1) && !getenv("MSGM_NO_WGRAD_TILE")) {
+  p.tile = same && C % 4 == 0 && Cout % 4 == 0 && (int64_t)geom->Ho * geom->Wo >= 64 &&
+           (taps == 1 || taps == 3 || (taps == 9 && geom->Ho > 1)) && (geom->Ho > 1 || geom->KH == 1) && !getenv("MSGM_NO_WGRAD_TILE");
+  if (p.tile) {
     const bool two_d = geom->Ho > 1;
     const int TH = two_d ? 8 : 1, TW = two_d ? 16 : 128;
-    const int tiles_x = (geom->Wo + TW - 1) / TW, tiles_y = (geom->Ho + TH - 1) / TH;
-    const int n_tiles = tiles_x * tiles_y * geom->N;
-    const int yblocks = ((Cout + 31) / 32) * ((C + 31) / 32);
-    int wgs = 1024 / yblocks;                              // ~4 workgroups per CU overall
+    p.tiles_x = (geom->Wo + TW - 1) / TW; p.tiles_y = (geom->Ho + TH - 1) / TH;
+    p.n_tiles = p.tiles_x * p.tiles_y * geom->N;
+    p.yblocks = ((Cout + 31) / 32) * ((C + 31) / 32);
+    int wgs = 1024 / p.yblocks;                            // ~4 workgroups per CU overall
     if (wgs < 1) wgs = 1;
-    int per = (n_tiles + wgs - 1) / wgs;
+    int per = (p.n_tiles + wgs - 1) / wgs;
     static const int min_per = getenv("MSGM_WGRAD_PER") ? atoi(getenv("MSGM_WGRAD_PER")) : 8;   // >= 8 tiles per workgroup amortise the cross-wave sum + atomics
-    if (per < min_per) per = n_tiles < min_per ? n_tiles : min_per;
-    wgs = (n_tiles + per - 1) / per;
+    if (per < min_per) per = p.n_tiles < min_per ? p.n_tiles : min_per;
+    p.per = per;
+    p.wgs = (p.n_tiles + per - 1) / per;
+    return p;
+  }
+  const int coblocks = (Cout + 31) / 32, cblocks = (C + 63) / 64;
+  // aim at ~2048 workgroups overall, at least 256 positions each
+  int64_t nchunks = 2048 / (int64_t)(coblocks * cblocks * taps);
+  if (nchunks < 1) nchunks = 1;
+  int64_t chunk = (Mtot + nchunks - 1) / nchunks;
+  if (chunk < 256) chunk = 256;
+  chunk = ((chunk + 15) / 16) * 16;
+  p.nchunks = (Mtot + chunk - 1) / chunk;
+  p.chunk = chunk;
+  p.yblocks = coblocks * cblocks;
+  if (n_bias > 0) {
+    const int64_t Pb = (int64_t)n_bias * geom->Ho * geom->Wo;
+    int64_t cch = (Pb + 1023) / 1024;
+    if (cch < 64) cch = 64;
+    if (cch > Pb) cch = Pb;
+    p.bias_chunk = cch;
+    p.bias_slots = (Pb + cch - 1) / cch;
+  }
+  return p;
+}
+
+static int wgrad_impl(const msgm_conv_geom_t* geom, const float* gy, const float* src, int32_t C, int32_t koff,
+                      float* dWp, int32_t Cout, int32_t CoutP, int32_t Ktot, float* dbias, int32_t n_bias,
+                      const uint16_t* tapmask_c32, const uint16_t* tapmask_co32, float* ws, size_t ws_bytes, bool det,
+                      msgm_stream_t stream);
+
+size_t msgm_conv_wgrad_workspace(const msgm_conv_geom_t* geom, int32_t C, int32_t Cout, int32_t CoutP, int32_t n_bias) {
+  if (check_geom(geom) || C <= 0 || Cout <= 0 || CoutP < Cout) return 0;
+  const WgradPlan p = wgrad_plan(geom, C, Cout, n_bias);
+  const size_t stride = (size_t)geom->KH * geom->KW * CoutP * C + CoutP;
+  const size_t slots = p.tile ? (size_t)p.wgs : (size_t)p.nchunks;
+  return (slots * stride + (size_t)p.bias_slots * Cout) * sizeof(float);
+}
+
+int msgm_conv_wgrad(const msgm_conv_geom_t* geom, const float* gy, const float* src, int32_t C, int32_t koff,
+                    float* dWp, int32_t Cout, int32_t CoutP, int32_t Ktot, float* dbias, int32_t n_bias,
+                    const uint16_t* tapmask_c32, const uint16_t* tapmask_co32, msgm_stream_t stream) {
+  return wgrad_impl(geom, gy, src, C, koff, dWp, Cout, CoutP, Ktot, dbias, n_bias, tapmask_c32, tapmask_co32, nullptr, 0, false,
+                    stream);
+}
+
+int msgm_conv_wgrad_det(const msgm_conv_geom_t* geom, const float* gy, const float* src, int32_t C, int32_t koff,
+                        float* dWp, int32_t Cout, int32_t CoutP, int32_t Ktot, float* dbias, int32_t n_bias,
+                        const uint16_t* tapmask_c32, const uint16_t* tapmask_co32, void* workspace, size_t workspace_bytes,
+                        msgm_stream_t stream) {
+  if (!workspace) return MSGM_E_BADARG;
+  return wgrad_impl(geom, gy, src, C, koff, dWp, Cout, CoutP, Ktot, dbias, n_bias, tapmask_c32, tapmask_co32,
+                    static_cast<float*>(workspace), workspace_bytes, true, stream);
+}
+
+static int wgrad_impl(const msgm_conv_geom_t* geom, const float* gy, const float* src, int32_t C, int32_t koff,
+                      float* dWp, int32_t Cout, int32_t CoutP, int32_t Ktot, float* dbias, int32_t n_bias,
+                      const uint16_t* tapmask_c32, const uint16_t* tapmask_co32, float* ws, size_t ws_bytes, bool det,
+                      msgm_stream_t stream) {
+  int rc = check_geom(geom);
+  if (rc) return rc;
+  if (!gy || !src || !dWp || C <= 0 || Cout <= 0 || koff < 0 || koff + C > Ktot || (dbias && n_bias <= 0)) return MSGM_E_BADARG;
+  if (det && ws_bytes < msgm_conv_wgrad_workspace(geom, C, Cout, CoutP, dbias ? n_bias : 0)) return MSGM_E_WORKSPACE;
+  WgradArgs A{to_geom(geom), gy, src, C, koff, dWp, Cout, CoutP, Ktot, 0, dbias, n_bias, {0}, {0}, nullptr, 0};
+  const WgradPlan pl = wgrad_plan(geom, C, Cout, dbias ? n_bias : 0);
+  const long img = (long)geom->KH * geom->KW * CoutP * C;
+  if (det) { A.slab = ws; A.slab_stride = img + CoutP; }
+  for (int i = 0; i < 16; ++i) {
+    A.tm_c[i] = (tapmask_c32 && i < (C + 31) / 32) ? tapmask_c32[i] : 0;
+    A.tm_o[i] = (tapmask_co32 && i < (Cout + 31) / 32) ? tapmask_co32[i] : 0;
+  }
+  const int taps = geom->KH * geom->KW;
+  auto reduce_slabs = [&](int nslots, bool with_bias) {     // deterministic mode: slabs -> dWp (+ dbias), slot order
+    hipLaunchKernelGGL(k_slot_reduce, dim3((unsigned)((img + 31) / 32)), dim3(256), 0, S(stream), (const float*)ws, nslots,
+                       A.slab_stride, img, dWp, C, Ktot, koff, 1, CoutP, Cout);
+    if (with_bias)
+      hipLaunchKernelGGL(k_slot_reduce, dim3((unsigned)((Cout + 31) / 32)), dim3(256), 0, S(stream), (const float*)ws + img, nslots,
+                         A.slab_stride, (long)Cout, dbias, 1, 0, 0, 1, 0, 0);
+  };
+  if (pl.tile) {
+    const bool two_d = geom->Ho > 1;
+    const int TH = two_d ? 8 : 1, TW = two_d ? 16 : 128;
+    const int tiles_x = pl.tiles_x, tiles_y = pl.tiles_y, n_tiles = pl.n_tiles, yblocks = pl.yblocks, per = pl.per, wgs = pl.wgs;
     const int halo = (TH + geom->KH - 1) * (TW + geom->KW - 1);
     const int IP = ((halo + 2) & ~7) + 5;
     size_t lds = (size_t)(WT_DBUF(taps) ? 2 : 1) * (32 * WT_GP + 32 * IP) * sizeof(float);
@@ -1124,25 +1241,24 @@ int msgm_conv_wgrad(const msgm_conv_geom_t* geom, const float* gy, const float* 
     if (two_d) { if (taps == 9) WT_LAUNCH(8, 16, 9); else if (taps == 3) WT_LAUNCH(8, 16, 3); else WT_LAUNCH(8, 16, 1); }
     else { if (taps == 3) WT_LAUNCH(1, 128, 3); else WT_LAUNCH(1, 128, 1); }
 #undef WT_LAUNCH
+    if (det) reduce_slabs(wgs, dbias != nullptr);
     return msgm_check_launch();
   }
-  const int coblocks = (Cout + 31) / 32, cblocks = (C + 63) / 64;
-  // aim at ~2048 workgroups overall, at least 256 positions each
-  int64_t nchunks = 2048 / (int64_t)(coblocks * cblocks * taps);
-  if (nchunks < 1) nchunks = 1;
-  int64_t chunk = (Mtot + nchunks - 1) / nchunks;
-  if (chunk < 256) chunk = 256;
-  chunk = ((chunk + 15) / 16) * 16;
-  nchunks = (Mtot + chunk - 1) / chunk;
-  A.chunk = (int)chunk;
-  dim3 grid((unsigned)nchunks, (unsigned)(coblocks * cblocks), (unsigned)taps);
+  const int64_t nchunks = pl.nchunks;
+  A.chunk = (int)pl.chunk;
+  dim3 grid((unsigned)nchunks, (unsigned)pl.yblocks, (unsigned)taps);
   hipLaunchKernelGGL((k_conv_wgrad<2, 4>), grid, dim3(256), 0, S(stream), A);
+  if (det) reduce_slabs((int)nchunks, false);
   if (dbias) {                                             // no by-product in this kernel: a separate accumulating column sum
     const int64_t Pb = (int64_t)n_bias * geom->Ho * geom->Wo;
-    int64_t cch = (Pb + 1023) / 1024;
-    if (cch < 64) cch = 64;
-    if (cch > Pb) cch = Pb;
-    hipLaunchKernelGGL(k_colsum, dim3(1, (unsigned)((Pb + cch - 1) / cch)), dim3(256), 0, S(stream), gy, dbias, (int)Pb, Cout, (int)cch, 1);
+    if (det) {
+      float* part = ws + (size_t)nchunks * A.slab_stride;   // [bias_slots][Cout] partials, then slot-ordered sum
+      hipLaunchKernelGGL(k_colsum, dim3(1, (unsigned)pl.bias_slots), dim3(256), 0, S(stream), gy, part, (int)Pb, Cout, (int)pl.bias_chunk, 2);
+      hipLaunchKernelGGL(k_slot_reduce, dim3((unsigned)((Cout + 31) / 32)), dim3(256), 0, S(stream), (const float*)part,
+                         (int)pl.bias_slots, (long)Cout, (long)Cout, dbias, 1, 0, 0, 1, 0, 0);
+    } else {
+      hipLaunchKernelGGL(k_colsum, dim3(1, (unsigned)pl.bias_slots), dim3(256), 0, S(stream), gy, dbias, (int)Pb, Cout, (int)pl.bias_chunk, 1);
+    }
   }
   return msgm_check_launch();
 }
@@ -1212,6 +1328,38 @@ int msgm_colsum(const float* x, float* Sout, int32_t N, int32_t P, int32_t C, ms
   nch = (P + chunk - 1) / chunk;
   if (nch > 1 && msgm_zero_async(Sout, (size_t)N * C * sizeof(float), S(stream)) != MSGM_OK) return MSGM_E_LAUNCH;
   hipLaunchKernelGGL(k_colsum, dim3(N, nch), dim3(256), 0, S(stream), x, Sout, P, C, chunk, 0);
+  return msgm_check_launch();
+}
+
+size_t msgm_colsum_workspace(int32_t N, int32_t P, int32_t C) {
+  if (N <= 0 || P <= 0 || C <= 0) return 0;
+  int nch = (1024 + N - 1) / N;
+  int chunk = (P + nch - 1) / nch;
+  if (chunk < 64) chunk = 64;
+  if (chunk > P) chunk = P;
+  nch = (P + chunk - 1) / chunk;
+  return nch > 1 ? (size_t)nch * N * C * sizeof(float) : 0;
+}
+
+// the same sums without float atomics: per-chunk partials [chunk][N][C] in the workspace, added in chunk order
+int msgm_colsum_det(const float* x, float* Sout, int32_t N, int32_t P, int32_t C, void* workspace, size_t workspace_bytes,
+                    msgm_stream_t stream) {
+  if (!x || !Sout || N <= 0 || P <= 0 || C <= 0) return MSGM_E_BADARG;
+  int nch = (1024 + N - 1) / N;
+  int chunk = (P + nch - 1) / nch;
+  if (chunk < 64) chunk = 64;
+  if (chunk > P) chunk = P;
+  nch = (P + chunk - 1) / chunk;
+  if (nch == 1) {
+    hipLaunchKernelGGL(k_colsum, dim3(N, 1), dim3(256), 0, S(stream), x, Sout, P, C, chunk, 0);
+    return msgm_check_launch();
+  }
+  if (!workspace || workspace_bytes < msgm_colsum_workspace(N, P, C)) return MSGM_E_WORKSPACE;
+  float* part = static_cast<float*>(workspace);
+  hipLaunchKernelGGL(k_colsum, dim3(N, nch), dim3(256), 0, S(stream), x, part, P, C, chunk, 2);
+  const long n_elem = (long)N * C;
+  hipLaunchKernelGGL(k_slot_reduce, dim3((unsigned)((n_elem + 31) / 32)), dim3(256), 0, S(stream), (const float*)part, nch, n_elem,
+                     n_elem, Sout, 1, 0, 0, 0, 0, 0);
   return msgm_check_launch();
 }
 

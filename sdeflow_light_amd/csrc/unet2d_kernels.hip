@@ -25,12 +25,16 @@ __device__ __forceinline__ void silu012u(float z, float& s0, float& s1, float& s
 // Two fully parallel launches per direction (a per-sample workgroup would leave the
 // chip idle at 32 samples/GPU):
 //   1. k_gn_*_reduce: grid (sample, pixel chunk); threads run along channels (coalesced,
-//      256/C pixel lanes), fp32 partials -> LDS -> one double atomicAdd per (sample, group,
-//      moment).  Moments are raw (sum x, sum x^2, sum xdot, sum x xdot) but combined in
-//      double, so the variance does not suffer from E[x^2]-mu^2 cancellation.
+//      256/C pixel lanes), fp32 partials -> LDS -> ONE double per (sample, chunk, group, moment)
+//      stored in that chunk's own slot — no atomics: the slots of a sample are added in chunk
+//      order by the finalise kernels, so the result is bitwise reproducible.  Moments are raw
+//      (sum x, sum x^2, sum xdot, sum x xdot) but combined in double, so the variance does not
+//      suffer from E[x^2]-mu^2 cancellation.
 //   2. k_gn_*_apply: grid-stride elementwise pass that rebuilds {mean, inv_std,
 //      mean(xdot), a = mean(xhat xdot)} from the moments.
-// acc[b][g][8] doubles: forward uses 0..3, backward 0..4 (+ dgamma/dbeta atomics).
+// acc[b][chunk < GN_SLOTS][g][8] doubles: forward uses moments 0..3, backward 0..4; the per-channel
+// parameter gradients of the backward go to per-(sample, chunk) slots too and are summed in a fixed order.
+#define GN_SLOTS 32
 struct GnArgs {
   const float* x; const float* gamma; const float* beta;
   float* out; double* acc; float* stats;
@@ -41,34 +45,17 @@ struct GnArgs {
   // forward statistics over the channel concatenation of two tensors (x: C0 channels, x1: C - C0), no tangent
   const float* x1; int C0;
   int sub;      // reduce kernels: pixels per fp32 partial sum — fixed per sample, whatever the batch size
+  int nch;      // pixel chunks (= slots) per sample of the reduce kernel that filled acc
+  double* accf; // backward: the five moments summed over the slots, [Bp][G][8]
+  float* pslots;// backward: dgamma | dbeta partials, [2][Bp * GN_SLOTS][C]
 };
 
-// V values per thread (channels V*cv .. V*cv+V-1 of pixel lane pl): LDS image [pl][C], then one thread per group sums
-// its channels over the pixel lanes and issues ONE double atomic.
+// V double partials per thread (channels V*cv .. V*cv+V-1 of pixel lane pl; per-thread fp32 sums over one sub-chunk
+// are widened and from there on everything is added in double): LDS image [pl][C], then one thread per group sums its
+// channels over the pixel lanes and STORES the chunk's value in its slot.
 template <int V>
-__device__ __forceinline__ void gn_group_atomic_v(float* red, const float (&v)[V], bool live, int cv, int pl, int C, int PL,
-                                                  int G, int cpg, double* dst, int stride) {
-  if (live) {
-#pragma unroll
-    for (int k = 0; k < V; ++k) red[pl * C + V * cv + k] = v[k];
-  }
-  __syncthreads();
-  const int tid = threadIdx.x;
-  if (tid < G) {
-    float s = 0.f;
-    for (int p = 0; p < PL; ++p)
-      for (int cc = 0; cc < cpg; ++cc) s += red[p * C + tid * cpg + cc];
-    atomicAdd(dst + (size_t)tid * stride, (double)s);
-  }
-  __syncthreads();
-}
-
-// the same with double partials (the reduce kernels): per-thread fp32 sums over one sub-chunk are widened and from
-// there on everything is added in double — exact for sums of a few thousand floats of comparable size, so the result
-// does not depend on how the sub-chunks are dealt to workgroups.
-template <int V>
-__device__ __forceinline__ void gn_group_atomic_d(double* red, const double (&v)[V], bool live, int cv, int pl, int C, int PL,
-                                                  int G, int cpg, double* dst, int stride) {
+__device__ __forceinline__ void gn_group_store_d(double* red, const double (&v)[V], bool live, int cv, int pl, int C, int PL,
+                                                 int G, int cpg, double* dst, int stride) {
   if (live) {
 #pragma unroll
     for (int k = 0; k < V; ++k) red[pl * C + V * cv + k] = v[k];
@@ -79,7 +66,7 @@ __device__ __forceinline__ void gn_group_atomic_d(double* red, const double (&v)
     double s = 0.0;
     for (int p = 0; p < PL; ++p)
       for (int cc = 0; cc < cpg; ++cc) s += red[p * C + tid * cpg + cc];
-    atomicAdd(dst + (size_t)tid * stride, s);
+    dst[(size_t)tid * stride] = s;
   }
   __syncthreads();
 }
@@ -133,12 +120,22 @@ __global__ void __launch_bounds__(256) k_gn_fwd_reduce(GnArgs A) {
 #pragma unroll
     for (int k = 0; k < V; ++k) { d0[k] += (double)s0[k]; d1[k] += (double)s1[k]; d2[k] += (double)s2[k]; d3[k] += (double)s3[k]; }
    }
-  double* dst = A.acc + (size_t)b * G * 8;
-  gn_group_atomic_d<V>(red, d0, live, cv, pl, C, PL, G, cpg, dst + 0, 8);
-  gn_group_atomic_d<V>(red, d1, live, cv, pl, C, PL, G, cpg, dst + 1, 8);
+  double* dst = A.acc + ((size_t)b * GN_SLOTS + blockIdx.y) * G * 8;
+  gn_group_store_d<V>(red, d0, live, cv, pl, C, PL, G, cpg, dst + 0, 8);
+  gn_group_store_d<V>(red, d1, live, cv, pl, C, PL, G, cpg, dst + 1, 8);
   if (A.dual) {
-    gn_group_atomic_d<V>(red, d2, live, cv, pl, C, PL, G, cpg, dst + 2, 8);
-    gn_group_atomic_d<V>(red, d3, live, cv, pl, C, PL, G, cpg, dst + 3, 8);
+    gn_group_store_d<V>(red, d2, live, cv, pl, C, PL, G, cpg, dst + 2, 8);
+    gn_group_store_d<V>(red, d3, live, cv, pl, C, PL, G, cpg, dst + 3, 8);
+  }
+}
+
+// moments of (sample b, group g): the chunk slots added in chunk order
+__device__ __forceinline__ void gn_sum_slots(const GnArgs& A, int b, int g, int nm, double (&a8)[8]) {
+#pragma unroll
+  for (int m = 0; m < 8; ++m) a8[m] = 0.0;
+  for (int ch = 0; ch < A.nch; ++ch) {
+    const double* p = A.acc + (((size_t)b * GN_SLOTS + ch) * A.G + g) * 8;
+    for (int m = 0; m < nm; ++m) a8[m] += p[m];
   }
 }
 
@@ -159,27 +156,27 @@ __global__ void __launch_bounds__(256) k_gn_finalize(GnArgs A, float* __restrict
   if (i >= A.Bp * A.G) return;
   const double cnt = (double)A.P * (A.C / A.G);
   float mu, inv, md, a;
-  double* acc = A.acc + (size_t)i * 8;
-  gn_stats(acc, cnt, A.eps, mu, inv, md, a);
-  acc[0] = 0.0; acc[1] = 0.0; acc[2] = 0.0; acc[3] = 0.0;      // leave the accumulators zero for the next call
+  double a8[8];
+  gn_sum_slots(A, i / A.G, i % A.G, A.dual ? 4 : 2, a8);
+  gn_stats(a8, cnt, A.eps, mu, inv, md, a);
   *reinterpret_cast<f32x4*>(wstats + (size_t)i * 4) = f32x4{mu, inv, md, a};
   if (A.stats) *reinterpret_cast<f32x4*>(A.stats + (size_t)i * 4) = f32x4{mu, inv, md, a};
 }
 
 // GroupNorm as a per-(sample, channel) affine map y = a x + b (a = gamma/sigma, b = beta - mean a) for a consumer that
-// applies it while reading x (msgm_conv_forward_fused).  One block per sample; clears the accumulators afterwards.
+// applies it while reading x (msgm_conv_forward_fused).  One block per sample.
 __global__ void __launch_bounds__(256) k_gn_affine(GnArgs A, float* __restrict__ scale, float* __restrict__ shift) {
   const int b = blockIdx.x, c = threadIdx.x, cpg = A.C / A.G;
   const double cnt = (double)A.P * cpg;
   if (c < A.C) {
     float mu, inv, md, a;
-    gn_stats(A.acc + ((size_t)b * A.G + c / cpg) * 8, cnt, A.eps, mu, inv, md, a);
+    double a8[8];
+    gn_sum_slots(A, b, c / cpg, 2, a8);
+    gn_stats(a8, cnt, A.eps, mu, inv, md, a);
     const float sc = inv * A.gamma[c];
     scale[(size_t)b * A.C + c] = sc;
     shift[(size_t)b * A.C + c] = A.beta[c] - mu * sc;
   }
-  __syncthreads();
-  if (c < A.G) { double* acc = A.acc + ((size_t)b * A.G + c) * 8; acc[0] = 0.0; acc[1] = 0.0; }
 }
 
 // Elementwise pass.  VEC: grid (pixel chunk, sample); a thread owns 4 consecutive channels (its statistics and
@@ -312,26 +309,60 @@ __global__ void __launch_bounds__(256) k_gn_bwd_reduce(GnArgs A) {
       dX[k] += (double)sX[k]; dXx[k] += (double)sXx[k]; dW[k] += (double)sW[k]; dWx[k] += (double)sWx[k]; dWw[k] += (double)sWw[k];
     }
    }
-  double* dst = A.acc + (size_t)b * G * 8;
-  gn_group_atomic_d<V>(redd, dX, live, cv, pl, C, PL, G, cpg, dst + 0, 8);
-  gn_group_atomic_d<V>(redd, dXx, live, cv, pl, C, PL, G, cpg, dst + 1, 8);
-  gn_group_atomic_d<V>(redd, dW, live, cv, pl, C, PL, G, cpg, dst + 2, 8);
-  gn_group_atomic_d<V>(redd, dWx, live, cv, pl, C, PL, G, cpg, dst + 3, 8);
-  gn_group_atomic_d<V>(redd, dWw, live, cv, pl, C, PL, G, cpg, dst + 4, 8);
-  // per-channel parameter gradients: sum the pixel lanes, one atomic per channel per block
+  double* dst = A.acc + ((size_t)b * GN_SLOTS + blockIdx.y) * G * 8;
+  gn_group_store_d<V>(redd, dX, live, cv, pl, C, PL, G, cpg, dst + 0, 8);
+  gn_group_store_d<V>(redd, dXx, live, cv, pl, C, PL, G, cpg, dst + 1, 8);
+  gn_group_store_d<V>(redd, dW, live, cv, pl, C, PL, G, cpg, dst + 2, 8);
+  gn_group_store_d<V>(redd, dWx, live, cv, pl, C, PL, G, cpg, dst + 3, 8);
+  gn_group_store_d<V>(redd, dWw, live, cv, pl, C, PL, G, cpg, dst + 4, 8);
+  // per-channel parameter gradients: sum the pixel lanes, one value per channel into this (sample, chunk)'s slot
+  const size_t slot = (size_t)b * gridDim.y + blockIdx.y, nslots = (size_t)gridDim.x * gridDim.y;
   if (live) {
 #pragma unroll
     for (int k = 0; k < V; ++k) red[pl * C + V * cv + k] = dga[k];
   }
   __syncthreads();
-  if (tid < C) { float t = 0.f; for (int p = 0; p < PL; ++p) t += red[p * C + tid]; atomicAdd(A.dgamma + tid, t); }
+  if (tid < C) { float t = 0.f; for (int p = 0; p < PL; ++p) t += red[p * C + tid]; A.pslots[slot * C + tid] = t; }
   __syncthreads();
   if (live) {
 #pragma unroll
     for (int k = 0; k < V; ++k) red[pl * C + V * cv + k] = dbe[k];
   }
   __syncthreads();
-  if (tid < C) { float t = 0.f; for (int p = 0; p < PL; ++p) t += red[p * C + tid]; atomicAdd(A.dbeta + tid, t); }
+  if (tid < C) { float t = 0.f; for (int p = 0; p < PL; ++p) t += red[p * C + tid]; A.pslots[(nslots + slot) * C + tid] = t; }
+}
+
+// backward moments of every (sample, group): the chunk slots in chunk order -> accf
+__global__ void __launch_bounds__(256) k_gn_bwd_finalize(GnArgs A) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= A.Bp * A.G) return;
+  double a8[8];
+  gn_sum_slots(A, i / A.G, i % A.G, 5, a8);
+  double* o = A.accf + (size_t)i * 8;
+#pragma unroll
+  for (int m = 0; m < 5; ++m) o[m] = a8[m];
+}
+
+// dgamma[c] += sum over the (sample, chunk) slots, dbeta alike (blockIdx.y = 0 / 1): 32 channels x 8 slot slices per
+// workgroup, every slice walks its slots in order and the 8 slices are added in order — no atomics, same bits every run.
+__global__ void __launch_bounds__(256) k_gn_param_reduce(const float* __restrict__ pslots, size_t nslots, int C,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float red[8][32];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  const float* p = pslots + (size_t)blockIdx.y * nslots * C;
+  float t = 0.f;
+  if (c < C)
+    for (size_t s = sl; s < nslots; s += 8) t += p[s * C + c];
+  red[sl][cl] = t;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    float r = red[0][cl];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) r += red[k][cl];
+    float* dst = blockIdx.y == 0 ? dgamma : dbeta;
+    dst[c] += r;
+  }
 }
 
 template <bool VEC>
@@ -350,7 +381,7 @@ __global__ void __launch_bounds__(256) k_gn_bwd_apply(GnArgs A) {
     const int c = V * cv + k, g = c / cpg;
     const f32x4 st = *reinterpret_cast<const f32x4*>(A.stats + ((size_t)b * G + g) * 4);
     mu[k] = st[0]; inv[k] = st[1]; md[k] = st[2]; a[k] = st[3];
-    const double* a8 = A.acc + ((size_t)b * G + g) * 8;
+    const double* a8 = A.accf + ((size_t)b * G + g) * 8;
     mX[k] = (float)a8[0] * rc; mXx[k] = (float)a8[1] * rc; mW[k] = (float)a8[2] * rc; pp[k] = (float)a8[3] * rc;
     cc[k] = (float)a8[4] * rc;
     ga[k] = A.gamma[c]; be[k] = A.beta[c];
@@ -744,9 +775,15 @@ static int gn_chunks_apply(int Bp, int P, int* chunk) {
   return (P + c - 1) / c;
 }
 
-// acc[Bp][G][8] doubles (moment atomics) followed by [Bp][G][4] floats (finalised forward statistics)
-static inline size_t gn_acc_bytes(int32_t Bp, int32_t G) { return (size_t)Bp * (size_t)G * 8 * sizeof(double); }
-size_t msgm_groupnorm_workspace(int32_t Bp, int32_t G) { return gn_acc_bytes(Bp, G) + (size_t)Bp * (size_t)G * 4 * sizeof(float); }
+// workspace: acc[Bp][GN_SLOTS][G][8] doubles (per-chunk moment slots) | accf[Bp][G][8] doubles (backward moments summed)
+// | [Bp][G][4] floats (finalised forward statistics) | [2][Bp*GN_SLOTS][256] floats (dgamma / dbeta slots, C <= 256).
+// Nothing in it has to be zero on entry: every slot that is read was written by the same call.
+static inline size_t gn_acc_bytes(int32_t Bp, int32_t G) { return (size_t)Bp * GN_SLOTS * (size_t)G * 8 * sizeof(double); }
+static inline size_t gn_accf_bytes(int32_t Bp, int32_t G) { return (size_t)Bp * (size_t)G * 8 * sizeof(double); }
+static inline size_t gn_stats_bytes(int32_t Bp, int32_t G) { return (size_t)Bp * (size_t)G * 4 * sizeof(float); }
+size_t msgm_groupnorm_workspace(int32_t Bp, int32_t G) {
+  return gn_acc_bytes(Bp, G) + gn_accf_bytes(Bp, G) + gn_stats_bytes(Bp, G) + (size_t)2 * Bp * GN_SLOTS * 256 * sizeof(float);
+}
 
 int msgm_groupnorm_dual_forward(const float* x, const float* gamma, const float* beta, float* out, float* stats, int32_t Bp,
                                 int32_t P, int32_t C, int32_t G, int32_t dual, int32_t silu, float eps, void* workspace,
@@ -756,8 +793,10 @@ int msgm_groupnorm_dual_forward(const float* x, const float* gamma, const float*
   if (workspace_bytes < msgm_groupnorm_workspace(Bp, G)) return MSGM_E_WORKSPACE;
   GnArgs A{x, gamma, beta, out, reinterpret_cast<double*>(workspace), stats, P, C, G, Bp, dual, silu, 0, eps,
            nullptr, nullptr, nullptr, nullptr};
-  float* wstats = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + gn_acc_bytes(Bp, G));
+  float* wstats = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + gn_acc_bytes(Bp, G) + gn_accf_bytes(Bp, G));
   const int nch = gn_chunks(Bp, P, &A.chunk, &A.sub);
+  if (nch > GN_SLOTS) return MSGM_E_UNSUPPORTED;
+  A.nch = nch;
   if (C % 4 == 0) hipLaunchKernelGGL(k_gn_fwd_reduce<true>, dim3(Bp, nch), dim3(256), 0, S(stream), A);
   else hipLaunchKernelGGL(k_gn_fwd_reduce<false>, dim3(Bp, nch), dim3(256), 0, S(stream), A);
   hipLaunchKernelGGL(k_gn_finalize, dim3((Bp * G + 255) / 256), dim3(256), 0, S(stream), A, wstats);
@@ -778,6 +817,8 @@ int msgm_groupnorm_affine(const float* x0, int32_t C0, const float* x1, int32_t 
   GnArgs A{x0, gamma, beta, nullptr, reinterpret_cast<double*>(workspace), nullptr, P, C, G, Bp, 0, 0, 0, eps,
            nullptr, nullptr, nullptr, nullptr, x1, C0};
   const int nch = gn_chunks(Bp, P, &A.chunk, &A.sub);
+  if (nch > GN_SLOTS) return MSGM_E_UNSUPPORTED;
+  A.nch = nch;
   if (C % 4 == 0 && C0 % 4 == 0) hipLaunchKernelGGL(k_gn_fwd_reduce<true>, dim3(Bp, nch), dim3(256), 0, S(stream), A);
   else hipLaunchKernelGGL(k_gn_fwd_reduce<false>, dim3(Bp, nch), dim3(256), 0, S(stream), A);
   hipLaunchKernelGGL(k_gn_affine, dim3(Bp), dim3(256), 0, S(stream), A, scale, shift);
@@ -794,12 +835,19 @@ int msgm_groupnorm_dual_backward(const float* x, const float* gamma, const float
   GnArgs A{x, gamma, beta, nullptr, reinterpret_cast<double*>(workspace), const_cast<float*>(stats), P, C, G, Bp, 1, silu, 0,
            eps, gout, gx, dgamma, dbeta};
   const int nch = gn_chunks(Bp, P, &A.chunk, &A.sub);
+  if (nch > GN_SLOTS) return MSGM_E_UNSUPPORTED;
+  A.nch = nch;
+  char* wsb = reinterpret_cast<char*>(workspace);
+  A.accf = reinterpret_cast<double*>(wsb + gn_acc_bytes(Bp, G));
+  A.pslots = reinterpret_cast<float*>(wsb + gn_acc_bytes(Bp, G) + gn_accf_bytes(Bp, G) + gn_stats_bytes(Bp, G));
   if (C % 4 == 0) hipLaunchKernelGGL(k_gn_bwd_reduce<true>, dim3(Bp, nch), dim3(256), 0, S(stream), A);
   else hipLaunchKernelGGL(k_gn_bwd_reduce<false>, dim3(Bp, nch), dim3(256), 0, S(stream), A);
+  hipLaunchKernelGGL(k_gn_bwd_finalize, dim3((Bp * G + 255) / 256), dim3(256), 0, S(stream), A);
+  hipLaunchKernelGGL(k_gn_param_reduce, dim3((C + 31) / 32, 2), dim3(256), 0, S(stream), (const float*)A.pslots,
+                     (size_t)Bp * nch, C, dgamma, dbeta);
   const int nap = gn_chunks_apply(Bp, P, &A.chunk);
   if (C % 4 == 0) hipLaunchKernelGGL(k_gn_bwd_apply<true>, dim3(nap, Bp), dim3(256), 0, S(stream), A);
   else hipLaunchKernelGGL(k_gn_bwd_apply<false>, dim3(nap, Bp), dim3(256), 0, S(stream), A);
-  if (msgm_zero_async(workspace, gn_acc_bytes(Bp, G), S(stream)) != MSGM_OK) return MSGM_E_LAUNCH;   // zero on exit
   return msgm_check_launch();
 }
 

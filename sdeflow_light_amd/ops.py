@@ -9,6 +9,8 @@ from __future__ import annotations
 import math
 from typing import Optional
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -352,8 +354,15 @@ def conv_wgrad(geom: L.ConvGeomT, gy: torch.Tensor, src: torch.Tensor, C: int, k
     mo = (C_.c_uint16 * len(tapmask_co32))(*tapmask_co32) if tapmask_co32 else None
     if (mc is not None and len(mc) < (C + 31) // 32) or (mo is not None and len(mo) < (Cout + 31) // 32):
         raise MsgmError("wgrad: tap masks need one entry per 32-channel block")
-    check(lib().msgm_conv_wgrad(geom, ptr(f32(gy)), ptr(f32(src)), C, koff, ptr(f32(dWp)), Cout, CoutP, Ktot,
-                                ptr(dbias), int(n_bias), mc, mo, stream()), "msgm_conv_wgrad")
+    if os.environ.get("MSGM_ATOMIC_WGRAD"):            # diagnostic A/B: float atomics across the position chunks
+        check(lib().msgm_conv_wgrad(geom, ptr(f32(gy)), ptr(f32(src)), C, koff, ptr(f32(dWp)), Cout, CoutP, Ktot,
+                                    ptr(dbias), int(n_bias), mc, mo, stream()), "msgm_conv_wgrad")
+        return
+    # default: deterministic — per-workgroup slabs added in slot order (no float atomics; same bits every run)
+    need = int(lib().msgm_conv_wgrad_workspace(geom, C, Cout, CoutP, int(n_bias) if dbias is not None else 0))
+    ws = scratch(gy.device, need, "wgrad")
+    check(lib().msgm_conv_wgrad_det(geom, ptr(f32(gy)), ptr(f32(src)), C, koff, ptr(f32(dWp)), Cout, CoutP, Ktot,
+                                    ptr(dbias), int(n_bias), mc, mo, ptr(ws), ws.numel() * 4, stream()), "msgm_conv_wgrad_det")
 
 
 def pack_weight(W: torch.Tensor, w_off: int, Wp: torch.Tensor, rows, ncols, col_off, taps, sr, sc, st, rowsP, Ktot, kp_off):
@@ -421,7 +430,12 @@ def colsum(x: torch.Tensor, N: int, P: int, C: int, out: Optional[torch.Tensor] 
     if x.numel() < N * P * C:
         raise MsgmError("colsum: tensor too small")
     out = torch.empty(N, C, dtype=torch.float32, device=x.device) if out is None else out
-    check(lib().msgm_colsum(ptr(f32(x)), ptr(out), N, P, C, stream()), "msgm_colsum")
+    if os.environ.get("MSGM_ATOMIC_WGRAD"):
+        check(lib().msgm_colsum(ptr(f32(x)), ptr(out), N, P, C, stream()), "msgm_colsum")
+        return out
+    need = int(lib().msgm_colsum_workspace(N, P, C))
+    ws = scratch(x.device, need, "colsum") if need else None
+    check(lib().msgm_colsum_det(ptr(f32(x)), ptr(out), N, P, C, ptr(ws), need, stream()), "msgm_colsum_det")
     return out
 
 
@@ -448,7 +462,7 @@ def _gn_ws(Bp: int, G: int, device) -> torch.Tensor:
     n = int(lib().msgm_groupnorm_workspace(Bp, G)) // 8
     key = (torch.device(device), n)
     if key not in _GN_WS:
-        _GN_WS[key] = torch.zeros(n, dtype=torch.float64, device=device)     # contract: zero on entry, left zero
+        _GN_WS[key] = torch.empty(n, dtype=torch.float64, device=device)     # per-chunk moment slots: no zero contract
     return _GN_WS[key]
 
 
@@ -552,8 +566,23 @@ def attention_dual_forward(qkv, Bp, T, C, scale):
     return att, stats
 
 
-_attn_ws = {}
-_attn_ws_keep = []          # outgrown workspaces stay alive: a captured hipGraph may still hold their address
+_SCRATCH = {}
+_SCRATCH_KEEP = []          # outgrown workspaces stay alive: a captured hipGraph may still hold their address
+
+
+def scratch(device, nbytes: int, tag: str) -> torch.Tensor:
+    """Per-(device, purpose) workspace that grows to the largest request.  A step enqueues its kernels one after the
+    other on one stream, so consecutive ops of one purpose share it.  It must reach its final size in an eager step
+    BEFORE a hipGraph capture (the trainers / samplers run one eager step first): a captured graph keeps the address."""
+    key = (torch.device(device), tag)
+    ws = _SCRATCH.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            raise MsgmError(f"{tag} workspace must exist before graph capture (run one eager step first)")
+        if ws is not None:
+            _SCRATCH_KEEP.append(ws)
+        ws = _SCRATCH[key] = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=device)
+    return ws
 
 
 def attention_dual_backward(qkv, att, datt, stats, Bp, T, C, scale):
@@ -562,13 +591,7 @@ def attention_dual_backward(qkv, att, datt, stats, Bp, T, C, scale):
     if min(qkv.numel() // 3, att.numel(), datt.numel()) < 2 * Bp * T * C or stats.numel() < 2 * Bp * T:
         raise MsgmError("attention_dual backward: buffer too small")
     need = int(lib().msgm_attention_dual_workspace(Bp, T, C))
-    ws = _attn_ws.get(qkv.device)
-    if ws is None or ws.numel() * 4 < need:
-        if torch.cuda.is_current_stream_capturing():
-            raise MsgmError("attention workspace must exist before graph capture (run one eager step first)")
-        if ws is not None:
-            _attn_ws_keep.append(ws)
-        ws = _attn_ws[qkv.device] = torch.empty(need // 4, dtype=torch.float32, device=qkv.device)
+    ws = scratch(qkv.device, need, "attention")
     dqkv = torch.empty(2 * Bp * T * 3 * C, dtype=torch.float32, device=qkv.device)
     check(lib().msgm_attention_dual_backward(ptr(f32(qkv)), ptr(f32(att)), ptr(f32(datt)), ptr(f32(stats)), ptr(dqkv), Bp, T, C,
                                              float(scale), ptr(ws), ws.numel() * 4, stream()), "msgm_attention_dual_backward")
