@@ -601,7 +601,7 @@ __global__ void __launch_bounds__(256) k_softmax_dual_fwd(float* __restrict__ S,
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
   float sum = 0.f;
-  for (int j = lane; j < T; j += 64) { const float e = __expf(s[j] - mx); s[j] = e; sum += e; }
+  for (int j = lane; j < T; j += 64) { const float e = expf(s[j] - mx); s[j] = e; sum += e; }
   sum = wave_sum(sum);
   const float rs = 1.0f / sum;
   float r = 0.f;

@@ -72,3 +72,40 @@ def check_digest(g, tag, grads, prefix, tol):
     print(f"gradient digest {tag}: worst per-tensor deviation {worst:.2e} ({worst_name}), tolerance {tol:.1e}")
     assert worst <= tol, (worst_name, worst)
     return worst
+
+
+def parity_vs_fp64(hip, oracle, what, floor_frac=1e-3, slack=2.0, abs_floor=1e-5):
+    """The yardstick for 'within fp32 tolerance' on a deep net.  ``hip()`` -> (per_sample, {name: grad}) from the HIP path;
+    ``oracle(dtype)`` -> the same from the CPU oracle evaluated in that dtype.  The float64 oracle is the truth, the
+    float32 oracle is the reference's own arithmetic (same formulas, ATen fp32).  The HIP result must be no further from
+    the truth than ``slack`` x the reference's own float32 evaluation — for the per-sample loss, the flat gradient and
+    the worst single parameter tensor (per-tensor errors relative to max(|g_k|, floor_frac * max_k |g_k|): tensors under
+    that floor have an analytically zero gradient and hold rounding noise only).  Prints everything it measured."""
+    per, grads = hip()
+    per32, g32 = oracle(torch.float32)
+    per64, g64 = oracle(torch.float64)
+    assert set(grads) == set(g64), set(grads) ^ set(g64)
+    keys = list(g64)
+    cat = lambda g: torch.cat([g[k].reshape(-1).double().cpu() for k in keys])
+    e_per, r_per = rel_l2(per.cpu(), per64), rel_l2(per32, per64)
+    e_flat, r_flat = rel_l2(cat(grads), cat(g64)), rel_l2(cat(g32), cat(g64))
+    top = max(float(g64[k].norm()) for k in keys)
+    pt = lambda g, k: float((g[k].double().cpu() - g64[k]).norm()) / max(float(g64[k].norm()), floor_frac * top)
+    e_t = {k: pt(grads, k) for k in keys}
+    r_t = {k: pt(g32, k) for k in keys}
+    kw, kr = max(e_t, key=e_t.get), max(r_t, key=r_t.get)
+    print(f"{what} (errors vs the float64 oracle; HIP | reference arithmetic = float32 oracle):\n"
+          f"  per-sample SSM loss rel-L2   {e_per:.2e} | {r_per:.2e}   (HIP vs fp32 oracle directly: {rel_l2(per.cpu(), per32):.2e})\n"
+          f"  all gradients, flat rel-L2   {e_flat:.2e} | {r_flat:.2e}\n"
+          f"  worst parameter tensor       {e_t[kw]:.2e} ({kw}) | {r_t[kr]:.2e} ({kr})")
+    assert e_per <= max(slack * r_per, abs_floor)
+    assert e_flat <= max(slack * r_flat, abs_floor)
+    assert e_t[kw] <= max(slack * r_t[kr], abs_floor), kw
+    return e_per, e_flat
+
+
+def within(measured, tol, what):
+    """assert measured <= tol, printing the measured value (tolerances are set from these prints: <= 2x measured)."""
+    print(f"{what}: measured {measured:.2e} (tolerance {tol:.1e})")
+    assert measured <= tol, (what, measured, tol)
+    return measured

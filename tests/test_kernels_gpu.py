@@ -259,12 +259,14 @@ def test_mlp_ssm_grad_golden(ops, L, tag, pre):
     ref = _flat_grads({k[len(tag) + 9:]: v for k, v in g.items() if k.startswith(f"{tag}_grad::a.")})
     assert rel_l2(grads.cpu(), ref) <= 1e-4, rel_l2(grads.cpu(), ref)
     # per-tensor check so a wrong small tensor cannot hide behind a big one
-    off = 0
+    off, worst = 0, 0.0
     for i in (0, 2, 4, 6):
         for wn in ("weight", "bias"):
             r = g[f"{tag}_grad::a.main.{i}.{wn}"].reshape(-1)
-            assert rel_l2(grads[off:off + r.numel()].cpu(), r) <= 2e-4, (i, wn)
+            worst = max(worst, rel_l2(grads[off:off + r.numel()].cpu(), r))
             off += r.numel()
+    from conftest import within
+    within(worst, 2e-4, f"fused MLP SSM kernel ({tag}): worst per-tensor gradient rel-L2 vs the reference")
 
 
 @pytest.mark.parametrize("B,d,pre", [(1, 2, None), (15, 2, None), (17, 5, "NormalizeLogRadius"), (4097, 2, None),

@@ -129,7 +129,8 @@ def test_unet2d_sampler_forward_fused_equals_composed(monkeypatch):
     assert calls, "fused attention was not taken for T=256/64, C=32/64"
     monkeypatch.setattr(ops, "attention_supported", lambda T, C: False)
     composed = net(x, t)
-    assert rel_l2(fused.cpu(), composed.cpu()) <= 2e-4      # whole-network amplification of the 2e-5 kernel-level bound
+    from conftest import within
+    within(rel_l2(fused.cpu(), composed.cpu()), 2e-4, "sampler forward, fused vs composed attention")
 
 
 def test_glue_kernels():
@@ -181,7 +182,8 @@ def test_unet2d_forward_golden(tag, S_, order):
     net = _vunet(S_, order)
     out = net(g[tag + "_x"].to(DEV), g[tag + "_t"].to(DEV))
     assert out.shape == g[tag + "_out"].shape
-    assert rel_l2(out.cpu(), g[tag + "_out"]) <= 1e-4, rel_l2(out.cpu(), g[tag + "_out"])
+    from conftest import within
+    within(rel_l2(out.cpu(), g[tag + "_out"]), 1e-4, f"VorticityUNet forward vs reference ({tag})")
 
 
 def test_unet2d_core64_three_channels_golden():
@@ -189,7 +191,8 @@ def test_unet2d_core64_three_channels_golden():
     g = load_golden("g09_unet2d")
     net = _vunet(64, "C", channels=3)
     out = net(g["core64_x"].to(DEV), g["core64_t"].to(DEV))
-    assert rel_l2(out.cpu(), g["core64_out"]) <= 1e-4, rel_l2(out.cpu(), g["core64_out"])
+    from conftest import within
+    within(rel_l2(out.cpu(), g["core64_out"]), 1e-4, "64x64x3 core forward vs reference")
 
 
 def test_unet2d_ssm_golden():
@@ -201,36 +204,30 @@ def test_unet2d_ssm_golden():
     gen = make_gen("sgm", net)
     gen.zero_grad()
     per = gen.ssm(g["u2d_x"].to(DEV), u=g["u2d_u_t"].reshape(-1).to(DEV), eps=g["u2d_eps"].to(DEV), u_v=g["u2d_u_v"].to(DEV))
-    assert rel_l2(per.detach().cpu(), g["u2d_per"]) <= 1e-4, rel_l2(per.detach().cpu(), g["u2d_per"])
+    from conftest import within
+    within(rel_l2(per.detach().cpu(), g["u2d_per"]), 1e-4, "2-D U-Net 16x16 per-sample SSM loss vs reference")
     per.mean().backward()
     grads = {k: p.grad.cpu() for k, p in gen.a.named_parameters()}
-    _check_digest(g, "u2d", grads, "a.", 1e-3)
+    _check_digest(g, "u2d", grads, "a.", 7e-5)            # measured 3.3e-05 (r2)
 
 
 def test_unet2d_ssm_vs_oracle_32():
-    """Second size (32x32, both attention resolutions with T=256 / 64) against the CPU oracle's JVP form."""
+    """Second size (32x32, attention at T = 256 (fused dual kernel, C = 64) and T = 64) against the CPU oracle: HIP no
+    further from the float64 oracle than twice the float32 oracle (conftest.parity_vs_fp64)."""
     from oracle.shapes import unet2d_shapes
     from test_host_gpu import make_gen
-    from oracle import sde_ref as S, nets_ref as N, ssm_ref as LR
+    from test_round2_gpu import ssm_parity_vs_fp64
+    from oracle import nets_ref as N
     from oracle.det_params import det_state_dict
-    torch.manual_seed(0)
     net = _vunet(32, "F")
     gen = make_gen("sgm", net)
+    torch.manual_seed(0)
     B, d = 2, 1024
     x, u, eps, uv = torch.randn(B, d) * 3, torch.rand(B), torch.randn(B, d), torch.rand(B, d)
-    gen.zero_grad()
-    per = gen.ssm(x.to(DEV), u=u.to(DEV), eps=eps.to(DEV), u_v=uv.to(DEV))
-    per.mean().backward()
-    sp = S.SdeSpec()
     cfg = N.UNet2DConfig(in_space=32)
     p = det_state_dict(unet2d_shapes(cfg, "core."))
-    t = S.clamp_time(sp, u.reshape(B, 1)); y = S.vp_perturb(sp, t, x, eps); v = S.rademacher_from_uniform(uv)
     score = lambda prm, yy, tt: N.vorticity_unet_forward(prm, yy, tt, cfg, None, "F")
-    loss, per_ref, gref = LR.ssm_mean_and_grads(sp, score, p, t, y, v)
-    assert rel_l2(per.detach().cpu(), per_ref) <= 1e-4
-    flat = torch.cat([pp.grad.reshape(-1).cpu() for _, pp in gen.a.named_parameters()])
-    ref = torch.cat([gref[k].reshape(-1) for k, _ in gen.a.named_parameters()])
-    assert rel_l2(flat, ref) <= 1e-3, rel_l2(flat, ref)
+    ssm_parity_vs_fp64(gen, score, p, x, u, eps, uv, "VorticityUNet 32x32, B=2")
 
 
 def test_unet2d_reference_loop_adam_steps_vs_oracle():
@@ -264,14 +261,14 @@ def test_unet2d_reference_loop_adam_steps_vs_oracle():
         losses_ref.append(float(lref))
         for k in ref:
             ref[k], m[k], vv[k] = LR.adam_step(ref[k], gref[k], m[k], vv[k], it + 1)
-    for a_, b_ in zip(losses, losses_ref):
-        assert a_ == pytest.approx(b_, rel=2e-3), (losses, losses_ref)
+    from conftest import within
+    within(max(abs(a_ - b_) / abs(b_) for a_, b_ in zip(losses, losses_ref)), 2e-3, "2 Adam steps, 2-D U-Net 16x16: loss sequence rel. error")
     flat = torch.cat([p_.detach().reshape(-1).cpu() for _, p_ in net.named_parameters()])
     flat_ref = torch.cat([ref[k].reshape(-1) for k, _ in net.named_parameters()])
     # Parameters: conv biases that feed a GroupNorm have an analytically ZERO gradient; Adam turns their rounding noise
     # into +-lr steps (in any implementation, the reference included), so ~1 % of the entries legitimately differ by
     # 2*lr per step — bounded here, while the losses above pin the parameters that matter.
-    assert rel_l2(flat, flat_ref) <= 5e-3, rel_l2(flat, flat_ref)
+    within(rel_l2(flat, flat_ref), 5e-3, "2 Adam steps, 2-D U-Net 16x16: parameters rel-L2")
     assert float((flat - flat_ref).abs().max()) <= 2 * 2 * 1e-3 + 1e-6
 
 
@@ -361,14 +358,14 @@ def test_unet_premodule_ssm_msgm_vs_oracle(which):
     per.mean().backward()
     sp = S.SdeSpec(kind=S.MSGM_SPARSE, n=n)
     loss, per_ref, gref = LR.ssm_mean_and_grads(sp, score, p, t, y, S.rademacher_from_uniform(uv))
-    assert rel_l2(per.detach().cpu(), per_ref) <= 2e-4, rel_l2(per.detach().cpu(), per_ref)
+    from conftest import within
+    within(rel_l2(per.detach().cpu(), per_ref), 2e-4, f"MSGM + NormalizeLogRadius U-Net ({which}): per-sample loss rel-L2")
     names = [k for k, _ in gen.a.named_parameters()]
     flat = torch.cat([pp.grad.reshape(-1).cpu() for _, pp in gen.a.named_parameters()])
     ref = torch.cat([gref[k].reshape(-1) for k in names])
-    assert rel_l2(flat, ref) <= 2e-3, rel_l2(flat, ref)
-    for k, pp in gen.a.named_parameters():            # the embedding MLPs must receive their tangent contributions
-        if "scale_embed" in k:
-            assert rel_l2(pp.grad.cpu(), gref[k]) <= 5e-3, (k, rel_l2(pp.grad.cpu(), gref[k]))
+    within(rel_l2(flat, ref), 2e-3, f"MSGM + NormalizeLogRadius U-Net ({which}): flat gradient rel-L2")
+    worst = max(rel_l2(pp.grad.cpu(), gref[k]) for k, pp in gen.a.named_parameters() if "scale_embed" in k)
+    within(worst, 5e-3, f"MSGM + NormalizeLogRadius U-Net ({which}): worst scale_embed tensor")   # they must receive their tangent contributions
 
 
 @pytest.mark.parametrize("kind", ["unet2d", "unet1d"])
@@ -454,7 +451,8 @@ def test_unet2d_sampler_forward_gn_fold_equals_unfused(monkeypatch):
     fused = net(x, t).clone()
     monkeypatch.setenv("MSGM_NO_GN_FOLD", "1")
     plain = net(x, t)
-    assert rel_l2(fused.cpu(), plain.cpu()) <= 2e-4
+    from conftest import within
+    within(rel_l2(fused.cpu(), plain.cpu()), 2e-4, "sampler forward, GroupNorm folded into the conv vs separate")
 
 
 def test_bmm_dual_output_shares_the_big_operand():
