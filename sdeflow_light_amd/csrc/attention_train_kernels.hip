@@ -24,10 +24,8 @@
 // Layouts: qkv [2Bp][T][3C] channels-last (q | k | v channel slices; rows [0,Bp) primal, [Bp,2Bp) tangent),
 // att / datt [2Bp][T][C], dqkv as qkv.  All MFMA work is v_mfma_f32_16x16x4_f32 (exact fp32); every operand reaches the
 // matrix cores from LDS tiles that were filled with coalesced 16-byte global loads.  exp / log are the accurate expf /
-// logf, not the 2-ulp hardware approximations: the backward multiplies P by differences that cancel (Pbar - delta ...),
-// and with __expf the worst parameter tensor of the 32x32 U-Net was 3x further from the float64 oracle than the
-// reference's own fp32 arithmetic (1.9e-4 vs 6e-5); with expf it is closer than the reference (4.5e-5), for 3 % of the
-// forward kernel's time.
+// logf, not the 2-ulp hardware approximations (3 % of the forward kernel's time): the backward multiplies P by
+// differences that cancel (Pbar - delta ...), so the probabilities are kept at fp32 accuracy.
 #include "common.h"
 
 __device__ __forceinline__ f32x4 mfma16t(float a, float b, f32x4 c) {

@@ -52,7 +52,7 @@ def test_ssm_reference_loop_surface(tag, d, pre):
     assert rel_l2(per.detach().cpu(), g[tag + "_per"]) <= 1e-5
     per.mean().backward()
     from conftest import within
-    within(max(rel_l2(p.grad.cpu(), g[f"{tag}_grad::{k}"]) for k, p in gen.named_parameters() if p.requires_grad), 2e-4,
+    within(max(rel_l2(p.grad.cpu(), g[f"{tag}_grad::{k}"]) for k, p in gen.named_parameters() if p.requires_grad), 5e-7,
            f"MLP {tag}: worst per-tensor gradient rel-L2 vs the reference's double backward")
     # a second backward pass accumulates (autograd semantics)
     per2 = gen.ssm(g[tag + "_x"].to(DEV), u=g[tag + "_u_t"].reshape(-1).to(DEV), eps=g[tag + "_eps"].to(DEV),
@@ -321,7 +321,7 @@ def test_unet1d_ssm_golden():
     gen.zero_grad()
     per = gen.ssm(g["u1d_x"].to(DEV), u=g["u1d_u_t"].reshape(-1).to(DEV), eps=g["u1d_eps"].to(DEV), u_v=g["u1d_u_v"].to(DEV))
     from conftest import within
-    within(rel_l2(per.detach().cpu(), g["u1d_per"]), 1e-4, "UNet1D L=256 per-sample SSM loss vs reference")
+    within(rel_l2(per.detach().cpu(), g["u1d_per"]), 1e-7, "UNet1D L=256 per-sample SSM loss vs reference")
     per.mean().backward()
     grads = {k: p.grad.cpu() for k, p in gen.a.named_parameters()}
     _check_digest(g, "u1d", grads, "a.", 5e-7)            # measured 2.4e-07 (r2)
@@ -379,12 +379,12 @@ def test_unet1d_reference_loop_adam_steps_vs_oracle():
         for k in ref:
             ref[k], m[k], vv[k] = LR.adam_step(ref[k], gref[k], m[k], vv[k], it + 1)
     from conftest import within
-    within(max(abs(a_ - b_) / abs(b_) for a_, b_ in zip(losses, losses_ref)), 2e-3, "3 Adam steps, UNet1D: loss sequence rel. error")
+    within(max(abs(a_ - b_) / abs(b_) for a_, b_ in zip(losses, losses_ref)), 1e-6, "3 Adam steps, UNet1D: loss sequence rel. error")
     # the iterations are different problems, so matching losses 2 and 3 needs the updated parameters
     assert abs(losses_ref[1] - losses_ref[0]) > 1e-2 * abs(losses_ref[0])
     flat = torch.cat([p_.detach().reshape(-1).cpu() for _, p_ in net.named_parameters()])
     flat_ref = torch.cat([ref[k].reshape(-1) for k, _ in net.named_parameters()])
-    within(rel_l2(flat, flat_ref), 2e-3, "3 Adam steps, UNet1D: parameters rel-L2")
+    within(rel_l2(flat, flat_ref), 6e-5, "3 Adam steps, UNet1D: parameters rel-L2")
 
 
 def test_unet1d_sampler_runs_and_matches_oracle():
@@ -454,10 +454,10 @@ def test_ssm_unet1d_msgm_sparse_vs_oracle():
     score = lambda prm, yy, tt: N.unet1d_forward(prm, yy, tt, None)
     loss, per_ref, gref = LR.ssm_mean_and_grads(sp, score, p, t, y, S.rademacher_from_uniform(uv))
     from conftest import within
-    within(rel_l2(per.detach().cpu(), per_ref), 1e-4, "MSGM sparse + UNet1D: per-sample loss rel-L2")
+    within(rel_l2(per.detach().cpu(), per_ref), 2e-6, "MSGM sparse + UNet1D: per-sample loss rel-L2")
     flat = torch.cat([pp.grad.reshape(-1).cpu() for _, pp in gen.a.named_parameters()])
     ref = torch.cat([gref[k].reshape(-1) for k, _ in gen.a.named_parameters()])
-    within(rel_l2(flat, ref), 1e-3, "MSGM sparse + UNet1D: flat gradient rel-L2")
+    within(rel_l2(flat, ref), 2e-6, "MSGM sparse + UNet1D: flat gradient rel-L2")
 
 
 def test_checkpoint_roundtrip_and_torch_adam_compat(tmp_path):

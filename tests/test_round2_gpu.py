@@ -41,7 +41,7 @@ def per_tensor_check(named_grads, ref, tol, floor_frac=1e-3, what=""):
 
 
 # ------------------------------------------------------------------------------------------ (a) trajectories
-@pytest.mark.parametrize("tag,steps,tol", [("em", 8, 2e-5), ("rk4", 4, 2e-5), ("heun", 4, 2e-5)])
+@pytest.mark.parametrize("tag,steps,tol", [("em", 8, 8e-6), ("rk4", 4, 8e-6), ("heun", 4, 8e-6)])
 def test_unet2d_reverse_sde_trajectory_vs_reference(tag, steps, tol):
     from sdeflow_light_amd import sde_scheme as SS
     g = load_golden("g16_round2")
@@ -65,7 +65,7 @@ def test_mlp_em_256_steps_vs_reference():
     ref = g["mlp_em256_every32"]
     e = [rel_l2(xs[32 * i], ref[i]) for i in range(ref.shape[0])]
     print("HIP vs reference, 256-step MLP EM, rel-L2 at steps 0,32,..,256: " + " ".join(f"{v:.1e}" for v in e))
-    assert max(e) <= 2e-5
+    assert max(e) <= 2e-7
 
 
 # ------------------------------------------------------------------------------------------ (b) BASELINE shapes
@@ -137,7 +137,7 @@ def test_ssm_gaussian_and_sphere_probes_vs_reference(vt):
     per.mean().backward()
     eg = max(rel_l2(p.grad.cpu(), g[f"ssm_{vt}_grad::{k}"]) for k, p in gen.named_parameters() if p.requires_grad)
     print(f"SSM with the {vt} probe: per-sample rel-L2 {e:.2e}, worst parameter-gradient rel-L2 {eg:.2e}")
-    assert e <= 1e-5 and eg <= 2e-4
+    assert e <= 2e-7 and eg <= 5e-7
     # drawn (not injected) probes: right law, fresh every call, same Philox numbers as the standalone draw
     gen.zero_grad()
     st = gen.base_sde.philox(torch.device(DEV)).state.clone()

@@ -183,7 +183,7 @@ def test_unet2d_forward_golden(tag, S_, order):
     out = net(g[tag + "_x"].to(DEV), g[tag + "_t"].to(DEV))
     assert out.shape == g[tag + "_out"].shape
     from conftest import within
-    within(rel_l2(out.cpu(), g[tag + "_out"]), 1e-4, f"VorticityUNet forward vs reference ({tag})")
+    within(rel_l2(out.cpu(), g[tag + "_out"]), 7e-6, f"VorticityUNet forward vs reference ({tag})")
 
 
 def test_unet2d_core64_three_channels_golden():
@@ -192,7 +192,7 @@ def test_unet2d_core64_three_channels_golden():
     net = _vunet(64, "C", channels=3)
     out = net(g["core64_x"].to(DEV), g["core64_t"].to(DEV))
     from conftest import within
-    within(rel_l2(out.cpu(), g["core64_out"]), 1e-4, "64x64x3 core forward vs reference")
+    within(rel_l2(out.cpu(), g["core64_out"]), 5e-5, "64x64x3 core forward vs reference")
 
 
 def test_unet2d_ssm_golden():
@@ -205,7 +205,7 @@ def test_unet2d_ssm_golden():
     gen.zero_grad()
     per = gen.ssm(g["u2d_x"].to(DEV), u=g["u2d_u_t"].reshape(-1).to(DEV), eps=g["u2d_eps"].to(DEV), u_v=g["u2d_u_v"].to(DEV))
     from conftest import within
-    within(rel_l2(per.detach().cpu(), g["u2d_per"]), 1e-4, "2-D U-Net 16x16 per-sample SSM loss vs reference")
+    within(rel_l2(per.detach().cpu(), g["u2d_per"]), 8e-6, "2-D U-Net 16x16 per-sample SSM loss vs reference")   # measured 4.1e-06
     per.mean().backward()
     grads = {k: p.grad.cpu() for k, p in gen.a.named_parameters()}
     _check_digest(g, "u2d", grads, "a.", 7e-5)            # measured 3.3e-05 (r2)
@@ -262,13 +262,13 @@ def test_unet2d_reference_loop_adam_steps_vs_oracle():
         for k in ref:
             ref[k], m[k], vv[k] = LR.adam_step(ref[k], gref[k], m[k], vv[k], it + 1)
     from conftest import within
-    within(max(abs(a_ - b_) / abs(b_) for a_, b_ in zip(losses, losses_ref)), 2e-3, "2 Adam steps, 2-D U-Net 16x16: loss sequence rel. error")
+    within(max(abs(a_ - b_) / abs(b_) for a_, b_ in zip(losses, losses_ref)), 6e-4, "2 Adam steps, 2-D U-Net 16x16: loss sequence rel. error")
     flat = torch.cat([p_.detach().reshape(-1).cpu() for _, p_ in net.named_parameters()])
     flat_ref = torch.cat([ref[k].reshape(-1) for k, _ in net.named_parameters()])
     # Parameters: conv biases that feed a GroupNorm have an analytically ZERO gradient; Adam turns their rounding noise
     # into +-lr steps (in any implementation, the reference included), so ~1 % of the entries legitimately differ by
     # 2*lr per step — bounded here, while the losses above pin the parameters that matter.
-    within(rel_l2(flat, flat_ref), 5e-3, "2 Adam steps, 2-D U-Net 16x16: parameters rel-L2")
+    within(rel_l2(flat, flat_ref), 4e-3, "2 Adam steps, 2-D U-Net 16x16: parameters rel-L2")
     assert float((flat - flat_ref).abs().max()) <= 2 * 2 * 1e-3 + 1e-6
 
 
@@ -359,13 +359,14 @@ def test_unet_premodule_ssm_msgm_vs_oracle(which):
     sp = S.SdeSpec(kind=S.MSGM_SPARSE, n=n)
     loss, per_ref, gref = LR.ssm_mean_and_grads(sp, score, p, t, y, S.rademacher_from_uniform(uv))
     from conftest import within
-    within(rel_l2(per.detach().cpu(), per_ref), 2e-4, f"MSGM + NormalizeLogRadius U-Net ({which}): per-sample loss rel-L2")
+    tol = {"1d": (5e-7, 3e-6, 2e-5), "2d": (5e-5, 8e-5, 1.5e-4)}[which]          # <= 2x the values measured in round 2
+    within(rel_l2(per.detach().cpu(), per_ref), tol[0], f"MSGM + NormalizeLogRadius U-Net ({which}): per-sample loss rel-L2")
     names = [k for k, _ in gen.a.named_parameters()]
     flat = torch.cat([pp.grad.reshape(-1).cpu() for _, pp in gen.a.named_parameters()])
     ref = torch.cat([gref[k].reshape(-1) for k in names])
-    within(rel_l2(flat, ref), 2e-3, f"MSGM + NormalizeLogRadius U-Net ({which}): flat gradient rel-L2")
+    within(rel_l2(flat, ref), tol[1], f"MSGM + NormalizeLogRadius U-Net ({which}): flat gradient rel-L2")
     worst = max(rel_l2(pp.grad.cpu(), gref[k]) for k, pp in gen.a.named_parameters() if "scale_embed" in k)
-    within(worst, 5e-3, f"MSGM + NormalizeLogRadius U-Net ({which}): worst scale_embed tensor")   # they must receive their tangent contributions
+    within(worst, tol[2], f"MSGM + NormalizeLogRadius U-Net ({which}): worst scale_embed tensor")   # they must receive their tangent contributions
 
 
 @pytest.mark.parametrize("kind", ["unet2d", "unet1d"])
@@ -452,7 +453,7 @@ def test_unet2d_sampler_forward_gn_fold_equals_unfused(monkeypatch):
     monkeypatch.setenv("MSGM_NO_GN_FOLD", "1")
     plain = net(x, t)
     from conftest import within
-    within(rel_l2(fused.cpu(), plain.cpu()), 2e-4, "sampler forward, GroupNorm folded into the conv vs separate")
+    within(rel_l2(fused.cpu(), plain.cpu()), 1.5e-4, "sampler forward, GroupNorm folded into the conv vs separate")
 
 
 def test_bmm_dual_output_shares_the_big_operand():
