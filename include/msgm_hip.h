@@ -88,6 +88,10 @@ int msgm_perturb_vp(const float* x0, float* y, float* t_out, float* eps_out,
                     int64_t B, int64_t d, const msgm_sde_t* sde,
                     const float* u, const float* eps, const uint64_t* rng,
                     msgm_stream_t stream);
+/* The same closed form with the times GIVEN: y = mean_weight(t_b) x0 + sqrt(var(t_b)) eps, t (B) used exactly as passed
+ * (no u*T round trip, no clamp) — SGMsde.sample(t, y0) / sample_Song_et_al (SDEs.py:134-146,196-199). */
+int msgm_perturb_vp_at(const float* x0, float* y, float* eps_out, int64_t B, int64_t d, const msgm_sde_t* sde,
+                       const float* t, const float* eps, const uint64_t* rng, msgm_stream_t stream);
 
 /* Training-step prologue in ONE launch: msgm_perturb_vp + msgm_rademacher with
  * in-kernel Philox draws (streams 0,1,2), plus `*step_ctr += 1` (optimizer step

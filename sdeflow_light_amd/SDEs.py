@@ -134,8 +134,7 @@ class SDE(nn.Module):
         (epsilon, std, g(t, y_t)) as upstream."""
         if self.kind != L.SDE_SGM:
             raise MsgmError("sample_Song_et_al is the closed form of the additive (VP) SDE")
-        T = self.T_float()
-        y, _, e = ops.perturb_vp(y0.contiguous().float(), self.struct(), u=(t.reshape(-1) / T).contiguous().float(), eps=eps,
+        y, e = ops.perturb_vp_at(y0.contiguous().float(), self.struct(), t, eps=eps,
                                  rng=None if eps is not None else self.philox(y0.device), return_eps=True)
         if eps is None:
             self.rng.advance(1)
@@ -178,12 +177,11 @@ class SGMsde(SDE):
     @torch.no_grad()
     def sample(self, t, y0, return_noise=False, eps=None):
         """y_t | y_0 in closed form — ONE kernel (K1) instead of ~8 eager ops.
-        ``t`` (B,1) must already be clamped (it is passed through unchanged);
+        ``t`` (B,1) is used exactly as given (no clamp, as upstream: SDEs.py:134-146);
         ``eps`` injects the Gaussian draw (parity tests)."""
         if return_noise:
             raise NotImplementedError('See the official repository.')
-        T = self.T_float()
-        y, _ = ops.perturb_vp(y0.contiguous(), self.struct(), u=(t.reshape(-1) / T).contiguous(), eps=eps,
+        y = ops.perturb_vp_at(y0.contiguous().float(), self.struct(), t, eps=eps,
                               rng=None if eps is not None else self.philox(y0.device))
         if eps is None:
             self.rng.advance(1)

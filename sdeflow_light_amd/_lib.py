@@ -64,6 +64,7 @@ SIGNATURES = {
     "msgm_fill_uniform": (C.c_int, [_P, _I64, _P, _U32, _P]),
     "msgm_fill_normal": (C.c_int, [_P, _I64, _P, _U32, _P]),
     "msgm_perturb_vp": (C.c_int, [_P, _P, _P, _P, _I64, _I64, C.POINTER(SdeT), _P, _P, _P, _P]),
+    "msgm_perturb_vp_at": (C.c_int, [_P, _P, _P, _I64, _I64, C.POINTER(SdeT), _P, _P, _P, _P]),
     "msgm_ssm_prep": (C.c_int, [_P, _P, _P, _P, _I64, _I64, C.POINTER(SdeT), _P, _P, _P]),
     "msgm_forward_step_index": (C.c_int, [_P, _P, _I64, _I32, _F, _P]),
     "msgm_rademacher": (C.c_int, [_P, _I64, _P, _P, _P]),

@@ -50,7 +50,15 @@ __global__ void __launch_bounds__(256) k_attn_dual_fwd(const float* __restrict__
   float* Vs = Kd + KB * KP;
   float* Vd = Vs + KB * KP;
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, il = lane & 15, q = lane >> 4;
-  const int smp = blockIdx.x / nqb, qb = blockIdx.x - smp * nqb;
+  // XCD-aware block order: workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2); the nqb query
+  // blocks of one sample all stream that sample's K / V tiles, so they get ids 8 apart (same XCD, back to back) and
+  // the re-reads hit that L2.  Samples beyond the last multiple of 8 keep the plain order.
+  int smp, qb;
+  {
+    const int full = (int)(Bp / 8) * 8 * nqb, b = blockIdx.x;
+    if (b < full) { const int loc = b >> 3; smp = (loc / nqb) * 8 + (b & 7); qb = loc % nqb; }
+    else { const int r = b - full; smp = (int)(Bp / 8) * 8 + r / nqb; qb = r % nqb; }
+  }
   const float* bp = qkv + (size_t)smp * T * LD;            // primal rows of this sample
   const float* bt = bp + (size_t)Bp * T * LD;              // tangent rows
   const int q0 = (qb * 4 + w) * 16 * QT;                   // first query of this wave
@@ -242,7 +250,12 @@ __global__ void __launch_bounds__(512) k_attn_dual_bwd(const float* __restrict__
   float* dSd = dS + QB * DP;                              // [32][DP] Sdbar
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, il = lane & 15, q = lane >> 4;
   const int qs = w & 1, kg = w >> 1;
-  const int smp = blockIdx.x / nkb, kb = blockIdx.x - smp * nkb;
+  int smp, kb;                                             // XCD-aware order (see the forward kernel): the key blocks
+  {                                                        // of one sample stream the same q / g rows
+    const int full = (int)(Bp / 8) * 8 * nkb, b = blockIdx.x;
+    if (b < full) { const int loc = b >> 3; smp = (loc / nkb) * 8 + (b & 7); kb = loc % nkb; }
+    else { const int r = b - full; smp = (int)(Bp / 8) * 8 + r / nkb; kb = r % nkb; }
+  }
   const size_t half_qkv = (size_t)Bp * T * LD, half_att = (size_t)Bp * T * C;
   const float* bp = qkv + (size_t)smp * T * LD;
   const float* gp = datt + (size_t)smp * T * C;

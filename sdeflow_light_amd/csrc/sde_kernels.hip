@@ -42,7 +42,7 @@ __global__ void k_time_tick(const float* __restrict__ ts, const int64_t* __restr
 __global__ void k_perturb_vp(const float* __restrict__ x0, float* __restrict__ y, float* __restrict__ t_out,
                              float* __restrict__ eps_out, int64_t B, int64_t d, float b0, float b1, float T,
                              float t_eps, const float* __restrict__ u, const float* __restrict__ eps,
-                             const uint64_t* __restrict__ rng) {
+                             const uint64_t* __restrict__ rng, const float* __restrict__ t_given) {
   const int64_t n = B * d;
   const int64_t nq = (n + 3) >> 2;
   for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
@@ -58,10 +58,14 @@ __global__ void k_perturb_vp(const float* __restrict__ x0, float* __restrict__ y
       if (e >= n) break;
       const int64_t b = e / d;
       if (b != b_prev) {
-        const float ub = u ? u[b] : philox_uniform1(rng, 0, RNG_STREAM_T, (uint64_t)b);
-        t = ub * T;
-        const float m = (t <= t_eps) ? 1.0f : 0.0f;      // mask arithmetic as upstream
-        t = m * t_eps + (1.0f - m) * t;
+        if (t_given) {                                    // SGMsde.sample(t, y0): t used as given, no clamp (SDEs.py:134-146)
+          t = t_given[b];
+        } else {
+          const float ub = u ? u[b] : philox_uniform1(rng, 0, RNG_STREAM_T, (uint64_t)b);
+          t = ub * T;
+          const float m = (t <= t_eps) ? 1.0f : 0.0f;    // mask arithmetic as upstream
+          t = m * t_eps + (1.0f - m) * t;
+        }
         mw = vp_mean_weight(b0, b1, t);
         sd = sqrtf(vp_var(b0, b1, t));
         b_prev = b;
@@ -69,7 +73,7 @@ __global__ void k_perturb_vp(const float* __restrict__ x0, float* __restrict__ y
       float ee = eps ? eps[e] : ez[k];
       y[e] = ee * sd + mw * x0[e];
       if (eps_out) eps_out[e] = ee;
-      if (e - b * d == 0) t_out[b] = t;
+      if (t_out && e - b * d == 0) t_out[b] = t;
     }
   }
 }
@@ -602,7 +606,16 @@ int msgm_perturb_vp(const float* x0, float* y, float* t_out, float* eps_out, int
   if ((!u || !eps) && !rng) return MSGM_E_BADARG;
   if (sde->kind != MSGM_SDE_SGM) return MSGM_E_UNSUPPORTED;   // MSGM has no closed form (SDEs.py:434-436)
   hipLaunchKernelGGL(k_perturb_vp, dim3(grid_for((B * d + 3) / 4, 256)), dim3(256), 0, S(stream), x0, y, t_out, eps_out,
-                     B, d, sde->beta_min, sde->beta_max, sde->T, sde->t_epsilon, u, eps, rng);
+                     B, d, sde->beta_min, sde->beta_max, sde->T, sde->t_epsilon, u, eps, rng, (const float*)nullptr);
+  return msgm_check_launch();
+}
+
+int msgm_perturb_vp_at(const float* x0, float* y, float* eps_out, int64_t B, int64_t d, const msgm_sde_t* sde, const float* t,
+                       const float* eps, const uint64_t* rng, msgm_stream_t stream) {
+  if (!x0 || !y || !t || !sde || B <= 0 || d <= 0 || (!eps && !rng)) return MSGM_E_BADARG;
+  if (sde->kind != MSGM_SDE_SGM) return MSGM_E_UNSUPPORTED;
+  hipLaunchKernelGGL(k_perturb_vp, dim3(grid_for((B * d + 3) / 4, 256)), dim3(256), 0, S(stream), x0, y, (float*)nullptr,
+                     eps_out, B, d, sde->beta_min, sde->beta_max, sde->T, sde->t_epsilon, (const float*)nullptr, eps, rng, t);
   return msgm_check_launch();
 }
 

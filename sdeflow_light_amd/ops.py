@@ -54,6 +54,22 @@ def perturb_vp(x0: torch.Tensor, sde: L.SdeT, u: Optional[torch.Tensor] = None, 
     return (y, t, eo) if return_eps else (y, t)
 
 
+def perturb_vp_at(x0: torch.Tensor, sde: L.SdeT, t: torch.Tensor, eps: Optional[torch.Tensor] = None,
+                  rng: Optional[PhiloxState] = None, return_eps: bool = False):
+    """y_t | y_0 at GIVEN times t (B,) — used as passed, no clamp (SGMsde.sample, SDEs.py:134-146)."""
+    if x0.dim() != 2:
+        raise MsgmError("x0 must be (B,d)")
+    B, d = x0.shape
+    t = t.reshape(-1).contiguous().float()
+    _same_shape(t, (B,), "t")
+    _same_shape(eps, (B, d), "eps")
+    y = torch.empty_like(x0)
+    eo = torch.empty_like(x0) if return_eps else None
+    check(lib().msgm_perturb_vp_at(ptr(f32(x0)), ptr(y), ptr(eo), B, d, sde, ptr(t), ptr(eps), _rng_ptr(rng), stream()),
+          "msgm_perturb_vp_at")
+    return (y, eo) if return_eps else y
+
+
 def forward_step_index(t: torch.Tensor, nsf: int, T: float) -> torch.Tensor:
     t = t.reshape(-1)
     k = torch.empty(t.numel(), dtype=torch.int32, device=t.device)

@@ -337,3 +337,10 @@ def test_g16_ssm_gaussian_and_sphere_probes(vt):
         close(per, g[f"ssm_{vt}_per"], 5e-6)
         for k, gr in grads.items():
             close(gr, g[f"ssm_{vt}_grad::a.{k}"], 2e-5)
+
+
+def test_g16_sample_at_times_below_t_epsilon():
+    """SGMsde.sample(t, y0) uses t as given — no clamp at t_epsilon (SDEs.py:134-146)."""
+    g = load_golden("g16_round2")
+    y = S.vp_perturb(spec(), g["smallt_t"], g["smallt_x0"], g["smallt_eps"])
+    close(y, g["smallt_y"], 1e-6)

@@ -244,3 +244,18 @@ def test_graphed_step_sampler_equals_eager_integrator(method, base_kind):
     assert e <= 2e-6
     c = gs.run(x0).clone()                                 # the stream advanced: a second run is a fresh sample
     assert not torch.equal(a, c) and torch.isfinite(c).all()
+
+
+def test_sgm_sample_uses_t_as_given_below_t_epsilon():
+    """SGMsde.sample(t, y0) went through the clamping kernel (t <= t_epsilon was raised to t_epsilon and
+    t/T*T could move t by an ulp).  It now uses t exactly as passed, like the reference (SDEs.py:134-146)."""
+    from sdeflow_light_amd.NN import MLP
+    g = load_golden("g16_round2")
+    gen = make_gen("sgm", MLP(2))
+    y = gen.base_sde.sample(g["smallt_t"].to(DEV), g["smallt_x0"].to(DEV), eps=g["smallt_eps"].to(DEV))
+    e = rel_l2(y.cpu(), g["smallt_y"])
+    print(f"SGMsde.sample at t in [1e-5, 1]: rel-L2 {e:.2e}")
+    assert e <= 1e-6
+    y2, eps, std, gg = gen.base_sde.sample_Song_et_al(g["smallt_t"].to(DEV), g["smallt_x0"].to(DEV), return_noise=True,
+                                                      eps=g["smallt_eps"].to(DEV))
+    assert torch.equal(y2, y) and torch.equal(eps.cpu(), g["smallt_eps"])

@@ -541,6 +541,13 @@ def g16_round2():
         u_t, eps, zv = (t for _, t in r.draws)
         out.update({f"ssm_{vt}_x": x, f"ssm_{vt}_u_t": u_t, f"ssm_{vt}_eps": eps, f"ssm_{vt}_zv": zv, f"ssm_{vt}_per": per.detach()})
         out.update({f"ssm_{vt}_grad::" + k: p.grad.detach().clone() for k, p in revv.named_parameters() if p.grad is not None})
+    # (d) SGMsde.sample(t, y0) with times BELOW t_epsilon: upstream uses t as given, no clamp (SDEs.py:134-146,196-199)
+    s0 = sgm()
+    x0 = torch.randn(8, 5)
+    t = torch.tensor([1e-5, 1e-4, 5e-4, 9.99e-4, 1e-3, 2e-3, 0.5, 1.0]).reshape(8, 1)
+    with Recorder() as r:
+        y = s0.sample(t, x0)
+    out.update(smallt_x0=x0, smallt_t=t, smallt_eps=r.draws[0][1], smallt_y=y)
     save("g16_round2", **out)
 
 
