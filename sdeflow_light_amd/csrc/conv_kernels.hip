@@ -1069,7 +1069,14 @@ int msgm_conv_forward_fused(const msgm_conv_geom_t* geom, const float* src0, int
     // measured +10..27 % in 2-D and +3..8 % in 1-D over the 128-pixel double-buffered form (tools/exp_wide.py);
     // 1x1 kernels (no tap reuse, HBM-bound) stay on the 128-pixel form, which measured equal or better
     const bool no_wide = getenv("MSGM_NO_CONV_WIDE") != nullptr;            // diagnostic A/B
-    const bool wide = geom->KW == 3 && !no_wide && (two_d ? (geom->Ho >= 16 && geom->Wo >= 16) : geom->Wo >= 256);
+    bool wide = geom->KW == 3 && !no_wide && (two_d ? (geom->Ho >= 16 && geom->Wo >= 16) : geom->Wo >= 256);
+    if (wide) {
+      // small launches (the 32-row per-GPU shard of C4): below two 256-pixel workgroups per CU the chip is not
+      // filled — 128-pixel tiles double the workgroup count (B = 32 step 26.3 -> 25.5 ms; no change at B >= 128)
+      const int64_t wtiles = (int64_t)geom->N * ((geom->Wo + (two_d ? 15 : 255)) / (two_d ? 16 : 256)) *
+                             (two_d ? (geom->Ho + 15) / 16 : 1) * (CoutP / (16 * nco));
+      if (wtiles < 512) wide = false;
+    }
     const int TH = two_d ? (wide ? 16 : 8) : 1, TW = two_d ? 16 : (wide ? 256 : 128);
     const int tiles_x = (geom->Wo + TW - 1) / TW, tiles_y = (geom->Ho + TH - 1) / TH;
     const int halo = (TH + geom->KH - 1) * (TW + geom->KW - 1);

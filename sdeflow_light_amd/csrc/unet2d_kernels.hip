@@ -343,23 +343,24 @@ __global__ void __launch_bounds__(256) k_gn_bwd_finalize(GnArgs A) {
   for (int m = 0; m < 5; ++m) o[m] = a8[m];
 }
 
-// dgamma[c] += sum over the (sample, chunk) slots, dbeta alike (blockIdx.y = 0 / 1): 32 channels x 8 slot slices per
-// workgroup, every slice walks its slots in order and the 8 slices are added in order — no atomics, same bits every run.
-__global__ void __launch_bounds__(256) k_gn_param_reduce(const float* __restrict__ pslots, size_t nslots, int C,
-                                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  __shared__ float red[8][32];
+// dgamma[c] += sum over the (sample, chunk) slots, dbeta alike (blockIdx.y = 0 / 1): 32 channels x 32 slot slices per
+// workgroup (1024 threads: the grid is only C/32 x 2 workgroups, so the parallelism has to come from inside), every
+// slice walks its slots in order and the 32 slices are added in order — no atomics, same bits every run.
+__global__ void __launch_bounds__(1024) k_gn_param_reduce(const float* __restrict__ pslots, size_t nslots, int C,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float red[32][32];
   const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   const float* p = pslots + (size_t)blockIdx.y * nslots * C;
   float t = 0.f;
   if (c < C)
-    for (size_t s = sl; s < nslots; s += 8) t += p[s * C + c];
+    for (size_t s = sl; s < nslots; s += 32) t += p[s * C + c];
   red[sl][cl] = t;
   __syncthreads();
   if (sl == 0 && c < C) {
     float r = red[0][cl];
 #pragma unroll
-    for (int k = 1; k < 8; ++k) r += red[k][cl];
+    for (int k = 1; k < 32; ++k) r += red[k][cl];
     float* dst = blockIdx.y == 0 ? dgamma : dbeta;
     dst[c] += r;
   }
@@ -843,7 +844,7 @@ int msgm_groupnorm_dual_backward(const float* x, const float* gamma, const float
   if (C % 4 == 0) hipLaunchKernelGGL(k_gn_bwd_reduce<true>, dim3(Bp, nch), dim3(256), 0, S(stream), A);
   else hipLaunchKernelGGL(k_gn_bwd_reduce<false>, dim3(Bp, nch), dim3(256), 0, S(stream), A);
   hipLaunchKernelGGL(k_gn_bwd_finalize, dim3((Bp * G + 255) / 256), dim3(256), 0, S(stream), A);
-  hipLaunchKernelGGL(k_gn_param_reduce, dim3((C + 31) / 32, 2), dim3(256), 0, S(stream), (const float*)A.pslots,
+  hipLaunchKernelGGL(k_gn_param_reduce, dim3((C + 31) / 32, 2), dim3(1024), 0, S(stream), (const float*)A.pslots,
                      (size_t)Bp * nch, C, dgamma, dbeta);
   const int nap = gn_chunks_apply(Bp, P, &A.chunk);
   if (C % 4 == 0) hipLaunchKernelGGL(k_gn_bwd_apply<true>, dim3(nap, Bp), dim3(256), 0, S(stream), A);
