@@ -386,24 +386,26 @@ int msgm_add_row(float* x, const float* E, int32_t N, int32_t P, int32_t C, int3
  * x [N][P][C] channels-last, N = 2*Bp when dual (model/nn_utils.py:39-46,107-114;
  * used at model/unet.py:140-143,152-155,214,443-444).  Tangent:
  *   ydot = gamma (xdot - mean(xdot) - xhat mean(xhat xdot)) / sigma.
- * Each direction is two fully parallel launches (moment reduction over
- * (sample, pixel-chunk) workgroups with double atomics into `workspace`, then an
- * elementwise apply pass), so 32 samples/GPU still fill the chip.
+ * Each direction is fully parallel launches (moment reduction over (sample,
+ * pixel-chunk) workgroups into per-chunk SLOTS of `workspace`, summed in chunk
+ * order by a finalise kernel, then an elementwise apply pass), so 32 samples/GPU
+ * still fill the chip and the result is bitwise reproducible (no atomics).
  * stats [Bp][G][4] = {mean, 1/sigma, mean(xdot), mean(xhat xdot)} is written by
  * forward (may be NULL when no backward follows) and read by backward, which
- * recomputes xhat / SiLU from x, adds to dgamma / dbeta (float atomics) and
- * writes the input cotangents (primal | tangent) to gx (may alias gout).
- * Workspace contract: the caller hands in a buffer that is ZERO the first time; every call leaves its
- * accumulator part zero again (forward clears it in its finalise kernel, backward with a trailing memset), so
- * consecutive calls on one stream share one buffer without a memset per call. */
+ * recomputes xhat / SiLU from x, adds to dgamma / dbeta (slot-ordered sums) and
+ * writes the input cotangents (primal | tangent) to gx (may alias gout);
+ * `residual` (may be NULL, same shape as gx, may alias gx) is added to them — the
+ * skip branch of a ResBlock / attention block (`h + x`, model/unet.py:187,232)
+ * without a separate axpy pass.
+ * The workspace needs no initialisation: every slot that is read was written by the same call. */
 size_t msgm_groupnorm_workspace(int32_t Bp, int32_t G);   /* bytes: double moment accumulators + float statistics */
 int msgm_groupnorm_dual_forward(const float* x, const float* gamma, const float* beta, float* out, float* stats,
                                 int32_t Bp, int32_t P, int32_t C, int32_t G, int32_t dual, int32_t silu, float eps,
                                 void* workspace, size_t workspace_bytes, msgm_stream_t stream);
 int msgm_groupnorm_dual_backward(const float* x, const float* gamma, const float* beta, const float* stats,
                                  const float* gout, float* gx, float* dgamma, float* dbeta, int32_t Bp, int32_t P,
-                                 int32_t C, int32_t G, int32_t silu, float eps, void* workspace, size_t workspace_bytes,
-                                 msgm_stream_t stream);
+                                 int32_t C, int32_t G, int32_t silu, float eps, const float* residual, void* workspace,
+                                 size_t workspace_bytes, msgm_stream_t stream);
 
 /* GroupNorm statistics only, returned as the per-(sample, channel) affine map y = scale x + shift
  * (scale = gamma/sigma, shift = beta - mean scale; [Bp][C0+C1] each) for a consumer that applies it while reading

@@ -495,9 +495,9 @@ class VorticityUNet(nn.Module, FlatParamMixin):
     def _groupnorms(self):
         return [m for m in self.modules() if isinstance(m, nn.GroupNorm)]
 
-    def _gn_bwd(self, gnm, xin, stats, g, Bp, P, C, silu):
+    def _gn_bwd(self, gnm, xin, stats, g, Bp, P, C, silu, residual=None):
         return ops.groupnorm_dual_backward(xin, gnm.weight.detach(), gnm.bias.detach(), stats, g, gnm.weight.grad, gnm.bias.grad,
-                                           Bp, P, C, gnm.num_groups, silu)
+                                           Bp, P, C, gnm.num_groups, silu, residual=residual)
 
     def _backward(self, tape, g, N, Bp):
         x = self._x
@@ -523,11 +523,10 @@ class VorticityUNet(nn.Module, FlatParamMixin):
                 deo = torch.empty(er * rb.co, device=dev)
                 (dh1,) = rb.conv1.backward(dh2, [h1], N, H, W, Bp, dsamp_bias=deo, emb_rows=er)
                 rb.lin.backward(deo, [semb], er, 1, 1, Bp, dsrc=[dsemb], dacc=[True])
-                dx = self._gn_bwd(rb.m.in_layers[0], xin, st1, dh1, Bp, P, rb.ci, True)
+                # identity skip: the `h + x` cotangent is added in the GroupNorm apply pass (no separate axpy)
+                dx = self._gn_bwd(rb.m.in_layers[0], xin, st1, dh1, Bp, P, rb.ci, True, residual=None if rb.skip is not None else dh)
                 if rb.skip is not None:
                     rb.skip.backward(dh, [xin], N, H, W, Bp, dsrc=[dx], dacc=[True])
-                else:
-                    ops.lincomb(dx, dx, 1.0, dh, 1.0)
                 dh = dx
             elif kind == "attn":
                 dh = self._attn_bwd(r, dh, N, Bp)
@@ -584,9 +583,7 @@ class VorticityUNet(nn.Module, FlatParamMixin):
         if Pm is None:                                                  # fused dual attention (Pd slot = its row stats)
             dqkv = ops.attention_dual_backward(qkv, att, datt, Pd, Bp, T, C, s2)
             (dhn,) = a.qkv.backward(dqkv, [hn], N, 1, T, Bp)
-            dx = self._gn_bwd(a.m.norm, xin, st, dhn, Bp, T, C, False)
-            ops.lincomb(dx, dx, 1.0, dout, 1.0)
-            return dx
+            return self._gn_bwd(a.m.norm, xin, st, dhn, Bp, T, C, False, residual=dout)     # x + proj(.): skip cotangent fused
         dqkv = torch.empty(N * T * ld, device=dev)                     # every slice is written exactly once below
         sP, sPt = (T * T, T, 1), (T * T, 1, T)                          # P(t,s) / P^T(s,t)
         sa, sq = (T * C, C, 1), (T * ld, ld, 1)
@@ -606,6 +603,4 @@ class VorticityUNet(nn.Module, FlatParamMixin):
         ops.bmm(Pdb, 0, qkv, half, dqkv, C, T, C, T, Bp, sPt, sq, sq, alpha=s2, pair2=(Pb, 0, qkv, 0),
                 third=(qkv, 0, dqkv, half + C))
         (dhn,) = a.qkv.backward(dqkv, [hn], N, 1, T, Bp)
-        dx = self._gn_bwd(a.m.norm, xin, st, dhn, Bp, T, C, False)
-        ops.lincomb(dx, dx, 1.0, dout, 1.0)
-        return dx
+        return self._gn_bwd(a.m.norm, xin, st, dhn, Bp, T, C, False, residual=dout)

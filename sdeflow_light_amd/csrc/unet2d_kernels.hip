@@ -48,6 +48,7 @@ struct GnArgs {
   int nch;      // pixel chunks (= slots) per sample of the reduce kernel that filled acc
   double* accf; // backward: the five moments summed over the slots, [Bp][G][8]
   float* pslots;// backward: dgamma | dbeta partials, [2][Bp * GN_SLOTS][C]
+  const float* resid;   // backward apply: added to gx (skip-branch cotangent), may alias gx
 };
 
 // V double partials per thread (channels V*cv .. V*cv+V-1 of pixel lane pl; per-thread fp32 sums over one sub-chunk
@@ -420,11 +421,12 @@ __global__ void __launch_bounds__(256) k_gn_bwd_apply(GnArgs A) {
       f32x4 o, od;
 #pragma unroll
       for (int k = 0; k < V; ++k) { o[k] = xb[k]; od[k] = xdb[k]; }
+      if (A.resid) { o += *reinterpret_cast<const f32x4*>(A.resid + e); od += *reinterpret_cast<const f32x4*>(A.resid + e + tot); }
       *reinterpret_cast<f32x4*>(A.gx + e) = o;
       *reinterpret_cast<f32x4*>(A.gx + e + tot) = od;
     } else {
-      A.gx[e] = xb[0];
-      A.gx[e + tot] = xdb[0];
+      A.gx[e] = xb[0] + (A.resid ? A.resid[e] : 0.f);
+      A.gx[e + tot] = xdb[0] + (A.resid ? A.resid[e + tot] : 0.f);
     }
   }
 }
@@ -828,7 +830,8 @@ int msgm_groupnorm_affine(const float* x0, int32_t C0, const float* x1, int32_t 
 
 int msgm_groupnorm_dual_backward(const float* x, const float* gamma, const float* beta, const float* stats, const float* gout,
                                  float* gx, float* dgamma, float* dbeta, int32_t Bp, int32_t P, int32_t C, int32_t G,
-                                 int32_t silu, float eps, void* workspace, size_t workspace_bytes, msgm_stream_t stream) {
+                                 int32_t silu, float eps, const float* residual, void* workspace, size_t workspace_bytes,
+                                 msgm_stream_t stream) {
   if (!x || !gamma || !beta || !stats || !gout || !gx || !dgamma || !dbeta || !workspace || Bp <= 0 || P <= 0 || C <= 0 || G <= 0)
     return MSGM_E_BADARG;
   if (C % G || C > 256 || G > 64) return MSGM_E_UNSUPPORTED;
@@ -841,6 +844,7 @@ int msgm_groupnorm_dual_backward(const float* x, const float* gamma, const float
   char* wsb = reinterpret_cast<char*>(workspace);
   A.accf = reinterpret_cast<double*>(wsb + gn_acc_bytes(Bp, G));
   A.pslots = reinterpret_cast<float*>(wsb + gn_acc_bytes(Bp, G) + gn_accf_bytes(Bp, G) + gn_stats_bytes(Bp, G));
+  A.resid = residual;
   if (C % 4 == 0) hipLaunchKernelGGL(k_gn_bwd_reduce<true>, dim3(Bp, nch), dim3(256), 0, S(stream), A);
   else hipLaunchKernelGGL(k_gn_bwd_reduce<false>, dim3(Bp, nch), dim3(256), 0, S(stream), A);
   hipLaunchKernelGGL(k_gn_bwd_finalize, dim3((Bp * G + 255) / 256), dim3(256), 0, S(stream), A);

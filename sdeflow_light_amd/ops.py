@@ -496,16 +496,19 @@ def groupnorm_dual_forward(x, gamma, beta, Bp, P, C, G, dual, silu, stats=None, 
     return out
 
 
-def groupnorm_dual_backward(x, gamma, beta, stats, gout, dgamma, dbeta, Bp, P, C, G, silu, gx=None, eps=1e-5):
+def groupnorm_dual_backward(x, gamma, beta, stats, gout, dgamma, dbeta, Bp, P, C, G, silu, gx=None, eps=1e-5, residual=None):
+    """``residual`` (same shape as x) is added to the returned cotangent in the apply pass (skip branch, no extra axpy)."""
     if x.numel() != 2 * Bp * P * C or gout.numel() != x.numel() or stats.numel() != Bp * G * 4:
         raise MsgmError("groupnorm backward: size mismatch")
     if dgamma.numel() != C or dbeta.numel() != C:
         raise MsgmError("groupnorm backward: dgamma/dbeta size")
     gx = gout if gx is None else gx
+    if residual is not None and residual.numel() != x.numel():
+        raise MsgmError("groupnorm backward: residual size")
     ws = _gn_ws(Bp, G, x.device)
     check(lib().msgm_groupnorm_dual_backward(ptr(f32(x)), ptr(f32(gamma)), ptr(f32(beta)), ptr(f32(stats)), ptr(f32(gout)),
                                              ptr(gx), ptr(dgamma), ptr(dbeta), Bp, P, C, G, int(bool(silu)), float(eps),
-                                             ptr(ws), ws.numel() * 8, stream()), "msgm_groupnorm_dual_backward")
+                                             ptr(residual), ptr(ws), ws.numel() * 8, stream()), "msgm_groupnorm_dual_backward")
     return gx
 
 

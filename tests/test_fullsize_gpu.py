@@ -1,12 +1,14 @@
-"""BASELINE full sizes of the U-Net configurations (C3, C4 shard, C5 chunk) on the GPU.  The CPU oracle needs minutes
-per sample at these sizes, so the checks are the size-independent properties the path has:
-rows never interact (GroupNorm is per sample, attention is per sample), so
+"""BASELINE full sizes of the U-Net configurations (C3, C4 shard, C5 chunk) on the GPU: size-independent PROPERTIES the
+path has.  (The oracle comparisons at these network shapes — 64x64x3 with T = 1024 attention, UNet1D
+L = 1024 — are in tests/test_round2_gpu.py at batch 2, where the float64 oracle takes seconds; here the batch is the
+config's own, which only properties can cover.)
+Rows never interact (GroupNorm is per sample, attention is per sample), so
   (i)  the per-sample losses of a batch are those of its two halves, and the mean gradient of the batch is the average
        of the two half-batch gradients — exactly the data-parallel equivalence the multi-GPU path relies on;
   (ii) the score of a row does not depend on which other rows share the launch.
 Per-row values are compared BIT FOR BIT: no kernel on the path lets the batch size choose the order of a row's
-arithmetic (the GroupNorm statistics are reduced over per-sample chunks of a fixed size and combined in double).
-Gradients: 1e-4 rel-L2 (weight gradients are float atomics over the batch).
+arithmetic (the GroupNorm statistics are reduced over per-sample chunks of a fixed size and combined in double, in a
+fixed order).  Gradients: 1e-4 rel-L2 (the slot-ordered sums group the batch differently for different batch sizes).
 Small-size parity against the oracle and the golden vectors of the same code paths: test_host_gpu.py (1-D),
 test_unet2d_gpu.py (2-D)."""
 import pytest

@@ -48,6 +48,13 @@ def test_groupnorm_dual_forward_backward(C, H, silu):
     assert rel_l2(gx[:half].cpu(), cl(xg.grad)) <= 2e-5, rel_l2(gx[:half].cpu(), cl(xg.grad))
     assert rel_l2(gx[half:].cpu(), cl(xdg.grad)) <= 2e-5
     assert rel_l2(dga.cpu(), gg.grad) <= 2e-5 and rel_l2(dbe.cpu(), bg.grad) <= 2e-5
+    # skip-branch cotangent added in the apply pass: gx + residual, same bits as a separate add
+    res = torch.randn(2 * half, device=DEV)
+    dga2, dbe2 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    gx2 = ops.groupnorm_dual_backward(xs, gam.to(DEV), bet.to(DEV), stats, gout.clone(), dga2, dbe2, B, P, C, G, silu, residual=res)
+    dga1 = torch.zeros(C, device=DEV)
+    gx1 = ops.groupnorm_dual_backward(xs, gam.to(DEV), bet.to(DEV), stats, gout.clone(), dga1, torch.zeros(C, device=DEV), B, P, C, G, silu)
+    assert torch.equal(gx2, gx1 + res) and torch.equal(dga2, dga1)     # (gout was overwritten in place by the first call above)
 
 
 def test_bmm_strided_and_softmax_dual():
