@@ -359,15 +359,43 @@ def kernel_probes(dev, Bp):
                 (f"k_attn_dual_fwd<{C // 16}> T={T} C={C}, batch {Bp} (msgm_attention_dual_forward)", 6 * prod,
                  lambda: ops.attention_dual_forward(qkv, Bp, T, C, s2), (qkv,))]
 
+    # order = share of the C4 step in the committed rocprofv3 kernel stats (profiles/r02/c4_b256_kernel_stats_v3.csv):
+    # the single largest kernel is the fused attention backward (19 %), then the 3x3 halo-tile conv (17 %), the tiled
+    # wgrad (12 %) and the attention forward (8 %)
+    probes += attn(1024, 64)
     probes.append(conv(32, 64, 64))
     probes.append(wgrad(32, 64, 64))
-    probes += attn(1024, 64)
+    share = {"k_attn_dual_bwd": 0.190, "k_attn_dual_fwd": 0.079, "k_conv_tile": 0.172, "k_wgrad_tile": 0.122}
+    pmc = {}
+    pj = os.path.join(ROOT, "profiles", "r02", "pmc_attention_bp256.json")
+    if os.path.exists(pj):
+        try:
+            pmc = json.load(open(pj))["kernels"]
+        except Exception:
+            pmc = {}
     res = []
     for name, flop, fn, keep in probes:
         tk = time_kernel_events(fn, 20, dev)
-        res.append({"kernel": name, "bound": "mfma", "achieved": flop / tk / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": flop / tk / 1e12 / PEAK_F32_MFMA_TFLOPS, "kernel_ms": tk * 1e3,
-                    "flop_per_launch": flop, "traffic": None})
+        r = {"kernel": name, "bound": "mfma", "achieved": flop / tk / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
+             "unit": "TFLOP/s", "frac": flop / tk / 1e12 / PEAK_F32_MFMA_TFLOPS, "kernel_ms": tk * 1e3,
+             "flop_per_launch": flop, "traffic": None,
+             "share_of_c4_step": next((v for k, v in share.items() if name.startswith(k)), None)}
+        if name.startswith("k_attn_dual_bwd") and Bp == 256:
+            r["executed_tflops"] = flop * 15 / 12 / tk / 1e12     # 15 products run (S / Sdot recomputed), 12 are algorithmic
+            t = [v.get("hbm_bytes") for k, v in pmc.items() if k.startswith(("void k_attn_dual_bwd<4> grid=2097152", "k_attn_dq_reduce grid=4194304",
+                                                                              "k_attn_dual_delta grid=4194304"))]
+            if len(t) == 3 and all(t):
+                r["traffic"] = float(sum(t))
+                r["traffic_source"] = ("profiles/r02/pmc_attention_bp256.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                       "tools/bench_attn.py, 2 x FETCH + WRITE, the three launches of the call; not measured in this run); "
+                                       "algorithmic bytes 0.81 GB (q, k, v, o, their tangents and cotangents once) — the rest is the 2.15 GB of "
+                                       "query-gradient slabs written and read back")
+        if name.startswith("k_attn_dual_fwd") and Bp == 256:
+            t = [v.get("hbm_bytes") for k, v in pmc.items() if k.startswith("void k_attn_dual_fwd<4, 1, 32> grid=1048576")]
+            if t and t[0]:
+                r["traffic"] = float(t[0])
+                r["traffic_source"] = "profiles/r02/pmc_attention_bp256.json (PMC pass, not measured in this run); algorithmic 0.54 GB"
+        res.append(r)
         del keep
     return res
 
@@ -425,8 +453,8 @@ def worker(a):
             probes = kernel_probes(dev, GLOBAL_BATCH[w]) if w == "c4" else []
             if probes:
                 # the dominant kernel of the C4 step (largest share in profiles/r02's rocprofv3 kernel stats) first
-                out["roofline"] = dict(probes[0], whole_step_frac=r["whole_step"]["frac_of_f32_mfma_peak"],
-                                       traffic_source="not measured in this run; PMC passes are under profiles/")
+                out["roofline"] = dict(probes[0], whole_step_frac=r["whole_step"]["frac_of_f32_mfma_peak"])
+                out["roofline"].setdefault("traffic_source", "not measured in this run; PMC passes are under profiles/")
                 out["roofline_other_kernels"] = probes[1:]
             else:
                 ws = r["whole_step"]
