@@ -406,6 +406,17 @@ int msgm_groupnorm_dual_backward(const float* x, const float* gamma, const float
                                  const float* gout, float* gx, float* dgamma, float* dbeta, int32_t Bp, int32_t P,
                                  int32_t C, int32_t G, int32_t silu, float eps, const float* residual, void* workspace,
                                  size_t workspace_bytes, msgm_stream_t stream);
+/* The same pair for an input that is the channel concatenation of TWO tensors (x0: C0 channels, x1: C1; the decoder's
+ * cat([h, skip]), model/unet.py:514) without materialising the concatenation: forward reads both and writes ONE
+ * normalised tensor of C0 + C1 channels; backward reads both and writes the input cotangent into gx0 / gx1 (each shaped
+ * like its source).  C0 % 4 == 0 and C1 % 4 == 0. */
+int msgm_groupnorm_dual_forward2(const float* x0, int32_t C0, const float* x1, int32_t C1, const float* gamma,
+                                 const float* beta, float* out, float* stats, int32_t Bp, int32_t P, int32_t G, int32_t dual,
+                                 int32_t silu, float eps, void* workspace, size_t workspace_bytes, msgm_stream_t stream);
+int msgm_groupnorm_dual_backward2(const float* x0, int32_t C0, const float* x1, int32_t C1, const float* gamma,
+                                  const float* beta, const float* stats, const float* gout, float* gx0, float* gx1,
+                                  float* dgamma, float* dbeta, int32_t Bp, int32_t P, int32_t G, int32_t silu, float eps,
+                                  void* workspace, size_t workspace_bytes, msgm_stream_t stream);
 
 /* GroupNorm statistics only, returned as the per-(sample, channel) affine map y = scale x + shift
  * (scale = gamma/sigma, shift = beta - mean scale; [Bp][C0+C1] each) for a consumer that applies it while reading

@@ -154,6 +154,7 @@ class _Res:
             ConvOp(m.skip_connection.weight, m.skip_connection.bias, "conv", (1, 1), 1, 0, [ci])
         self.ops = [self.conv1, self.lin, self.conv2] + ([self.skip] if self.skip else [])
         self.conv1_2 = self.skip_2 = None      # two-source twins for decoder blocks (sampler path, see make_two_source)
+        self.skip_2t = None                    # the skip twin of the TRAINING path (its own gradient image)
         self.split = None
 
     def make_two_source(self, C0: int, C1: int):
@@ -166,6 +167,9 @@ class _Res:
         self.split = (C0, C1)
         self.conv1_2 = ConvOp(m.in_layers[2].weight, m.in_layers[2].bias, "conv", (3, 3), 1, 1, [C0, C1])
         self.skip_2 = ConvOp(m.skip_connection.weight, m.skip_connection.bias, "conv", (1, 1), 1, 0, [C0, C1])
+        # training: GroupNorm reads the two tensors and writes ONE normalised tensor (conv1 stays single-source); only the
+        # 1x1 skip conv needs a two-source twin, with its own gradient image (it REPLACES self.skip on that path)
+        self.skip_2t = ConvOp(m.skip_connection.weight, m.skip_connection.bias, "conv", (1, 1), 1, 0, [C0, C1])
         return [self.conv1_2, self.skip_2]
 
 
@@ -253,6 +257,8 @@ class VorticityUNet(nn.Module, FlatParamMixin):
             if kind == "res" and res.skip is not None and res.ci > Cs and (res.ci - Cs) % 16 == 0 and Cs % 16 == 0:
                 twins += res.make_two_source(res.ci - Cs, Cs)
         x["set2"] = ConvOpSet(twins) if twins else None
+        tw_t = [o.skip_2t for blk in x["outb"] for kind, o in blk if kind == "res" and o.skip_2t is not None]
+        x["set2t"] = ConvOpSet(tw_t) if tw_t else None
         self._x = x
         return x
 
@@ -270,6 +276,19 @@ class VorticityUNet(nn.Module, FlatParamMixin):
     def _res_fwd(self, r: _Res, x, N, Bp, H, W, semb, dual, tape, er):
         P = H * W
         eo, _, _ = r.lin.forward([semb], er, 1, 1, Bp)           # er rows carry an embedding (N with log-radius conditioning)
+        if isinstance(x, tuple) and tape is not None:            # training, decoder block: cat([h, skip]) never materialised
+            h0, s0 = x
+            C0, C1 = r.split
+            gnm = r.m.in_layers[0]
+            st1 = torch.empty(Bp * gnm.num_groups * 4, device=h0.device)
+            h1 = ops.groupnorm_dual_forward2(h0, C0, s0, C1, gnm.weight.detach(), gnm.bias.detach(), Bp, P, gnm.num_groups, dual, True,
+                                             stats=st1)
+            h2, _, _ = r.conv1.forward([h1], N, H, W, Bp, samp_bias=eo, emb_rows=er)
+            h3, st2 = self._gn(r.m.out_layers[0], h2, Bp, P, r.co, dual, True, tape)
+            out, _, _ = r.skip_2t.forward([h0, s0], N, H, W, Bp)
+            r.conv2.forward([h3], N, H, W, Bp, out=out, accumulate=True)
+            tape.append(("res2", r, h0, s0, H, W, h1, st1, h2, st2, h3))
+            return out
         if isinstance(x, tuple):                                 # (h, skip): decoder block without the concatenation
             h0, s0 = x
             C0, C1 = r.split
@@ -412,11 +431,19 @@ class VorticityUNet(nn.Module, FlatParamMixin):
                 tape.append(("save_skip",))
         h, C, H, W = run_block(x["mid"], h, C, H, W)
         nocat = (not dual and tape is None and x["set2"] is not None and not os.environ.get("MSGM_NO_GN_FOLD"))
+        nocat_t = tape is not None and dual and x["set2t"] is not None and not os.environ.get("MSGM_TRAIN_CAT")
         if nocat:
             x["set2"].pack()
+        if nocat_t:
+            x["set2t"].pack()
         for blk in x["outb"]:
             s, Cs = hs.pop()
             r0 = blk[0][1]
+            if nocat_t and blk[0][0] == "res" and r0.split == (C, Cs) and r0.skip_2t is not None:
+                # training path: GroupNorm, the skip conv and their backward read h and the skip tensor as two sources
+                h = self._res_fwd(r0, (h, s), N, Bp, H, W, semb, dual, tape, er)
+                h, C, H, W = run_block(blk[1:], h, r0.co, H, W)
+                continue
             if nocat and blk[0][0] == "res" and r0.split == (C, Cs) and r0.conv1_2.can_transform_input(N, H, W):
                 # sampler path: the decoder ResBlock reads h and the skip tensor as two sources — no concatenation
                 h = self._res_fwd(r0, (h, s), N, Bp, H, W, semb, dual, tape, er)
@@ -474,6 +501,8 @@ class VorticityUNet(nn.Module, FlatParamMixin):
                 break
         x = self._build()
         x["set"].zero_grad_images(bias_grads_zeroed=True)
+        if x["set2t"] is not None:
+            x["set2t"].zero_grad_images(bias_grads_zeroed=True)
         flat, gflat = self.flat_parameters()
         gflat.zero_()                    # GroupNorm parameter gradients are accumulated with atomics; one memset for all
         forder = self.flatten_order == "F"
@@ -490,6 +519,8 @@ class VorticityUNet(nn.Module, FlatParamMixin):
         gimg = ops.flat_to_image(g.view(N, d), N, Cc, S_, S_, forder, float(scale_image))   # adjoint of (x5, unflatten)
         self._backward(tape, gimg, N, B)
         x["set"].unpack_grads()
+        if x["set2t"] is not None and any(rec[0] == "res2" for rec in tape):
+            x["set2t"].unpack_grads()            # after "set": the twins' images replace the (unused, zero) single-source ones
         return per
 
     def _groupnorms(self):
@@ -528,6 +559,21 @@ class VorticityUNet(nn.Module, FlatParamMixin):
                 if rb.skip is not None:
                     rb.skip.backward(dh, [xin], N, H, W, Bp, dsrc=[dx], dacc=[True])
                 dh = dx
+            elif kind == "res2":                                   # decoder ResBlock on (h, skip) without the concatenation
+                _, rb, h0, s0, H, W, h1, st1, h2, st2, h3 = r
+                P = H * W
+                C0, C1 = rb.split
+                (dh3,) = rb.conv2.backward(dh, [h3], N, H, W, Bp)
+                dh2 = self._gn_bwd(rb.m.out_layers[0], h2, st2, dh3, Bp, P, rb.co, True)
+                deo = torch.empty(er * rb.co, device=dev)
+                (dh1,) = rb.conv1.backward(dh2, [h1], N, H, W, Bp, dsamp_bias=deo, emb_rows=er)
+                rb.lin.backward(deo, [semb], er, 1, 1, Bp, dsrc=[dsemb], dacc=[True])
+                gnm = rb.m.in_layers[0]
+                dx0, dx1 = ops.groupnorm_dual_backward2(h0, C0, s0, C1, gnm.weight.detach(), gnm.bias.detach(), st1, dh1,
+                                                        gnm.weight.grad, gnm.bias.grad, Bp, P, gnm.num_groups, True)
+                rb.skip_2t.backward(dh, [h0, s0], N, H, W, Bp, dsrc=[dx0, dx1], dacc=[True, True])
+                pend.append(dx1)                                    # cotangent of the skip tensor, consumed by the encoder
+                dh = dx0
             elif kind == "attn":
                 dh = self._attn_bwd(r, dh, N, Bp)
             elif kind == "conv":

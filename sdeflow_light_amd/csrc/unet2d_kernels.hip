@@ -42,8 +42,11 @@ struct GnArgs {
   float eps;
   // backward
   const float* gout; float* gx; float* dgamma; float* dbeta;
-  // forward statistics over the channel concatenation of two tensors (x: C0 channels, x1: C - C0), no tangent
+  // input = channel concatenation of two tensors (x: C0 channels, x1: C - C0; both (primal | tangent) stacked when
+  // dual): the decoder's cat([h, skip]) (model/unet.py:514) is never materialised.  out / gout stay ONE tensor of C
+  // channels; the backward writes the input cotangent into gx (C0 channels) and gx1 (C - C0).
   const float* x1; int C0;
+  float* gx1;
   int sub;      // reduce kernels: pixels per fp32 partial sum — fixed per sample, whatever the batch size
   int nch;      // pixel chunks (= slots) per sample of the reduce kernel that filled acc
   double* accf; // backward: the five moments summed over the slots, [Bp][G][8]
@@ -183,6 +186,17 @@ __global__ void __launch_bounds__(256) k_gn_affine(GnArgs A, float* __restrict__
 // Elementwise pass.  VEC: grid (pixel chunk, sample); a thread owns 4 consecutive channels (its statistics and
 // affine parameters are loaded once) and walks over pixels — 16-B loads/stores, consecutive threads on consecutive
 // addresses.  !VEC (C % 4 != 0): one thread per channel, same walk.
+// element offset of (sample b, pixel p, channel c) of the possibly two-source input: `pitch` / `coff` select the source
+// of this thread's channel vector (a vector never straddles the sources: C0 % 4 == 0), `half` is the primal -> tangent
+// offset of that source
+struct GnSrc { const float* base; long half; int pitch; };
+__device__ __forceinline__ GnSrc gn_src(const GnArgs& A, int c) {
+  const int C0 = A.x1 ? A.C0 : A.C;
+  const bool second = c >= C0;
+  const int pitch = second ? A.C - C0 : C0;
+  return GnSrc{(second ? A.x1 : A.x) + (second ? c - C0 : c), (long)A.Bp * A.P * pitch, pitch};
+}
+
 template <bool VEC>
 __global__ void __launch_bounds__(256) k_gn_fwd_apply(GnArgs A, const float* __restrict__ wstats) {
   constexpr int V = VEC ? 4 : 1;
@@ -201,21 +215,23 @@ __global__ void __launch_bounds__(256) k_gn_fwd_apply(GnArgs A, const float* __r
     ga[k] = A.gamma[c]; be[k] = A.beta[c];
   }
   const int p0 = blockIdx.x * A.chunk, p1 = min(p0 + A.chunk, P);
+  const GnSrc sx = gn_src(A, V * cv);
   for (int p = p0 + pl; p < p1; p += PL) {
     const long e = ((long)b * P + p) * C + V * cv;
+    const long ex = ((long)b * P + p) * sx.pitch;
     float x[V], xd[V], y[V], yd[V];
     if (VEC) {
-      const f32x4 xv = *reinterpret_cast<const f32x4*>(A.x + e);
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(sx.base + ex);
 #pragma unroll
       for (int k = 0; k < V; ++k) x[k] = xv[k];
       if (A.dual) {
-        const f32x4 dv = *reinterpret_cast<const f32x4*>(A.x + e + tot);
+        const f32x4 dv = *reinterpret_cast<const f32x4*>(sx.base + ex + sx.half);
 #pragma unroll
         for (int k = 0; k < V; ++k) xd[k] = dv[k];
       }
     } else {
-      x[0] = A.x[e];
-      if (A.dual) xd[0] = A.x[e + tot];
+      x[0] = sx.base[ex];
+      if (A.dual) xd[0] = sx.base[ex + sx.half];
     }
 #pragma unroll
     for (int k = 0; k < V; ++k) {
@@ -266,6 +282,7 @@ __global__ void __launch_bounds__(256) k_gn_bwd_reduce(GnArgs A) {
     ga[k] = A.gamma[c]; be[k] = A.beta[c];
   }
   const int p0 = blockIdx.y * A.chunk, p1 = min(p0 + A.chunk, P);
+  const GnSrc sx = gn_src(A, V * cv);
   double dX[V], dXx[V], dW[V], dWx[V], dWw[V];
   float dga[V], dbe[V];
 #pragma unroll
@@ -278,14 +295,15 @@ __global__ void __launch_bounds__(256) k_gn_bwd_reduce(GnArgs A) {
     for (int k = 0; k < V; ++k) { sX[k] = sXx[k] = sW[k] = sWx[k] = sWw[k] = 0.f; }
     for (int p = ps + pl; p < pe; p += PL) {
       const long e = ((long)b * P + p) * C + V * cv;
+      const long ex = ((long)b * P + p) * sx.pitch;
       float x[V], xd[V], zb[V], zdb[V];
       if (VEC) {
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(A.x + e), v1 = *reinterpret_cast<const f32x4*>(A.x + e + tot);
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(sx.base + ex), v1 = *reinterpret_cast<const f32x4*>(sx.base + ex + sx.half);
         const f32x4 v2 = *reinterpret_cast<const f32x4*>(A.gout + e), v3 = *reinterpret_cast<const f32x4*>(A.gout + e + tot);
 #pragma unroll
         for (int k = 0; k < V; ++k) { x[k] = v0[k]; xd[k] = v1[k]; zb[k] = v2[k]; zdb[k] = v3[k]; }
       } else {
-        x[0] = A.x[e]; xd[0] = A.x[e + tot]; zb[0] = A.gout[e]; zdb[0] = A.gout[e + tot];
+        x[0] = sx.base[ex]; xd[0] = sx.base[ex + sx.half]; zb[0] = A.gout[e]; zdb[0] = A.gout[e + tot];
       }
 #pragma unroll
       for (int k = 0; k < V; ++k) {
@@ -389,16 +407,21 @@ __global__ void __launch_bounds__(256) k_gn_bwd_apply(GnArgs A) {
     ga[k] = A.gamma[c]; be[k] = A.beta[c];
   }
   const int p0 = blockIdx.x * A.chunk, p1 = min(p0 + A.chunk, P);
+  const GnSrc sx = gn_src(A, V * cv);
+  // destination of the input cotangent: the source's own tensor when the input is a concatenation
+  float* gbase = A.x1 ? ((V * cv >= A.C0) ? A.gx1 + (V * cv - A.C0) : A.gx + V * cv) : A.gx + V * cv;
+  const float* rbase = A.resid ? A.resid + V * cv : nullptr;            // single-source only (host checks)
   for (int p = p0 + pl; p < p1; p += PL) {
     const long e = ((long)b * P + p) * C + V * cv;
+    const long ex = ((long)b * P + p) * sx.pitch;
     float x[V], xd[V], zb[V], zdb[V], xb[V], xdb[V];
     if (VEC) {
-      const f32x4 v0 = *reinterpret_cast<const f32x4*>(A.x + e), v1 = *reinterpret_cast<const f32x4*>(A.x + e + tot);
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(sx.base + ex), v1 = *reinterpret_cast<const f32x4*>(sx.base + ex + sx.half);
       const f32x4 v2 = *reinterpret_cast<const f32x4*>(A.gout + e), v3 = *reinterpret_cast<const f32x4*>(A.gout + e + tot);
 #pragma unroll
       for (int k = 0; k < V; ++k) { x[k] = v0[k]; xd[k] = v1[k]; zb[k] = v2[k]; zdb[k] = v3[k]; }
     } else {
-      x[0] = A.x[e]; xd[0] = A.x[e + tot]; zb[0] = A.gout[e]; zdb[0] = A.gout[e + tot];
+      x[0] = sx.base[ex]; xd[0] = sx.base[ex + sx.half]; zb[0] = A.gout[e]; zdb[0] = A.gout[e + tot];
     }
 #pragma unroll
     for (int k = 0; k < V; ++k) {
@@ -421,12 +444,12 @@ __global__ void __launch_bounds__(256) k_gn_bwd_apply(GnArgs A) {
       f32x4 o, od;
 #pragma unroll
       for (int k = 0; k < V; ++k) { o[k] = xb[k]; od[k] = xdb[k]; }
-      if (A.resid) { o += *reinterpret_cast<const f32x4*>(A.resid + e); od += *reinterpret_cast<const f32x4*>(A.resid + e + tot); }
-      *reinterpret_cast<f32x4*>(A.gx + e) = o;
-      *reinterpret_cast<f32x4*>(A.gx + e + tot) = od;
+      if (rbase) { o += *reinterpret_cast<const f32x4*>(rbase + ex); od += *reinterpret_cast<const f32x4*>(rbase + ex + sx.half); }
+      *reinterpret_cast<f32x4*>(gbase + ex) = o;
+      *reinterpret_cast<f32x4*>(gbase + ex + sx.half) = od;
     } else {
-      A.gx[e] = xb[0] + (A.resid ? A.resid[e] : 0.f);
-      A.gx[e + tot] = xdb[0] + (A.resid ? A.resid[e + tot] : 0.f);
+      gbase[ex] = xb[0] + (rbase ? rbase[ex] : 0.f);
+      gbase[ex + sx.half] = xdb[0] + (rbase ? rbase[ex + sx.half] : 0.f);
     }
   }
 }
@@ -788,14 +811,14 @@ size_t msgm_groupnorm_workspace(int32_t Bp, int32_t G) {
   return gn_acc_bytes(Bp, G) + gn_accf_bytes(Bp, G) + gn_stats_bytes(Bp, G) + (size_t)2 * Bp * GN_SLOTS * 256 * sizeof(float);
 }
 
-int msgm_groupnorm_dual_forward(const float* x, const float* gamma, const float* beta, float* out, float* stats, int32_t Bp,
-                                int32_t P, int32_t C, int32_t G, int32_t dual, int32_t silu, float eps, void* workspace,
-                                size_t workspace_bytes, msgm_stream_t stream) {
+static int gn_forward_impl(const float* x, int32_t C0, const float* x1, int32_t C, const float* gamma, const float* beta, float* out,
+                           float* stats, int32_t Bp, int32_t P, int32_t G, int32_t dual, int32_t silu, float eps, void* workspace,
+                           size_t workspace_bytes, msgm_stream_t stream) {
   if (!x || !gamma || !beta || !out || !workspace || Bp <= 0 || P <= 0 || C <= 0 || G <= 0) return MSGM_E_BADARG;
-  if (C % G || C > 256 || G > 64) return MSGM_E_UNSUPPORTED;
+  if (C % G || C > 256 || G > 64 || (x1 && (C0 % 4 || (C - C0) % 4 || C0 <= 0 || C0 >= C))) return MSGM_E_UNSUPPORTED;
   if (workspace_bytes < msgm_groupnorm_workspace(Bp, G)) return MSGM_E_WORKSPACE;
   GnArgs A{x, gamma, beta, out, reinterpret_cast<double*>(workspace), stats, P, C, G, Bp, dual, silu, 0, eps,
-           nullptr, nullptr, nullptr, nullptr};
+           nullptr, nullptr, nullptr, nullptr, x1, C0};
   float* wstats = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + gn_acc_bytes(Bp, G) + gn_accf_bytes(Bp, G));
   const int nch = gn_chunks(Bp, P, &A.chunk, &A.sub);
   if (nch > GN_SLOTS) return MSGM_E_UNSUPPORTED;
@@ -807,6 +830,19 @@ int msgm_groupnorm_dual_forward(const float* x, const float* gamma, const float*
   if (C % 4 == 0) hipLaunchKernelGGL(k_gn_fwd_apply<true>, dim3(nap, Bp), dim3(256), 0, S(stream), A, (const float*)wstats);
   else hipLaunchKernelGGL(k_gn_fwd_apply<false>, dim3(nap, Bp), dim3(256), 0, S(stream), A, (const float*)wstats);
   return msgm_check_launch();
+}
+
+int msgm_groupnorm_dual_forward(const float* x, const float* gamma, const float* beta, float* out, float* stats, int32_t Bp,
+                                int32_t P, int32_t C, int32_t G, int32_t dual, int32_t silu, float eps, void* workspace,
+                                size_t workspace_bytes, msgm_stream_t stream) {
+  return gn_forward_impl(x, C, nullptr, C, gamma, beta, out, stats, Bp, P, G, dual, silu, eps, workspace, workspace_bytes, stream);
+}
+
+int msgm_groupnorm_dual_forward2(const float* x0, int32_t C0, const float* x1, int32_t C1, const float* gamma, const float* beta,
+                                 float* out, float* stats, int32_t Bp, int32_t P, int32_t G, int32_t dual, int32_t silu, float eps,
+                                 void* workspace, size_t workspace_bytes, msgm_stream_t stream) {
+  if (!x1 || C1 <= 0) return MSGM_E_BADARG;
+  return gn_forward_impl(x0, C0, x1, C0 + C1, gamma, beta, out, stats, Bp, P, G, dual, silu, eps, workspace, workspace_bytes, stream);
 }
 
 int msgm_groupnorm_affine(const float* x0, int32_t C0, const float* x1, int32_t C1, const float* gamma, const float* beta,
@@ -828,16 +864,17 @@ int msgm_groupnorm_affine(const float* x0, int32_t C0, const float* x1, int32_t 
   return msgm_check_launch();
 }
 
-int msgm_groupnorm_dual_backward(const float* x, const float* gamma, const float* beta, const float* stats, const float* gout,
-                                 float* gx, float* dgamma, float* dbeta, int32_t Bp, int32_t P, int32_t C, int32_t G,
-                                 int32_t silu, float eps, const float* residual, void* workspace, size_t workspace_bytes,
-                                 msgm_stream_t stream) {
+static int gn_backward_impl(const float* x, int32_t C0, const float* x1, int32_t C, const float* gamma, const float* beta,
+                            const float* stats, const float* gout, float* gx, float* gx1, float* dgamma, float* dbeta, int32_t Bp,
+                            int32_t P, int32_t G, int32_t silu, float eps, const float* residual, void* workspace,
+                            size_t workspace_bytes, msgm_stream_t stream) {
   if (!x || !gamma || !beta || !stats || !gout || !gx || !dgamma || !dbeta || !workspace || Bp <= 0 || P <= 0 || C <= 0 || G <= 0)
     return MSGM_E_BADARG;
   if (C % G || C > 256 || G > 64) return MSGM_E_UNSUPPORTED;
+  if (x1 && (!gx1 || residual || C0 % 4 || (C - C0) % 4 || C0 <= 0 || C0 >= C)) return MSGM_E_UNSUPPORTED;
   if (workspace_bytes < msgm_groupnorm_workspace(Bp, G)) return MSGM_E_WORKSPACE;
   GnArgs A{x, gamma, beta, nullptr, reinterpret_cast<double*>(workspace), const_cast<float*>(stats), P, C, G, Bp, 1, silu, 0,
-           eps, gout, gx, dgamma, dbeta};
+           eps, gout, gx, dgamma, dbeta, x1, C0, gx1};
   const int nch = gn_chunks(Bp, P, &A.chunk, &A.sub);
   if (nch > GN_SLOTS) return MSGM_E_UNSUPPORTED;
   A.nch = nch;
@@ -854,6 +891,23 @@ int msgm_groupnorm_dual_backward(const float* x, const float* gamma, const float
   if (C % 4 == 0) hipLaunchKernelGGL(k_gn_bwd_apply<true>, dim3(nap, Bp), dim3(256), 0, S(stream), A);
   else hipLaunchKernelGGL(k_gn_bwd_apply<false>, dim3(nap, Bp), dim3(256), 0, S(stream), A);
   return msgm_check_launch();
+}
+
+int msgm_groupnorm_dual_backward(const float* x, const float* gamma, const float* beta, const float* stats, const float* gout,
+                                 float* gx, float* dgamma, float* dbeta, int32_t Bp, int32_t P, int32_t C, int32_t G,
+                                 int32_t silu, float eps, const float* residual, void* workspace, size_t workspace_bytes,
+                                 msgm_stream_t stream) {
+  return gn_backward_impl(x, C, nullptr, C, gamma, beta, stats, gout, gx, nullptr, dgamma, dbeta, Bp, P, G, silu, eps, residual,
+                          workspace, workspace_bytes, stream);
+}
+
+int msgm_groupnorm_dual_backward2(const float* x0, int32_t C0, const float* x1, int32_t C1, const float* gamma, const float* beta,
+                                  const float* stats, const float* gout, float* gx0, float* gx1, float* dgamma, float* dbeta,
+                                  int32_t Bp, int32_t P, int32_t G, int32_t silu, float eps, void* workspace,
+                                  size_t workspace_bytes, msgm_stream_t stream) {
+  if (!x1 || C1 <= 0) return MSGM_E_BADARG;
+  return gn_backward_impl(x0, C0, x1, C0 + C1, gamma, beta, stats, gout, gx0, gx1, dgamma, dbeta, Bp, P, G, silu, eps, nullptr,
+                          workspace, workspace_bytes, stream);
 }
 
 int msgm_bmm(const float* A, const float* B, const float* A2, const float* B2, float* C, int32_t M, int32_t N, int32_t K,

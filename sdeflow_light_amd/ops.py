@@ -512,6 +512,31 @@ def groupnorm_dual_backward(x, gamma, beta, stats, gout, dgamma, dbeta, Bp, P, C
     return gx
 
 
+def groupnorm_dual_forward2(x0, C0, x1, C1, gamma, beta, Bp, P, G, dual, silu, stats=None, eps=1e-5):
+    """GroupNorm(+SiLU) of the channel concatenation [x0 | x1] without materialising it: ONE normalised output tensor."""
+    n = (2 if dual else 1) * Bp * P
+    if x0.numel() != n * C0 or x1.numel() != n * C1:
+        raise MsgmError("groupnorm2: size mismatch")
+    out = torch.empty(n * (C0 + C1), dtype=torch.float32, device=x0.device)
+    ws = _gn_ws(Bp, G, x0.device)
+    check(lib().msgm_groupnorm_dual_forward2(ptr(f32(x0)), C0, ptr(f32(x1)), C1, ptr(f32(gamma)), ptr(f32(beta)), ptr(out), ptr(stats),
+                                             Bp, P, G, int(bool(dual)), int(bool(silu)), float(eps), ptr(ws), ws.numel() * 8, stream()),
+          "msgm_groupnorm_dual_forward2")
+    return out
+
+
+def groupnorm_dual_backward2(x0, C0, x1, C1, gamma, beta, stats, gout, dgamma, dbeta, Bp, P, G, silu, eps=1e-5):
+    """Backward of ``groupnorm_dual_forward2``: the input cotangent as two tensors shaped like x0 / x1."""
+    if gout.numel() != 2 * Bp * P * (C0 + C1) or x0.numel() != 2 * Bp * P * C0 or x1.numel() != 2 * Bp * P * C1:
+        raise MsgmError("groupnorm2 backward: size mismatch")
+    gx0, gx1 = torch.empty_like(x0), torch.empty_like(x1)
+    ws = _gn_ws(Bp, G, x0.device)
+    check(lib().msgm_groupnorm_dual_backward2(ptr(f32(x0)), C0, ptr(f32(x1)), C1, ptr(f32(gamma)), ptr(f32(beta)), ptr(f32(stats)),
+                                              ptr(f32(gout)), ptr(gx0), ptr(gx1), ptr(dgamma), ptr(dbeta), Bp, P, G, int(bool(silu)),
+                                              float(eps), ptr(ws), ws.numel() * 8, stream()), "msgm_groupnorm_dual_backward2")
+    return gx0, gx1
+
+
 def bmm(A, a_off, B, b_off, Cm, c_off, M, N, K, batch, sA, sB, sC, alpha=1.0, accumulate=False, pair2=None, third=None):
     """C[b](i,j) (+)= alpha (sum_k A[b](i,k) B[b](k,j) [+ A2.B2]); sA = (batch, i, k), sB = (batch, k, j),
     sC = (batch, i, j) element strides; *_off are element offsets into the given tensors (channel slices of a fused

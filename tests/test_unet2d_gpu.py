@@ -542,3 +542,27 @@ def test_fused_dual_attention_forward_backward(Bp, T, C):
     # deterministic: a second backward gives the same bits (slab reduction in block order, no atomics)
     dq2 = ops.attention_dual_backward(dev_qkv, att, g.to(DEV).contiguous().view(-1), stats, Bp, T, C, 1.0 / math.sqrt(C))
     assert torch.equal(dq, dq2)
+
+
+def test_training_decoder_without_cat_equals_cat_path(monkeypatch):
+    """Training path: the decoder's cat([h, skip]) (model/unet.py:514) is never materialised — GroupNorm, the 1x1 skip conv
+    and their backward read the two tensors as two sources.  Same loss and gradients as the path that concatenates."""
+    from test_host_gpu import make_gen
+    torch.manual_seed(5)
+    gen = make_gen("sgm", _vunet(32, "F"))
+    B, d = 3, 1024
+    x, u, eps, uv = torch.randn(B, d, device=DEV), torch.rand(B, device=DEV), torch.randn(B, d, device=DEV), torch.rand(B, d, device=DEV)
+    res = {}
+    for cat in (False, True):
+        if cat:
+            monkeypatch.setenv("MSGM_TRAIN_CAT", "1")
+        gen.zero_grad()
+        per = gen.ssm(x, u=u, eps=eps, u_v=uv)
+        per.mean().backward()
+        res[cat] = (per.detach().clone(), {k: p.grad.detach().clone() for k, p in gen.a.named_parameters()})
+    from conftest import within
+    within(rel_l2(res[False][0].cpu(), res[True][0].cpu()), 1e-6, "no-cat vs cat training path: per-sample loss")
+    worst = max(rel_l2(res[False][1][k].cpu(), g.cpu()) for k, g in res[True][1].items() if float(g.norm()) > 1e-3 * max(float(v.norm()) for v in res[True][1].values()))
+    within(worst, 1e-5, "no-cat vs cat training path: worst parameter-gradient tensor")
+    skipw = [k for k in res[True][1] if "output_blocks" in k and "skip_connection.weight" in k]
+    assert skipw and all(float(res[False][1][k].abs().max()) > 0 for k in skipw)       # the twin's gradient reached the parameter
