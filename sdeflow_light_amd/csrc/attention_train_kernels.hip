@@ -246,8 +246,8 @@ __global__ void __launch_bounds__(512) k_attn_dual_bwd(const float* __restrict__
   float* Gs = Qd + QB * KP;
   float* Gd = Gs + QB * KP;
   float* St = Gd + QB * KP;                               // [4][32] row scalars
-  float* dS = St + 4 * QB;                                // [32][DP] Sbar
-  float* dSd = dS + QB * DP;                              // [32][DP] Sdbar
+  float* dS0 = St + 4 * QB;                               // 2 x ([32][DP] Sbar | [32][DP] Sdbar): double-buffered, so the
+                                                          // next block's phase 1 may start while a slow wave is still in phase 2
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, il = lane & 15, q = lane >> 4;
   const int qs = w & 1, kg = w >> 1;
   int smp, kb;                                             // XCD-aware order (see the forward kernel): the key blocks
@@ -298,7 +298,10 @@ __global__ void __launch_bounds__(512) k_attn_dual_bwd(const float* __restrict__
   gload(0);
   const int nqb = T / QB;
   for (int qb = 0; qb < nqb; ++qb) {
-    __syncthreads();                                       // [A] phase-2 readers of the previous block are done
+    float* dS = dS0 + (qb & 1) * (2 * QB * DP);
+    float* dSd = dS + QB * DP;
+    // no barrier here: every wave has passed [C] of the previous block, i.e. finished READING Q / Qd / G / Gd and the row
+    // scalars; phase 2 of the previous block only reads its own dS buffer and the resident K tiles
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
       const int idx = tid + 512 * i, qr = idx / (C / 4), c4 = idx - qr * (C / 4);
@@ -309,7 +312,7 @@ __global__ void __launch_bounds__(512) k_attn_dual_bwd(const float* __restrict__
       *reinterpret_cast<f32x4*>(Gd + qr * KP + 4 * c4) = pgd[i];
     }
     if (tid < 4 * QB) St[tid] = pst;
-    __syncthreads();                                       // [B]
+    __syncthreads();                                       // [B] staged block visible
     if (qb + 1 < nqb) gload(qb + 1);
 
     // ---- phase 1a: S, Sd, Pbar, D for (queries 16qs.., keys 16kg..); D layout: lane (key il, queries 4q+r)
@@ -459,7 +462,7 @@ template <int CT>
 static int launch_bwd(const float* qkv, const float* att, const float* datt, const float* stats, float* dqkv, int64_t Bp, int T,
                       float scale, float* ws, hipStream_t st) {
   constexpr int C = 16 * CT, KP = C + 4;
-  constexpr size_t lds = ((size_t)4 * 64 * KP + 4 * 32 * KP + 4 * 32 + 2 * 32 * 68) * sizeof(float);
+  constexpr size_t lds = ((size_t)4 * 64 * KP + 4 * 32 * KP + 4 * 32 + 4 * 32 * 68) * sizeof(float);
   static const int once = [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_dual_bwd<CT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);

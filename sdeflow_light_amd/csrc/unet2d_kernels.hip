@@ -580,6 +580,143 @@ __global__ void __launch_bounds__(256) k_bmm(BmmArgs P) {
   }
 }
 
+// ------------------------------------------------------------------ batched GEMM, LDS-staged
+// The same contract as k_bmm (BmmArgs), for operands with ONE unit stride each: a workgroup owns a 64 x 64 output tile
+// and walks K in blocks of 32.  Per block the A rows [64][32], the B columns [64][32] (and the A3 rows when DUAL) are
+// brought in with coalesced 16-byte global loads — along k when k is the contiguous index (KV), along the row index when
+// the operand is stored transposed (RV: the float4 is scattered into four LDS rows) — into a canonical [row][k] LDS image
+// (pitch 36 floats), double-buffered, with the next block's loads in flight during this block's MFMAs.  Every wave then
+// reads its fragments with ds_read_b128, like k_conv_tile.  k_bmm (register-direct, no LDS) stays as the fallback for
+// operands without a unit stride / unaligned bases.
+#define BL_P 36
+enum { BL_KV = 0, BL_RV = 1 };
+template <int MODE>
+__device__ __forceinline__ void bl_load(f32x4 (&dst)[2], const float* base, long sRow, long sK, int row0, int rmax, int k0, int tid) {
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    f32x4 v = {0, 0, 0, 0};
+    if (MODE == BL_KV) {
+      const int row = (tid >> 3) + 32 * ps, k4 = tid & 7;
+      if (row0 + row < rmax) v = *reinterpret_cast<const f32x4*>(base + (size_t)(row0 + row) * sRow + k0 + 4 * k4);
+    } else {
+      const int kk = (tid >> 4) + 16 * ps, r4 = tid & 15;
+      if (row0 + 4 * r4 < rmax) v = *reinterpret_cast<const f32x4*>(base + (size_t)(k0 + kk) * sK + row0 + 4 * r4);
+    }
+    dst[ps] = v;
+  }
+}
+template <int MODE>
+__device__ __forceinline__ void bl_store(float* L, const f32x4 (&src)[2], int tid) {
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    if (MODE == BL_KV) {
+      const int row = (tid >> 3) + 32 * ps, k4 = tid & 7;
+      *reinterpret_cast<f32x4*>(L + row * BL_P + 4 * k4) = src[ps];
+    } else {
+      const int kk = (tid >> 4) + 16 * ps, r4 = tid & 15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) L[(4 * r4 + r) * BL_P + kk] = src[ps][r];
+    }
+  }
+}
+
+template <int AMODE, int BMODE, bool DUAL>
+__global__ void __launch_bounds__(256) k_bmm_lds(BmmArgs P) {
+  __shared__ __attribute__((aligned(16))) float lds[2][(DUAL ? 3 : 2) * 64 * BL_P];
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, il = lane & 15, q = lane >> 4;
+  const int tiles_n = (P.N + 63) / 64;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+  const int i0 = tm * 64, j0 = tn * 64;
+  const int wi = (w >> 1) * 32, wj = (w & 1) * 32;
+  f32x4 acc[2][2], acc3[DUAL ? 2 : 1][DUAL ? 2 : 1];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) { acc[m][n] = f32x4{0, 0, 0, 0}; if (DUAL) acc3[m][n] = f32x4{0, 0, 0, 0}; }
+  const int nkb = P.K >> 5;                               // host guarantees K % 32 == 0
+  const int npairs = P.A2 ? 2 : 1;
+  const int total = nkb * npairs;                         // the second operand pair simply continues the K loop
+  f32x4 ra[2], rb[2], ra3[2];
+  auto gload = [&](int it) __attribute__((always_inline)) {
+    const int pair = it / nkb, k0 = (it - pair * nkb) * 32;
+    const float* Ab = (pair ? P.A2 : P.A) + (size_t)blockIdx.y * P.sAb;
+    const float* Bb = (pair ? P.B2 : P.B) + (size_t)blockIdx.y * P.sBb;
+    bl_load<AMODE>(ra, Ab, P.sAi, P.sAk, i0, P.M, k0, tid);
+    bl_load<BMODE>(rb, Bb, P.sBj, P.sBk, j0, P.N, k0, tid);
+    if (DUAL) {
+      if (pair == 0) bl_load<AMODE>(ra3, P.A3 + (size_t)blockIdx.y * P.sAb, P.sAi, P.sAk, i0, P.M, k0, tid);
+    }
+  };
+  auto lstore = [&](int buf, int it) __attribute__((always_inline)) {
+    float* L = lds[buf];
+    bl_store<AMODE>(L, ra, tid);
+    bl_store<BMODE>(L + 64 * BL_P, rb, tid);
+    if (DUAL) {
+      if (it < nkb) bl_store<AMODE>(L + 128 * BL_P, ra3, tid);
+    }
+  };
+  gload(0);
+  lstore(0, 0);
+  __syncthreads();
+  for (int it = 0; it < total; ++it) {
+    const int cur = it & 1;
+    if (it + 1 < total) gload(it + 1);
+    const float* LA = lds[cur];
+    const float* LB = LA + 64 * BL_P;
+    const float* LA3 = LA + 128 * BL_P;
+    const bool third = DUAL && it < nkb;                  // A3 rides along with the first pair's B operand
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      f32x4 a[2], b[2], a3[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        a[m] = *reinterpret_cast<const f32x4*>(LA + (wi + 16 * m + il) * BL_P + 16 * g + 4 * q);
+        if (third) a3[m] = *reinterpret_cast<const f32x4*>(LA3 + (wi + 16 * m + il) * BL_P + 16 * g + 4 * q);
+      }
+#pragma unroll
+      for (int n = 0; n < 2; ++n) b[n] = *reinterpret_cast<const f32x4*>(LB + (wj + 16 * n + il) * BL_P + 16 * g + 4 * q);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < 2; ++n) {
+            acc[m][n] = mfma16u(a[m][r], b[n][r], acc[m][n]);
+            if (third) acc3[m][n] = mfma16u(a3[m][r], b[n][r], acc3[m][n]);
+          }
+    }
+    if (it + 1 < total) lstore(cur ^ 1, it + 1);          // the other buffer: its readers finished before the last barrier
+    __syncthreads();
+  }
+#pragma unroll
+  for (int which = 0; which < (DUAL ? 2 : 1); ++which) {
+    float* Cb = (which ? P.C3 : P.C) + (size_t)blockIdx.y * P.sCb;
+    const bool cvec = P.sCi == 1 && (P.sCj & 3) == 0 && (P.sCb & 3) == 0 && ((reinterpret_cast<uintptr_t>(which ? P.C3 : P.C) & 15) == 0);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const int j = j0 + wj + 16 * n + il;
+        if (j >= P.N) continue;
+        const int i = i0 + wi + 16 * m + 4 * q;
+        if (i >= P.M) continue;
+        f32x4 v = P.alpha * (which ? acc3[DUAL ? m : 0][DUAL ? n : 0] : acc[m][n]);
+        if (cvec && i + 3 < P.M) {
+          float* cp = Cb + (size_t)j * P.sCj + i;
+          if (P.accumulate) v += *reinterpret_cast<const f32x4*>(cp);
+          *reinterpret_cast<f32x4*>(cp) = v;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (i + r >= P.M) continue;
+            float* cp = Cb + (size_t)(i + r) * P.sCi + (size_t)j * P.sCj;
+            *cp = P.accumulate ? *cp + v[r] : v[r];
+          }
+        }
+      }
+  }
+}
+
 // generic-K fallback (K % 16 != 0): scalar, one k per lane quarter
 __global__ void __launch_bounds__(256) k_bmm_slow(BmmArgs P) {
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, il = lane & 15, q = lane >> 4;
@@ -941,6 +1078,29 @@ int msgm_bmm_dual(const float* A, const float* B, const float* A2, const float* 
     return msgm_check_launch();
   }
   auto al16 = [](const float* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  // LDS-staged kernel: every operand has a unit stride (along k or along its row index), 16-byte aligned bases and
+  // strides, K a multiple of 32, M and N multiples of 4
+  {
+    static const bool no_lds = getenv("MSGM_BMM_NO_LDS") != nullptr;   // diagnostic A/B
+    auto mode = [&](long sRow, long sK, long sB) { return (sK == 1 && sRow % 4 == 0 && sB % 4 == 0) ? (int)BL_KV
+                                                        : (sRow == 1 && sK % 4 == 0 && sB % 4 == 0) ? (int)BL_RV : -1; };
+    const int am = mode(P.sAi, P.sAk, P.sAb), bm = mode(P.sBj, P.sBk, P.sBb);
+    if (!no_lds && am >= 0 && bm >= 0 && P.K % 32 == 0 && P.M % 4 == 0 && P.N % 4 == 0 && al16(P.A) && al16(P.A2) && al16(P.B) &&
+        al16(P.B2) && al16(P.A3)) {
+      dim3 grid((unsigned)(((P.M + 63) / 64) * ((P.N + 63) / 64)), (unsigned)batch);
+#define BL_GO(AM, BM)                                                                                              \
+  do {                                                                                                             \
+    if (P.A3) hipLaunchKernelGGL((k_bmm_lds<AM, BM, true>), grid, dim3(256), 0, S(stream), P);                      \
+    else hipLaunchKernelGGL((k_bmm_lds<AM, BM, false>), grid, dim3(256), 0, S(stream), P);                          \
+  } while (0)
+      if (am == BL_KV && bm == BL_KV) BL_GO(BL_KV, BL_KV);
+      else if (am == BL_KV) BL_GO(BL_KV, BL_RV);
+      else if (bm == BL_KV) BL_GO(BL_RV, BL_KV);
+      else BL_GO(BL_RV, BL_RV);
+#undef BL_GO
+      return msgm_check_launch();
+    }
+  }
   const bool avec = P.sAk == 1 && (P.sAi % 4 == 0) && (P.sAb % 4 == 0) && al16(P.A) && al16(P.A2);
   const bool bvec = P.sBk == 1 && (P.sBj % 4 == 0) && (P.sBb % 4 == 0) && al16(P.B) && al16(P.B2);
   const int tiles = ((P.M + 63) / 64) * ((P.N + 63) / 64);

@@ -566,3 +566,35 @@ def test_training_decoder_without_cat_equals_cat_path(monkeypatch):
     within(worst, 1e-5, "no-cat vs cat training path: worst parameter-gradient tensor")
     skipw = [k for k in res[True][1] if "output_blocks" in k and "skip_connection.weight" in k]
     assert skipw and all(float(res[False][1][k].abs().max()) > 0 for k in skipw)       # the twin's gradient reached the parameter
+
+
+@pytest.mark.parametrize("T,C", [(256, 128), (64, 128), (96, 32)])
+def test_bmm_lds_staged_equals_register_direct(T, C, monkeypatch):
+    """The LDS-staged batched GEMM (k_bmm_lds) against torch einsum on the eight operand layouts the composed dual attention
+    uses (K-contiguous / transposed A and B, second operand pair, second output sharing the big operand)."""
+    from sdeflow_light_amd import ops
+    torch.manual_seed(T + C)
+    Bn, ld = 2, 3 * C
+    qkv = torch.randn(2 * Bn, T, ld)
+    P, Pd = torch.randn(Bn, T, T), torch.randn(Bn, T, T)
+    half = Bn * T * ld
+    qd, Pg, Pdg = qkv.to(DEV).contiguous().view(-1), P.to(DEV).contiguous().view(-1), Pd.to(DEV).contiguous().view(-1)
+    q, k, v = qkv[:Bn, :, :C], qkv[:Bn, :, C:2 * C], qkv[:Bn, :, 2 * C:]
+    qdot, kdot, vdot = qkv[Bn:, :, :C], qkv[Bn:, :, C:2 * C], qkv[Bn:, :, 2 * C:]
+    sq, sk, sS, sSt, sa = (T * ld, ld, 1), (T * ld, 1, ld), (T * T, T, 1), (T * T, 1, T), (T * C, C, 1)
+    S = torch.empty(Bn * T * T, device=DEV)
+    ops.bmm(qd, half, qd, C, S, 0, T, T, C, Bn, sq, sk, sS, alpha=0.5, pair2=(qd, 0, qd, half + C))      # qdot k^T + q kdot^T
+    ref = 0.5 * (torch.einsum("btc,bsc->bts", qdot, k) + torch.einsum("btc,bsc->bts", q, kdot))
+    e1 = rel_l2(S.view(Bn, T, T).cpu(), ref)
+    att = torch.full((2 * Bn * T * C,), float("nan"), device=DEV)
+    ops.bmm(Pg, 0, qd, half + 2 * C, att, Bn * T * C, T, C, T, Bn, sS, sq, sa, pair2=(Pdg, 0, qd, 2 * C), third=(qd, 2 * C, att, 0))
+    a = att.view(2 * Bn, T, C).cpu()
+    e2 = max(rel_l2(a[:Bn], torch.einsum("bts,bsc->btc", P, v)),
+             rel_l2(a[Bn:], torch.einsum("bts,bsc->btc", P, vdot) + torch.einsum("bts,bsc->btc", Pd, v)))
+    dq = torch.zeros(2 * Bn * T * ld, device=DEV)
+    ops.bmm(Pdg, 0, qd, half, dq, C, T, C, T, Bn, sSt, sq, sq, alpha=0.5, pair2=(Pg, 0, qd, 0), third=(qd, 0, dq, half + C))   # transposed A
+    o = dq.view(2 * Bn, T, ld).cpu()
+    e3 = max(rel_l2(o[:Bn, :, C:2 * C], 0.5 * (torch.einsum("bts,btc->bsc", Pd, qdot) + torch.einsum("bts,btc->bsc", P, q))),
+             rel_l2(o[Bn:, :, C:2 * C], 0.5 * torch.einsum("bts,btc->bsc", Pd, q)))
+    print(f"k_bmm_lds T={T} C={C}: NT pair {e1:.1e}, NN dual {e2:.1e}, TN dual {e3:.1e}")
+    assert max(e1, e2, e3) <= 2e-6
