@@ -323,6 +323,20 @@ int msgm_conv_forward_fused(const msgm_conv_geom_t* geom, const float* src0, int
                             const float* samp_bias, int32_t n_bias, int32_t n_samp, float* out, int32_t accumulate,
                             const msgm_conv_fuse_t* fuse, msgm_stream_t stream);
 
+/* Winograd F(2x2, 3x3) FORWARD of a stride-1, pad-1 3x3 convolution (mode 0; Ho, Wo multiples of 16; C0, C1 multiples
+ * of 16; CoutP a multiple of 32) for the reverse-SDE SAMPLER, whose step is 55 % 3x3 convolutions (sde_scheme.py:82 ->
+ * model/unet.py:140-158): 16 instead of 36 multiplications per (co, ci) and 2x2 outputs, all in fp32 (the result differs
+ * from msgm_conv_forward by rounding only).  Same arguments and fused options (second source, folded 2x upsample,
+ * bias / per-sample bias, accumulate, residual, GroupNorm(+SiLU) input transform) as msgm_conv_forward_fused, except
+ * that the weight image WpW is [16][CoutP][Ktot]: the transformed kernels G g G^T written by
+ * msgm_wino_pack_weights_batched (same job table as msgm_pack_weights_batched, taps = 9).  No tangent-specific code and no
+ * backward: the training path keeps the direct kernels. */
+int msgm_conv_wino_supported(const msgm_conv_geom_t* geom, int32_t C0, int32_t C1, int32_t CoutP);
+int msgm_conv_forward_wino(const msgm_conv_geom_t* geom, const float* src0, int32_t C0, const float* src1, int32_t C1,
+                           const float* WpW, int32_t Cout, int32_t CoutP, int32_t Ktot, const float* bias,
+                           const float* samp_bias, int32_t n_bias, int32_t n_samp, float* out, int32_t accumulate,
+                           const msgm_conv_fuse_t* fuse, msgm_stream_t stream);
+
 /* dWp[tap][co][koff + c] += sum_m gy[m][co] in[src(m,tap)][c] (float atomics across
  * position chunks; zero dWp first).  One call per concatenated source.
  * dbias (may be NULL): dbias[co] += sum over the primal rows n < n_bias and all pixels of gy — the bias gradient
@@ -364,6 +378,8 @@ typedef struct {
   int32_t rows, ncols, col_off, taps, rowsP, Ktot, kp_off, reserved;
 } msgm_pack_job_t;
 int msgm_pack_weights_batched(const msgm_pack_job_t* jobs, int32_t n_jobs, int32_t unpack, msgm_stream_t stream);
+/* The Winograd images of msgm_conv_forward_wino: same job table (taps = 9), Wp = [16][rowsP][Ktot]. */
+int msgm_wino_pack_weights_batched(const msgm_pack_job_t* jobs, int32_t n_jobs, msgm_stream_t stream);
 
 /* Dual-number activations on a (primal | tangent) stacked tensor of 2*half
  * elements: act 0 = exact-erf GELU (NNUnet1D.py:18), 1 = SiLU (nn_utils.py:44-46).

@@ -294,28 +294,30 @@ class VorticityUNet(nn.Module, FlatParamMixin):
             C0, C1 = r.split
             gnm = r.m.in_layers[0]
             aff = ops.groupnorm_affine(h0, C0, gnm.weight.detach(), gnm.bias.detach(), Bp, P, gnm.num_groups, x1=s0, C1=C1)
-            h2, _, _ = r.conv1_2.forward([h0, s0], N, H, W, Bp, samp_bias=eo, emb_rows=er, in_affine=aff, in_act=1)
+            wn = getattr(self, "_wino", False)
+            h2, _, _ = r.conv1_2.forward([h0, s0], N, H, W, Bp, samp_bias=eo, emb_rows=er, in_affine=aff, in_act=1, wino=wn)
             out, _, _ = r.skip_2.forward([h0, s0], N, H, W, Bp)
             if r.conv2.can_transform_input(N, H, W):
                 r.conv2.forward([h2], N, H, W, Bp, out=out, accumulate=True,
-                                in_affine=self._gn_fold(r.m.out_layers[0], h2, Bp, P, r.co), in_act=1)
+                                in_affine=self._gn_fold(r.m.out_layers[0], h2, Bp, P, r.co), in_act=1, wino=wn)
             else:
                 h3, _ = self._gn(r.m.out_layers[0], h2, Bp, P, r.co, False, True, None)
-                r.conv2.forward([h3], N, H, W, Bp, out=out, accumulate=True)
+                r.conv2.forward([h3], N, H, W, Bp, out=out, accumulate=True, wino=wn)
             return out
         fold = (not dual and tape is None and not os.environ.get("MSGM_NO_GN_FOLD")
                 and r.conv1.can_transform_input(N, H, W) and r.conv2.can_transform_input(N, H, W))
         if fold:
             # sampler path: GroupNorm+SiLU are applied by the consuming conv while it stages its input tile, the residual
             # is added in conv2's epilogue — the two normalised tensors and the separate add pass never exist
+            wn = getattr(self, "_wino", False)
             h2, _, _ = r.conv1.forward([x], N, H, W, Bp, samp_bias=eo, emb_rows=er,
-                                       in_affine=self._gn_fold(r.m.in_layers[0], x, Bp, P, r.ci), in_act=1)
+                                       in_affine=self._gn_fold(r.m.in_layers[0], x, Bp, P, r.ci), in_act=1, wino=wn)
             aff2 = self._gn_fold(r.m.out_layers[0], h2, Bp, P, r.co)
             if r.skip is not None:
                 out, _, _ = r.skip.forward([x], N, H, W, Bp)
-                r.conv2.forward([h2], N, H, W, Bp, out=out, accumulate=True, in_affine=aff2, in_act=1)
+                r.conv2.forward([h2], N, H, W, Bp, out=out, accumulate=True, in_affine=aff2, in_act=1, wino=wn)
             else:
-                out, _, _ = r.conv2.forward([h2], N, H, W, Bp, residual=x, in_affine=aff2, in_act=1)
+                out, _, _ = r.conv2.forward([h2], N, H, W, Bp, residual=x, in_affine=aff2, in_act=1, wino=wn)
             return out
         h1, st1 = self._gn(r.m.in_layers[0], x, Bp, P, r.ci, dual, True, tape)
         h2, _, _ = r.conv1.forward([h1], N, H, W, Bp, samp_bias=eo, emb_rows=er)
@@ -382,6 +384,13 @@ class VorticityUNet(nn.Module, FlatParamMixin):
         logr: [log r ; rdot/r] (N,) with NormalizeLogRadius conditioning."""
         x = self._build()
         x["set"].pack()
+        # sampler path (no tangent, nothing kept): with MSGM_WINO=1 the 3x3 stride-1 convolutions take the Winograd
+        # F(2x2,3x3) forward kernel.  Opt-in: measured 1.11-1.20x on plain convolutions but only 1.01-1.07x once GroupNorm +
+        # SiLU are applied in the halo staging (the staging, not the MFMA count, is what those launches wait for), i.e.
+        # +1 % on the C5 step (tools/bench_wino.py) — not worth a second rounding path in the default sampler
+        self._wino = not dual and tape is None and bool(os.environ.get("MSGM_WINO"))
+        if self._wino:
+            x["set"].pack_wino()
         core = self.core
         mc = core.model_channels
         H = W = self.in_space
@@ -419,7 +428,7 @@ class VorticityUNet(nn.Module, FlatParamMixin):
                 elif kind in ("down", "up"):
                     if tape is not None:
                         tape.append((kind, o, h, H, W))
-                    h, H, W = o.forward([h], N, H, W, Bp)
+                    h, H, W = o.forward([h], N, H, W, Bp, wino=getattr(self, "_wino", False))
             return h, C, H, W
 
         h, C = img, core.in_channels
@@ -434,6 +443,8 @@ class VorticityUNet(nn.Module, FlatParamMixin):
         nocat_t = tape is not None and dual and x["set2t"] is not None and not os.environ.get("MSGM_TRAIN_CAT")
         if nocat:
             x["set2"].pack()
+            if self._wino:
+                x["set2"].pack_wino()
         if nocat_t:
             x["set2t"].pack()
         for blk in x["outb"]:

@@ -81,6 +81,9 @@ SIGNATURES = {
     "msgm_counter_inc": (C.c_int, [_P, _P]),
     "msgm_conv_forward": (C.c_int, [C.POINTER(ConvGeomT), _P, _I32, _P, _I32, _P, _I32, _I32, _I32, _P, _P, _I32, _I32, _P, _I32, _P]),
     "msgm_conv_forward_fused": (C.c_int, [C.POINTER(ConvGeomT), _P, _I32, _P, _I32, _P, _I32, _I32, _I32, _P, _P, _I32, _I32, _P, _I32, C.POINTER(ConvFuseT), _P]),
+    "msgm_conv_wino_supported": (C.c_int, [C.POINTER(ConvGeomT), _I32, _I32, _I32]),
+    "msgm_wino_pack_weights_batched": (C.c_int, [_P, _I32, _P]),
+    "msgm_conv_forward_wino": (C.c_int, [C.POINTER(ConvGeomT), _P, _I32, _P, _I32, _P, _I32, _I32, _I32, _P, _P, _I32, _I32, _P, _I32, C.POINTER(ConvFuseT), _P]),
     "msgm_conv_input_transform_supported": (C.c_int, [C.POINTER(ConvGeomT), _I32, _I32, _I32]),
     "msgm_groupnorm_affine": (C.c_int, [_P, _I32, _P, _I32, _P, _P, _P, _P, _I32, _I32, _I32, _F, _P, C.c_size_t, _P]),
     "msgm_conv_wgrad": (C.c_int, [C.POINTER(ConvGeomT), _P, _P, _I32, _I32, _P, _I32, _I32, _I32, _P, _I32,

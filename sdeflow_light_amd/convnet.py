@@ -48,8 +48,8 @@ class ConvOpSet:
                 if t is not None:
                     n = t.numel()
                     setattr(o, a, self.gimg[off:off + n]); off += n
-        self._pack = self._unpack = None
-        self._pack_sig = self._unpack_sig = None
+        self._pack = self._unpack = self._pack_w = None
+        self._pack_sig = self._unpack_sig = self._pack_w_sig = None
 
     def pack(self):
         sig = tuple(o.weight.data_ptr() for o in self.ops)          # the parameter bucket may have been rebuilt
@@ -57,6 +57,17 @@ class ConvOpSet:
             self._pack = ops.PackTable([j for o in self.ops for j in o.pack_jobs()], self.gimg.device)
             self._pack_sig = sig
         self._pack.run(False)
+
+    def pack_wino(self):
+        """Winograd images G g G^T of every 3x3 stride-1 convolution of the set (sampler path), ONE launch."""
+        wops = [o for o in self.ops if getattr(o, "wino_capable", lambda: False)()]
+        if not wops:
+            return
+        sig = tuple(o.weight.data_ptr() for o in wops)
+        if self._pack_w is None or sig != self._pack_w_sig:
+            self._pack_w = ops.PackTable([j for o in wops for j in o.wino_jobs()], self.gimg.device)
+            self._pack_w_sig = sig
+        self._pack_w.run_wino()
 
     def zero_grad_images(self, bias_grads_zeroed: bool = False):
         """bias_grads_zeroed: the caller has zeroed the flat gradient bucket for this step, so each op's next
@@ -112,6 +123,21 @@ class ConvOp:
             self.WdE = torch.zeros(3 * pad16(emb_channels) * pad16(self.Cout), device=dev)
         self._E = None
         self._bias_zeroed = False      # set per step by ConvOpSet.zero_grad_images, consumed by the next backward
+        self.WpW = None                # Winograd F(2x2,3x3) image [16][CoutP][Ktot] (sampler path), built on demand
+
+    def wino_capable(self) -> bool:
+        return (self.kind == "conv" and self.KH == 3 and self.KW == 3 and self.stride == 1 and self.pad == 1 and not self.embC
+                and self.CoutP % 32 == 0 and all(c % 16 == 0 for c in self.srcC))
+
+    def wino_jobs(self):
+        if self.WpW is None:
+            self.WpW = torch.zeros(16 * self.CoutP * self.Ktot, device=self.weight.device)
+        W = self.weight.detach()
+        jobs, off = [], 0
+        for s, C in enumerate(self.srcC):
+            jobs.append((W, 0, self.WpW, self.Cout, C, off, 9, self.s_row, self.s_col, 1, self.CoutP, self.Ktot, self.koff[s]))
+            off += C
+        return jobs
 
     # -------------------------------------------------------------- packing
     def pack(self):
@@ -195,10 +221,13 @@ class ConvOp:
     def forward(self, srcs: List[torch.Tensor], N: int, Hi: int, Wi: int, n_bias: int, emb: Optional[torch.Tensor] = None,
                 samp_bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, accumulate=False,
                 emb_rows: Optional[int] = None, residual: Optional[torch.Tensor] = None,
-                in_affine: Optional[tuple] = None, in_act: int = 0):
+                in_affine: Optional[tuple] = None, in_act: int = 0, wino: bool = False):
         """emb_rows: rows that carry an embedding / per-sample bias (n_bias by default; N when the embedding itself
-        has a tangent — NormalizeLogRadius conditioning)."""
+        has a tangent — NormalizeLogRadius conditioning).  wino: take the Winograd F(2x2,3x3) forward kernel when this
+        op has its image (ConvOpSet.pack_wino) and the geometry allows it (sampler path)."""
         geom, Ho, Wo = self._geom(N, Hi, Wi)
+        wino = bool(wino and self.WpW is not None and
+                    ops.conv_wino_supported(geom, self.srcC[0], self.srcC[1] if len(srcs) > 1 else 0, self.CoutP))
         dev = srcs[0].device
         if out is None:
             out = torch.empty(N * Ho * Wo * self.Cout, device=dev)
@@ -214,12 +243,12 @@ class ConvOp:
             sb = torch.empty(Bp * self.Cout, device=dev)
             ops.lincomb(sb, E[0], 1.0, E[1], 1.0, E[2], 1.0)
             self._E = E
-        ops.conv_forward(geom, srcs[0], self.srcC[0], self.Wp, self.Cout, out,
+        ops.conv_forward(geom, srcs[0], self.srcC[0], self.WpW if wino else self.Wp, self.Cout, out,
                          src1=srcs[1] if len(srcs) > 1 else None, C1=self.srcC[1] if len(srcs) > 1 else 0,
                          bias=self.bias.detach() if self.bias is not None else None, samp_bias=sb, n_bias=n_bias,
                          accumulate=accumulate, CoutP=self.CoutP, n_samp=er, residual=residual,
                          in_scale=in_affine[0] if in_affine is not None else None,
-                         in_shift=in_affine[1] if in_affine is not None else None, in_act=in_act)
+                         in_shift=in_affine[1] if in_affine is not None else None, in_act=in_act, wino=wino)
         if self.embC:
             # taps 0 / 2 fall on the zero padding at l = 0 / L-1 (rows that carry an embedding)
             ops.add_row(out, self._E[0], er, Ho * Wo, self.Cout, 0, -1.0)

@@ -533,6 +533,230 @@ __global__ void __launch_bounds__(256, CT_MINWG) k_conv_tile(ConvArgs A, int fli
   }
 }
 
+// ------------------------------------------------------------------ Winograd F(2x2, 3x3) forward (sampler path)
+// The reverse-SDE sampler spends 55 % of a step in stride-1 3x3 convolutions (C5, rocprofv3), a third of that in the
+// 32-output-channel layers where the direct halo-tile kernel reaches only ~65 TFLOP/s (the halo staging is amortised over
+// half as many MFMAs).  For those convolutions the minimal-filtering form Y = A^T [ (G g G^T) o (B^T d B) ] A computes a
+// 2x2 output tile from a 4x4 input patch with 16 instead of 36 multiplications per (co, ci): 2.25x fewer MFMAs, all in
+// fp32 (the transforms are additions and halvings; the result differs from the direct form by fp32 rounding only —
+// measured in tests/test_conv_gpu.py).  No tangent, no backward: the training path keeps the direct kernels.
+//   * workgroup = 16x16 output pixels = 8x8 Winograd tiles x 32 output channels, the (16+2)^2 halo of a 32-channel chunk
+//     staged in LDS exactly as k_conv_tile does (same fused GroupNorm(+SiLU) input transform, two sources, folded
+//     2x upsample);
+//   * wave w owns 16 tiles (lane&15) for ALL 16 transform positions: per 16-channel group a lane reads its 4x4 patch of
+//     4 channels (16 ds_read_b128), transforms it in registers (B^T d B: 32 additions per channel) and the 16 results
+//     are the B operands of 16 x NCO MFMAs per k-step — so the output transform A^T M A needs no exchange between
+//     lanes: the 16 position-accumulators of a tile sit in the same lane;
+//   * the transformed weights U[pos][co][ci] (packed like Wp with 16 "taps" by k_wino_pack) stream L2 -> registers one
+//     position ahead.
+template <int NCO>
+__global__ void __launch_bounds__(256, 2) k_conv_wino(ConvArgs A, int tiles_x, int tiles_y, int n_tiles, int n_cob, int n_tgrp) {
+  extern __shared__ __attribute__((aligned(16))) float cw_lds[];
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, il = lane & 15, q = lane >> 4;
+  const ConvGeom g = A.g;
+  constexpr int HW = 18, halo = 18 * 18;
+  float* cur = cw_lds;
+  const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;            // XCD-aware order, as k_conv_tile
+  const int cob = loc % n_cob, tile = (loc / n_cob) * 8 + xcd;
+  (void)n_tgrp;
+  if (tile >= n_tiles) return;
+  const int co0 = cob * (NCO * 16);
+  // this lane's Winograd tile inside the 16x16 output tile: 8x8 tiles, wave w owns tile rows 2w, 2w+1
+  const int tt = 16 * w + il, ty = tt >> 3, tx = tt & 7;
+  const int pbase = (2 * ty * HW + 2 * tx) * CT_P + 4 * q;            // LDS offset of patch element (0,0), channel 4q
+  f32x4 acc[16][NCO];
+#pragma unroll
+  for (int p = 0; p < 16; ++p)
+#pragma unroll
+    for (int c = 0; c < NCO; ++c) acc[p][c] = f32x4{0, 0, 0, 0};
+
+  int nch[CONV_MAX_SRC];
+#pragma unroll
+  for (int s = 0; s < CONV_MAX_SRC; ++s) nch[s] = s < A.nsrc ? (A.C[s] + CT_KC - 1) / CT_KC : 0;
+  constexpr int MAXST = (halo * (CT_KC / 4) + 255) / 256;
+  constexpr int n_items = halo * (CT_KC / 4);
+  const int up = g.ups ? 1 : 0;
+  const int ctot_all = A.C[0] + (A.nsrc > 1 ? A.C[1] : 0);
+  int n, y0, x0;
+  { int t = tile; const int tx_i = t % tiles_x; t /= tiles_x; const int ty_i = t % tiles_y; n = t / tiles_y; y0 = ty_i * 16; x0 = tx_i * 16; }
+  auto stage = [&](int s_, int c0) __attribute__((always_inline)) {    // global -> (transform) -> LDS, one 32-channel chunk
+    const int C = A.C[s_];
+    const float* base = A.src[s_] + (size_t)n * g.Hi * g.Wi * C;
+    f32x4 ga = {1.f, 1.f, 1.f, 1.f}, gb = {0.f, 0.f, 0.f, 0.f};
+    const int cq = c0 + 4 * (tid & 7);
+    if (A.in_scale && cq < C) {
+      const size_t o = (size_t)n * ctot_all + (s_ ? A.C[0] : 0) + cq;
+      ga = *reinterpret_cast<const f32x4*>(A.in_scale + o);
+      gb = *reinterpret_cast<const f32x4*>(A.in_shift + o);
+    }
+    f32x4 st[MAXST];
+#pragma unroll
+    for (int k = 0; k < MAXST; ++k) {
+      const int idx = tid + 256 * k;
+      f32x4 v = {0, 0, 0, 0};
+      if (idx < n_items) {
+        const int hp = idx >> 3, hy = hp / HW, hx = hp - hy * HW;        // division by the constant 18
+        const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+        const int c = c0 + 4 * (idx & 7);
+        if (iy >= 0 && iy < (g.Hi << up) && ix >= 0 && ix < (g.Wi << up) && c < C) {
+          v = *reinterpret_cast<const f32x4*>(base + ((size_t)(iy >> up) * g.Wi + (ix >> up)) * C + c);
+          if (A.in_scale) {
+            v = v * ga + gb;
+            if (A.in_act == 1) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[r]));
+            }
+          }
+        }
+      }
+      st[k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < MAXST; ++k) {
+      const int idx = tid + 256 * k;
+      if (idx < n_items) *reinterpret_cast<f32x4*>(cur + (idx >> 3) * CT_P + 4 * (idx & 7)) = st[k];
+    }
+  };
+
+  const size_t a_co_stride = (size_t)16 * A.Ktot, pos_stride = (size_t)A.CoutP * A.Ktot;
+  for (int cs = 0; cs < A.nsrc; ++cs)
+    for (int cc = 0; cc < (cs ? nch[1] : nch[0]); ++cc) {
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");           // the previous chunk's readers are done
+      stage(cs, cc * CT_KC);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      const int C = A.C[cs], c0 = cc * CT_KC;
+      const int ngrp = (C - c0 >= CT_KC) ? 2 : ((C - c0 + 15) >> 4);
+      const float* wbase = A.Wp + (size_t)(co0 + il) * A.Ktot + A.koff[cs] + c0 + 4 * q;
+      f32x4 an[NCO];
+#pragma unroll
+      for (int c = 0; c < NCO; ++c) an[c] = *reinterpret_cast<const f32x4*>(wbase + c * a_co_stride);
+      // ONE running weight pointer (kept opaque to the optimiser: with 16 x NCO precomputed 64-bit addresses per group the
+      // kernel spilled at 256 registers), advanced by one position per step and to the next channel group after 16
+      const float* wq = wbase;
+      for (int grp = 0; grp < ngrp; ++grp) {
+        // ---- the lane's 4x4 patch (4 channels) and its transform V = B^T d B, in place
+        f32x4 d[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) d[i][j] = *reinterpret_cast<const f32x4*>(cur + pbase + (i * HW + j) * CT_P + 16 * grp);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 r0 = d[0][j] - d[2][j], r1 = d[1][j] + d[2][j], r2 = d[2][j] - d[1][j], r3 = d[1][j] - d[3][j];
+          d[0][j] = r0; d[1][j] = r1; d[2][j] = r2; d[3][j] = r3;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const f32x4 c0_ = d[i][0] - d[i][2], c1_ = d[i][1] + d[i][2], c2_ = d[i][2] - d[i][1], c3_ = d[i][1] - d[i][3];
+          d[i][0] = c0_; d[i][1] = c1_; d[i][2] = c2_; d[i][3] = c3_;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- 16 positions: M_p += U_p V_p
+#pragma unroll
+        for (int pos = 0; pos < 16; ++pos) {
+          f32x4 a[NCO];
+#pragma unroll
+          for (int c = 0; c < NCO; ++c) a[c] = an[c];
+          // weights one (group, position) pair ahead
+          if (pos < 15) wq += pos_stride;
+          else wq = wbase + 16 * (grp + 1);
+          asm volatile("" : "+v"(wq));
+          if (pos < 15 || grp + 1 < ngrp) {
+#pragma unroll
+            for (int c = 0; c < NCO; ++c) an[c] = *reinterpret_cast<const f32x4*>(wq + c * a_co_stride);
+          }
+          const f32x4 b = d[pos >> 2][pos & 3];
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < NCO; ++c) acc[pos][c] = mfma16c(a[c][r], b[r], acc[pos][c]);
+          __builtin_amdgcn_sched_barrier(0);          // one position's weight fragments in flight, not all sixteen
+        }
+      }
+    }
+
+  // ---- output transform Y = A^T M A per (tile, co quad) and the epilogue of k_conv_tile (bias / per-sample bias /
+  //      accumulate / residual), 2x2 pixels x 4 consecutive output channels per lane and co tile
+  const bool primal = n < A.n_bias;
+  const bool vec = (A.Cout & 3) == 0;
+#pragma unroll
+  for (int c = 0; c < NCO; ++c) {
+    const int co = co0 + 16 * c + 4 * q;
+    if (co >= A.Cout) continue;
+    const bool full = vec && (co + 3 < A.Cout);
+    f32x4 add = {0.f, 0.f, 0.f, 0.f};
+    if (primal && A.bias) {
+      if (full) add = *reinterpret_cast<const f32x4*>(A.bias + co);
+      else
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (co + r < A.Cout) add[r] = A.bias[co + r];
+    }
+    if (A.samp_bias && n < A.n_samp) {
+      const float* sbp = A.samp_bias + (size_t)n * A.Cout + co;
+      if (full) add += *reinterpret_cast<const f32x4*>(sbp);
+      else
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (co + r < A.Cout) add[r] += sbp[r];
+    }
+    f32x4 t0[4], t1[4];
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) {
+      t0[nu] = acc[nu][c] + acc[4 + nu][c] + acc[8 + nu][c];
+      t1[nu] = acc[4 + nu][c] - acc[8 + nu][c] - acc[12 + nu][c];
+    }
+    f32x4 Y[2][2];
+    Y[0][0] = t0[0] + t0[1] + t0[2]; Y[0][1] = t0[1] - t0[2] - t0[3];
+    Y[1][0] = t1[0] + t1[1] + t1[2]; Y[1][1] = t1[1] - t1[2] - t1[3];
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const int oy = y0 + 2 * ty + dy, ox = x0 + 2 * tx + dx;
+        if (oy >= g.Ho || ox >= g.Wo) continue;
+        const size_t m = ((size_t)n * g.Ho + oy) * g.Wo + ox;
+        f32x4 v = Y[dy][dx] + add;
+        float* op = A.out + m * A.Cout + co;
+        if (full) {
+          if (A.accumulate) v += *reinterpret_cast<const f32x4*>(op);
+          if (A.residual) v += *reinterpret_cast<const f32x4*>(A.residual + (op - A.out));
+          *reinterpret_cast<f32x4*>(op) = v;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (co + r < A.Cout) op[r] = (A.accumulate ? op[r] + v[r] : v[r]) + (A.residual ? A.residual[(op - A.out) + r] : 0.f);
+        }
+      }
+  }
+}
+
+// U[pos = 4 xi + nu][r][kp_off + c] = (G g G^T)[xi][nu] of the 3x3 kernel g = W[r][col_off + c][:, :]; same job table
+// as k_pack_batched (taps = 9 on input: element (r, c, t) at W + r*sr + (col_off + c)*sc + t*st), 16 positions out
+__global__ void __launch_bounds__(256) k_wino_pack_batched(const msgm_pack_job_t* __restrict__ jobs) {
+  const msgm_pack_job_t J = jobs[blockIdx.y];
+  const int64_t tot = (int64_t)J.rows * J.ncols;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < tot; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % J.ncols), r = (int)(e / J.ncols);
+    const float* w = J.W + r * J.sr + (J.col_off + c) * J.sc;
+    float gk[3][3], h[4][3];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) gk[t / 3][t % 3] = w[t * J.st];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      h[0][j] = gk[0][j];
+      h[1][j] = 0.5f * (gk[0][j] + gk[1][j] + gk[2][j]);
+      h[2][j] = 0.5f * (gk[0][j] - gk[1][j] + gk[2][j]);
+      h[3][j] = gk[2][j];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float u0 = h[i][0], u1 = 0.5f * (h[i][0] + h[i][1] + h[i][2]), u2 = 0.5f * (h[i][0] - h[i][1] + h[i][2]), u3 = h[i][2];
+      float* p = J.Wp + ((int64_t)(4 * i) * J.rowsP + r) * J.Ktot + J.kp_off + c;
+      const int64_t ps = (int64_t)J.rowsP * J.Ktot;
+      p[0] = u0; p[ps] = u1; p[2 * ps] = u2; p[3 * ps] = u3;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ wgrad
 struct WgradArgs {
   ConvGeom g;
@@ -1025,6 +1249,52 @@ int msgm_conv_input_transform_supported(const msgm_conv_geom_t* geom, int32_t C0
   if (check_geom(geom)) return 0;
   static const float dummy = 0.f;
   return conv_tile_eligible(geom, C0, C1 > 0 ? &dummy : nullptr, C1, CoutP) ? 1 : 0;
+}
+
+static bool conv_wino_eligible(const msgm_conv_geom_t* geom, int32_t C0, int32_t C1, int32_t CoutP) {
+  const int ups_sh = geom->ups ? 1 : 0;
+  return geom->mode == 0 && geom->KH == 3 && geom->KW == 3 && geom->strideH == 1 && geom->strideW == 1 && geom->padH == 1 &&
+         geom->padW == 1 && (geom->Hi << ups_sh) == geom->Ho && (geom->Wi << ups_sh) == geom->Wo && geom->Ho % 16 == 0 &&
+         geom->Wo % 16 == 0 && C0 % 16 == 0 && C1 % 16 == 0 && CoutP % 32 == 0;
+}
+
+int msgm_conv_wino_supported(const msgm_conv_geom_t* geom, int32_t C0, int32_t C1, int32_t CoutP) {
+  if (check_geom(geom)) return 0;
+  return conv_wino_eligible(geom, C0, C1, CoutP) ? 1 : 0;
+}
+
+int msgm_wino_pack_weights_batched(const msgm_pack_job_t* jobs, int32_t n_jobs, msgm_stream_t stream) {
+  if (!jobs || n_jobs <= 0) return MSGM_E_BADARG;
+  hipLaunchKernelGGL(k_wino_pack_batched, dim3(8, (unsigned)n_jobs), dim3(256), 0, S(stream), jobs);
+  return msgm_check_launch();
+}
+
+int msgm_conv_forward_wino(const msgm_conv_geom_t* geom, const float* src0, int32_t C0, const float* src1, int32_t C1,
+                           const float* WpW, int32_t Cout, int32_t CoutP, int32_t Ktot, const float* bias,
+                           const float* samp_bias, int32_t n_bias, int32_t n_samp, float* out, int32_t accumulate,
+                           const msgm_conv_fuse_t* fuse, msgm_stream_t stream) {
+  int rc = check_geom(geom);
+  if (rc) return rc;
+  if (fuse && ((fuse->in_scale == nullptr) != (fuse->in_shift == nullptr) || (fuse->in_act != 0 && fuse->in_act != 1)))
+    return MSGM_E_BADARG;
+  if (!src0 || !WpW || !out || C0 <= 0 || Cout <= 0 || (src1 && C1 <= 0)) return MSGM_E_BADARG;
+  if (!conv_wino_eligible(geom, C0, src1 ? C1 : 0, CoutP)) return MSGM_E_UNSUPPORTED;
+  const int k0 = ((C0 + 15) / 16) * 16, k1 = src1 ? ((C1 + 15) / 16) * 16 : 0;
+  if (Ktot != k0 + k1 || CoutP < Cout) return MSGM_E_BADARG;
+  ConvArgs A{};
+  A.g = to_geom(geom);
+  A.src[0] = src0; A.C[0] = C0; A.koff[0] = 0;
+  A.src[1] = src1; A.C[1] = src1 ? C1 : 0; A.koff[1] = k0;
+  A.nsrc = src1 ? 2 : 1;
+  A.Wp = WpW; A.Cout = Cout; A.CoutP = CoutP; A.Ktot = Ktot;
+  A.bias = bias; A.samp_bias = samp_bias; A.n_bias = n_bias; A.n_samp = n_samp; A.out = out; A.accumulate = accumulate;
+  if (fuse) { A.residual = fuse->residual; A.in_scale = fuse->in_scale; A.in_shift = fuse->in_shift; A.in_act = fuse->in_act; }
+  const int tiles_x = geom->Wo / 16, tiles_y = geom->Ho / 16;
+  const int n_tiles = tiles_x * tiles_y * geom->N, gy = CoutP / 32;
+  const size_t lds = (size_t)18 * 18 * CT_P * sizeof(float);
+  dim3 grid((unsigned)(8 * gy * ((n_tiles + 7) / 8)));
+  hipLaunchKernelGGL((k_conv_wino<2>), grid, dim3(256), lds, S(stream), A, tiles_x, tiles_y, n_tiles, gy, n_tiles);
+  return msgm_check_launch();
 }
 
 int msgm_conv_forward(const msgm_conv_geom_t* geom, const float* src0, int32_t C0, const float* src1, int32_t C1,

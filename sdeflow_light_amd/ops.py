@@ -297,13 +297,14 @@ def conv_forward(geom: L.ConvGeomT, src0: torch.Tensor, C0: int, Wp: torch.Tenso
                  samp_bias: Optional[torch.Tensor] = None, n_bias: int = 0, accumulate: bool = False,
                  CoutP: Optional[int] = None, n_samp: Optional[int] = None, residual: Optional[torch.Tensor] = None,
                  in_scale: Optional[torch.Tensor] = None, in_shift: Optional[torch.Tensor] = None,
-                 in_act: int = 0, tapmask_in=None, tapmask_out=None) -> torch.Tensor:
+                 in_act: int = 0, tapmask_in=None, tapmask_out=None, wino: bool = False) -> torch.Tensor:
     """out[N][Ho][Wo][Cout] (+)= implicit-GEMM convolution of channels-last inputs (K6/K11).
+    wino: Wp is the Winograd image [16][CoutP][Ktot] and the F(2x2,3x3) forward kernel runs (sampler path).
     residual: added in the epilogue.  in_scale / in_shift [N][C0+C1] (+ in_act=1: SiLU): the conv reads
     act(a x + b) — GroupNorm(+SiLU) folded into the input staging (see conv_input_transform_supported)."""
     CoutP = pad16(Cout) if CoutP is None else CoutP
     Ktot = pad16(C0) + (pad16(C1) if src1 is not None else 0)
-    taps = geom.KH * geom.KW
+    taps = 16 if wino else geom.KH * geom.KW
     if src0.numel() != geom.N * geom.Hi * geom.Wi * C0:
         raise MsgmError(f"src0 has {src0.numel()} elements, geometry says {geom.N * geom.Hi * geom.Wi * C0}")
     if src1 is not None and src1.numel() != geom.N * geom.Hi * geom.Wi * C1:
@@ -330,6 +331,13 @@ def conv_forward(geom: L.ConvGeomT, src0: torch.Tensor, C0: int, Wp: torch.Tenso
             fuse.tapmask_in[i] = int(m)
         for i, m in enumerate((tapmask_out or [])[:8]):
             fuse.tapmask_out[i] = int(m)
+    if wino:
+        if tapmask_in or tapmask_out:
+            raise MsgmError("the Winograd kernel has no tap masks")
+        check(lib().msgm_conv_forward_wino(geom, ptr(f32(src0)), C0, ptr(src1), C1, ptr(f32(Wp)), Cout, CoutP, Ktot, ptr(bias),
+                                           ptr(samp_bias), int(n_bias), int(n_samp), ptr(f32(out)), int(bool(accumulate)),
+                                           fuse, stream()), "msgm_conv_forward_wino")
+        return out
     check(lib().msgm_conv_forward_fused(geom, ptr(f32(src0)), C0, ptr(src1), C1, ptr(f32(Wp)), Cout, CoutP, Ktot, ptr(bias),
                                         ptr(samp_bias), int(n_bias), int(n_samp), ptr(f32(out)), int(bool(accumulate)),
                                         fuse, stream()), "msgm_conv_forward")
@@ -352,6 +360,10 @@ def groupnorm_affine(x0, C0, gamma, beta, Bp, P, G, x1=None, C1=0, eps=1e-5):
     check(lib().msgm_groupnorm_affine(ptr(f32(x0)), C0, ptr(x1), C1, ptr(f32(gamma)), ptr(f32(beta)), ptr(scale), ptr(shift),
                                       Bp, P, G, float(eps), ptr(ws), ws.numel() * 8, stream()), "msgm_groupnorm_affine")
     return scale, shift
+
+
+def conv_wino_supported(geom: L.ConvGeomT, C0: int, C1: int, CoutP: int) -> bool:
+    return bool(lib().msgm_conv_wino_supported(geom, int(C0), int(C1), int(CoutP)))
 
 
 def conv_wgrad(geom: L.ConvGeomT, gy: torch.Tensor, src: torch.Tensor, C: int, koff: int, dWp: torch.Tensor, Cout: int,
@@ -412,6 +424,10 @@ class PackTable:
 
     def run(self, unpack: bool = False):
         check(lib().msgm_pack_weights_batched(ptr(self.table), self.n, int(bool(unpack)), stream()), "msgm_pack_weights_batched")
+
+    def run_wino(self):
+        """The jobs are 3x3 kernels (taps = 9) and Wp the [16][rowsP][Ktot] Winograd images: writes G g G^T."""
+        check(lib().msgm_wino_pack_weights_batched(ptr(self.table), self.n, stream()), "msgm_wino_pack_weights_batched")
 
 
 def unpack_weight(dW: torch.Tensor, w_off: int, dWp: torch.Tensor, rows, ncols, col_off, taps, sr, sc, st, rowsP, Ktot,

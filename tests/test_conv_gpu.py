@@ -290,3 +290,36 @@ def test_stride2_pair_op_fwd_bwd(kind, N, Cin, Cout, L):
     o2 = out2.view(2 * N, Lo, Cout).cpu()
     assert rel_l2(o2[:N], cl1(y.detach())) <= 1e-5
     assert rel_l2(o2[N:], cl1(f(x.detach(), W, None))) <= 1e-5
+
+
+@pytest.mark.parametrize("N,H,Ci,Co,two,ups,aff", [(3, 32, 64, 64, False, False, False), (2, 64, 32, 32, False, False, True),
+                                                   (2, 32, 64, 32, True, False, True), (2, 16, 128, 128, False, False, False),
+                                                   (2, 16, 64, 64, False, True, False), (1, 16, 32, 96, False, False, True)])
+def test_winograd_forward_equals_direct_conv(N, H, Ci, Co, two, ups, aff):
+    """Winograd F(2x2,3x3) forward (sampler path) vs the direct halo-tile kernel on the same inputs and fused options:
+    second source, folded 2x upsample, GroupNorm(+SiLU) input transform, bias, per-sample bias, residual.  Both are fp32;
+    they differ by the rounding of the transforms only."""
+    from sdeflow_light_amd import ops
+    from sdeflow_light_amd.convnet import ConvOp
+    torch.manual_seed(N * 1000 + H + Ci + Co)
+    dev = "cuda"
+    C0, C1 = (Ci, 32) if two else (Ci, 0)
+    w = torch.nn.Parameter(torch.randn(Co, C0 + C1, 3, 3, device=dev) * (2.0 / (9 * (C0 + C1))) ** 0.5)
+    b = torch.nn.Parameter(torch.randn(Co, device=dev) * 0.1)
+    op = ConvOp(w, b, "conv", (3, 3), 1, 1, [C0, C1] if two else [C0], ups=ups)
+    op.pack()
+    assert op.wino_capable()
+    tab = ops.PackTable(op.wino_jobs(), dev)
+    tab.run_wino()
+    Hi = H // 2 if ups else H
+    srcs = [torch.randn(N * Hi * Hi * C0, device=dev)] + ([torch.randn(N * Hi * Hi * C1, device=dev)] if two else [])
+    sb = torch.randn(N * Co, device=dev) * 0.1
+    res = torch.randn(N * H * H * Co, device=dev)
+    in_aff = (1 + 0.3 * torch.randn(N * (C0 + C1), device=dev), 0.2 * torch.randn(N * (C0 + C1), device=dev)) if aff else None
+    kw = dict(samp_bias=sb, residual=res, in_affine=in_aff, in_act=1 if aff else 0)
+    ref, _, _ = op.forward(srcs, N, Hi, Hi, N, **kw)
+    got, _, _ = op.forward(srcs, N, Hi, Hi, N, wino=True, **kw)
+    e = rel_l2(got.cpu(), ref.cpu())
+    print(f"Winograd vs direct 3x3 conv N={N} {H}x{H} {C0}+{C1}->{Co} ups={ups} affine={aff}: rel-L2 {e:.2e}")
+    assert e <= 2e-6
+    assert not torch.equal(got, ref)                       # it really took the other kernel
