@@ -533,6 +533,116 @@ __global__ void __launch_bounds__(256, CT_MINWG) k_conv_tile(ConvArgs A, int fli
   }
 }
 
+// ------------------------------------------------------------------ 1x1 convolutions: pixel-stationary streaming kernel
+// A 1x1 (stride 1) convolution is a plain GEMM out[p][co] = sum_c x[p][c] W[co][c] with K = Cin of only 32..256: per
+// 32-channel chunk the halo-tile kernel above has 2 (tap, group) pairs = 64 MFMAs per wave between two barriers, and it
+// measured a FLAT ~45-60 TFLOP/s whatever the shape (1.2-3.7 TB/s of algorithmic bytes; tools/bench_1x1.py) — bound by
+// its own barrier / staging cadence, not by HBM.  Here nothing is staged and nothing is shared: a wave owns 16*PT pixels,
+// reads their activations ONCE from global memory straight into registers as MFMA B fragments (16 B per lane; the 4
+// lanes of a pixel cover 64 contiguous bytes per 16-channel group) and keeps them for the whole kernel, then walks over
+// the output-channel tiles with the weight fragments streamed L2 -> registers one (tile, group) pair ahead: PT*4 MFMAs
+// per 16-byte weight load, no LDS, no barrier, every activation byte read once, every output byte written once.
+// Same fused options as k_conv_tile: second source (concatenated K), per-(sample, channel) input affine (+SiLU), bias,
+// per-sample bias, accumulate, residual.  Also the dgrad of the same convolution (with the Wd image).
+template <int PT, int KG>     // PT pixel tiles of 16 per wave; KG = 16-channel groups of the whole (concatenated) input
+__global__ void __launch_bounds__(256) k_conv1x1(ConvArgs A, int P /* pixels per sample */, long Mtot) {
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, il = lane & 15, q = lane >> 4;
+  const long m0 = ((long)blockIdx.x * 4 + w) * (16 * PT);
+  if (m0 >= Mtot) return;                                  // no barriers in this kernel
+  const int g0 = (A.C[0] + 15) >> 4;                       // groups of the first source
+  const int ctot = A.C[0] + (A.nsrc > 1 ? A.C[1] : 0);
+  // ---- activations of this wave's pixels: B fragments, resident
+  f32x4 b[PT][KG];
+  long pm[PT];
+  bool pin[PT];
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    long m = m0 + 16 * pt + il;
+    pin[pt] = m < Mtot;
+    if (!pin[pt]) m = Mtot - 1;
+    pm[pt] = m;
+    const int n = (int)(m / P);
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+      const bool second = g >= g0;
+      const int c = (second ? 16 * (g - g0) : 16 * g) + 4 * q;           // channel inside its source
+      const int C = second ? A.C[1] : A.C[0];
+      f32x4 v = {0, 0, 0, 0};
+      if (c < C) {
+        v = *reinterpret_cast<const f32x4*>((second ? A.src[1] : A.src[0]) + (size_t)m * C + c);
+        if (A.in_scale) {
+          const size_t o = (size_t)n * ctot + (second ? A.C[0] : 0) + c;
+          v = v * *reinterpret_cast<const f32x4*>(A.in_scale + o) + *reinterpret_cast<const f32x4*>(A.in_shift + o);
+          if (A.in_act == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[r]));
+          }
+        }
+      }
+      b[pt][g] = v;
+    }
+  }
+  // ---- output-channel tiles: weights streamed one (tile, group) pair ahead
+  const int ntile = (A.Cout + 15) >> 4;
+  const float* wrow = A.Wp + (size_t)il * A.Ktot + 4 * q;   // row co = 16*ct + il, k = 16*g + 4*q (sources are 16-padded in K)
+  const size_t tile_stride = (size_t)16 * A.Ktot;
+  f32x4 an = *reinterpret_cast<const f32x4*>(wrow);
+  const bool vec = (A.Cout & 3) == 0;
+  for (int ct = 0; ct < ntile; ++ct) {
+    f32x4 acc[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) acc[pt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+      const f32x4 a = an;
+      // next pair: (ct, g+1) or (ct+1, 0); the K offset of group g is 16*g (koff[1] = 16*g0 for the second source)
+      const int ng = (g + 1 < KG) ? g + 1 : 0, nct = (g + 1 < KG) ? ct : ct + 1;
+      if (nct < ntile) an = *reinterpret_cast<const f32x4*>(wrow + (size_t)nct * tile_stride + 16 * ng);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) acc[pt] = mfma16c(a[r], b[pt][g][r], acc[pt]);
+    }
+    // ---- epilogue of this tile: lane (pixel il of tile pt, channels 16ct + 4q .. +3)
+    const int co = 16 * ct + 4 * q;
+    if (co >= A.Cout) continue;
+    const bool full = vec && (co + 3 < A.Cout);
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      if (!pin[pt]) continue;
+      const int n = (int)(pm[pt] / P);
+      f32x4 add = {0.f, 0.f, 0.f, 0.f};
+      if (n < A.n_bias && A.bias) {
+        if (full) add = *reinterpret_cast<const f32x4*>(A.bias + co);
+        else
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (co + r < A.Cout) add[r] = A.bias[co + r];
+      }
+      if (A.samp_bias && n < A.n_samp) {
+        const float* sbp = A.samp_bias + (size_t)n * A.Cout + co;
+        if (full) add += *reinterpret_cast<const f32x4*>(sbp);
+        else
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (co + r < A.Cout) add[r] += sbp[r];
+      }
+      f32x4 v = acc[pt] + add;
+      float* op = A.out + (size_t)pm[pt] * A.Cout + co;
+#ifdef C1_EXP_NOSTORE      // diagnostic: what the kernel costs without its output stores
+      if (v[0] != 12345.678f) continue;
+#endif
+      if (full) {
+        if (A.accumulate) v += *reinterpret_cast<const f32x4*>(op);
+        if (A.residual) v += *reinterpret_cast<const f32x4*>(A.residual + (op - A.out));
+        *reinterpret_cast<f32x4*>(op) = v;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (co + r < A.Cout) op[r] = (A.accumulate ? op[r] + v[r] : v[r]) + (A.residual ? A.residual[(op - A.out) + r] : 0.f);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ Winograd F(2x2, 3x3) forward (sampler path)
 // The reverse-SDE sampler spends 55 % of a step in stride-1 3x3 convolutions (C5, rocprofv3), a third of that in the
 // 32-output-channel layers where the direct halo-tile kernel reaches only ~65 TFLOP/s (the halo staging is amortised over
@@ -1331,6 +1441,34 @@ int msgm_conv_forward_fused(const msgm_conv_geom_t* geom, const float* src0, int
   }
   const int64_t Mtot = (int64_t)geom->N * geom->Ho * geom->Wo;
   const bool fast = (C0 % 16 == 0) && (!src1 || C1 % 16 == 0);
+  // 1x1 stride-1 convolution (forward or dgrad): pixel-stationary streaming kernel, no LDS
+  {
+    static const bool no1 = getenv("MSGM_NO_CONV1X1") != nullptr;            // diagnostic A/B
+    const int kg = Ktot / 16;
+    bool masks = false;
+    if (fuse) {
+      for (int i = 0; i < 16; ++i) masks = masks || fuse->tapmask_in[i];
+      for (int i = 0; i < 8; ++i) masks = masks || fuse->tapmask_out[i];
+    }
+    if (!no1 && geom->KH == 1 && geom->KW == 1 && geom->strideH == 1 && geom->strideW == 1 && geom->padH == 0 && geom->padW == 0 &&
+        !geom->ups && geom->Hi == geom->Ho && geom->Wi == geom->Wo && fast && !masks && Mtot >= 4096 &&
+        (kg == 2 || kg == 4 || kg == 6 || kg == 8 || kg == 12 || kg == 16)) {
+      const int P = geom->Ho * geom->Wo;
+#define C1_LAUNCH(PT_, KG_)                                                                                          \
+  hipLaunchKernelGGL((k_conv1x1<PT_, KG_>), dim3((unsigned)((Mtot + 64 * PT_ - 1) / (64 * PT_))), dim3(256), 0, S(stream), A, P, \
+                     (long)Mtot)
+      switch (kg) {                                        // resident activations: PT * KG float4 per lane (<= 64 registers)
+        case 2: C1_LAUNCH(4, 2); break;
+        case 4: C1_LAUNCH(4, 4); break;
+        case 6: C1_LAUNCH(2, 6); break;
+        case 8: C1_LAUNCH(2, 8); break;
+        case 12: C1_LAUNCH(1, 12); break;
+        default: C1_LAUNCH(1, 16); break;
+      }
+#undef C1_LAUNCH
+      return msgm_check_launch();
+    }
+  }
   // stride-1 "same" convolution (or its dgrad) on a big enough image: halo-tile kernel
   if (conv_tile_eligible(geom, C0, src1, C1, CoutP)) {
     const bool two_d = geom->Ho > 1;
