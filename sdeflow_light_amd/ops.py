@@ -626,6 +626,40 @@ def attention_dual_forward(qkv, Bp, T, C, scale):
     return att, stats
 
 
+_HIP_NODE_KINDS = {0: "kernel", 1: "memcpy", 2: "memset", 3: "host", 4: "graph", 5: "empty", 6: "wait_event",
+                   7: "event_record", 8: "ext_semas_signal", 9: "ext_semas_wait", 10: "mem_alloc", 11: "mem_free",
+                   12: "memcpy_from_symbol", 13: "memcpy_to_symbol"}
+
+
+def new_graph():
+    """A torch hipGraph wrapper that KEEPS the captured hipGraph_t next to the executable one, so that graph_node_kinds()
+    can list what was captured."""
+    return torch.cuda.CUDAGraph(keep_graph=True)
+
+
+def graph_node_kinds(graph) -> dict:
+    """{node kind: count} of a captured graph made by new_graph().  The captured steps of this package are meant to be
+    kernel nodes only: a hipMemsetAsync / D2D hipMemcpyAsync node can lose its ordering against the kernel nodes around it
+    when a replay starts on an idle GPU (ROCm 7.2; see msgm_zero_async in csrc/common.h), so tests assert on this."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    g = ctypes.c_void_p(graph.raw_cuda_graph())
+    n = ctypes.c_size_t(0)
+    if hip.hipGraphGetNodes(g, None, ctypes.byref(n)) != 0:
+        raise MsgmError("hipGraphGetNodes failed")
+    nodes = (ctypes.c_void_p * max(n.value, 1))()
+    if hip.hipGraphGetNodes(g, nodes, ctypes.byref(n)) != 0:
+        raise MsgmError("hipGraphGetNodes failed")
+    kinds = {}
+    for i in range(n.value):
+        t = ctypes.c_int(-1)
+        if hip.hipGraphNodeGetType(ctypes.c_void_p(nodes[i]), ctypes.byref(t)) != 0:
+            raise MsgmError("hipGraphNodeGetType failed")
+        k = _HIP_NODE_KINDS.get(t.value, f"kind{t.value}")
+        kinds[k] = kinds.get(k, 0) + 1
+    return kinds
+
+
 _SCRATCH = {}
 _SCRATCH_KEEP = []          # outgrown workspaces stay alive: a captured hipGraph may still hold their address
 

@@ -271,7 +271,7 @@ class GraphedEMSampler:
             body()                                   # warm-up (loads code objects) before capture
         torch.cuda.current_stream(dev).wait_stream(s)
         torch.cuda.synchronize(dev)
-        self.graph = torch.cuda.CUDAGraph()
+        self.graph = ops.new_graph()
         with torch.cuda.graph(self.graph):
             body()
 
@@ -364,7 +364,7 @@ class GraphedStepSampler:
             body()                                   # warm-up outside capture
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        self.graph = torch.cuda.CUDAGraph()
+        self.graph = ops.new_graph()
         with torch.cuda.graph(self.graph):
             body()
 

@@ -128,7 +128,7 @@ class MLPScoreTrainer(_TrainerState):
             self._body()
         torch.cuda.current_stream(self.dev).wait_stream(s)
         torch.cuda.synchronize(self.dev)
-        self.graph = torch.cuda.CUDAGraph()
+        self.graph = ops.new_graph()
         with torch.cuda.graph(self.graph):
             self._body()
 
@@ -220,7 +220,7 @@ class UNetScoreTrainer(_TrainerState):
         torch.cuda.current_stream(self.dev).wait_stream(side)
         self._collective_update()
         torch.cuda.synchronize(self.dev)
-        self.graph = torch.cuda.CUDAGraph()
+        self.graph = ops.new_graph()
         mode = "global" if self.world == 1 else "thread_local"      # a collective backend's watchdog thread must not
         with torch.cuda.graph(self.graph, capture_error_mode=mode):  # invalidate the capture
             self._fwd_bwd()

@@ -97,6 +97,11 @@ def test_trainer_graph_equals_eager():
         tr.set_data(gaussian_mixture_2d(4096, device=DEV))
         losses = [float(tr.step()) for _ in range(6)]
         outs.append((losses, tr.flat.clone()))
+        if use_graph:
+            from sdeflow_light_amd import ops
+            kinds = ops.graph_node_kinds(tr.graph)
+            print(f"captured MLP train step = {kinds}")
+            assert set(kinds) == {"kernel"}, kinds
     # ONE optimizer update per step() call in both modes (capture()'s warm-up is the first call's step): the two runs
     # match step for step, and end with the same parameters
     assert all(abs(l) < 1e6 for l in outs[0][0])

@@ -13,6 +13,7 @@ import pytest
 import torch
 
 from conftest import load_golden, rel_l2
+from sdeflow_light_amd import ops
 from test_host_gpu import make_gen, _unet1d
 from test_unet2d_gpu import _vunet
 
@@ -227,6 +228,9 @@ def test_graphed_step_sampler_equals_eager_integrator(method, base_kind):
     B, N = 6, 5
     x0 = torch.randn(B, n, device=DEV)
     gs = SS.GraphedStepSampler(gen, B, n, N, method=method, norm_correction=nc)
+    kinds = ops.graph_node_kinds(gs.graph)
+    print(f"graphed {method} ({base_kind}) step = {kinds}")
+    assert set(kinds) == {"kernel"}, kinds                 # no memset / memcpy nodes (see ops.graph_node_kinds)
     st = gen.base_sde.rng.state.clone()
     a = gs.run(x0).clone()
     gen.base_sde.rng.state.copy_(st)

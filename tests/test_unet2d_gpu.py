@@ -8,6 +8,7 @@ import torch
 import torch.nn.functional as F
 
 from conftest import load_golden, rel_l2
+from sdeflow_light_amd import ops
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -411,6 +412,10 @@ def test_unet_trainer_graph_replay_equals_eager(kind):
         tr.set_data(torch.randn(8, d, device=DEV))
         losses = [float(tr.step()) for _ in range(4)]
         assert (tr.graph is not None) == use_graph
+        if use_graph:                                       # kernel nodes only: no memset / memcpy node in the captured step
+            kinds = ops.graph_node_kinds(tr.graph)
+            print(f"{kind}: captured train step = {kinds}")
+            assert set(kinds) == {"kernel"} and kinds["kernel"] > 50, kinds
         flat, _ = net.flat_parameters()
         assert float((flat - p0).abs().max()) > 1e-6, "parameters did not move"
         out[use_graph] = (losses, flat.clone().cpu())
