@@ -316,8 +316,16 @@ typedef struct {
    * (flattened over the sources); tapmask_out[y]: y-th output-channel block of 32 (CoutP % 64 != 0) or 64. */
   uint16_t tapmask_in[16];
   uint16_t tapmask_out[8];
+  /* optional by-product for the GroupNorm that reads this convolution's output next (model/unet.py:140-143,152-155,214:
+   * every GroupNorm of the U-Net reads a convolution output): per-channel partial sums of the FINAL output values
+   * (after bias / accumulate / residual), chanstats[N][S][2][Cout] floats = {sum, sum of squares} per (sample, slot),
+   * S = msgm_conv_chanstats_slots(...) > 0 (one slot per (tile, wave) of the kernel's tiling; 0 = this convolution
+   * cannot produce them -> MSGM_E_UNSUPPORTED when set).  msgm_groupnorm_affine_chanstats() turns them into the
+   * (scale, shift) a consuming convolution applies — the separate statistics pass over the tensor disappears. */
+  float* chanstats;
 } msgm_conv_fuse_t;
 int msgm_conv_input_transform_supported(const msgm_conv_geom_t* geom, int32_t C0, int32_t C1, int32_t CoutP);
+int32_t msgm_conv_chanstats_slots(const msgm_conv_geom_t* geom, int32_t C0, int32_t C1, int32_t Cout, int32_t CoutP);
 int msgm_conv_forward_fused(const msgm_conv_geom_t* geom, const float* src0, int32_t C0, const float* src1, int32_t C1,
                             const float* Wp, int32_t Cout, int32_t CoutP, int32_t Ktot, const float* bias,
                             const float* samp_bias, int32_t n_bias, int32_t n_samp, float* out, int32_t accumulate,
@@ -442,6 +450,14 @@ int msgm_groupnorm_dual_backward2(const float* x0, int32_t C0, const float* x1, 
 int msgm_groupnorm_affine(const float* x0, int32_t C0, const float* x1, int32_t C1, const float* gamma, const float* beta,
                           float* scale, float* shift, int32_t Bp, int32_t P, int32_t G, float eps, void* workspace,
                           size_t workspace_bytes, msgm_stream_t stream);
+
+/* The same affine map WITHOUT reading the tensor: from the per-channel partial sums the producing convolution(s) wrote
+ * (msgm_conv_fuse_t.chanstats; cs0 = [Bp][S0][2][C0], cs1 (may be NULL) = [Bp][S1][2][C1] for the second, concatenated
+ * source).  Slots are added in slot order in double, so the result does not depend on the batch size or launch shape.
+ * P = pixels per sample.  No workspace. */
+int msgm_groupnorm_affine_chanstats(const float* cs0, int32_t S0, int32_t C0, const float* cs1, int32_t S1, int32_t C1,
+                                    const float* gamma, const float* beta, float* scale, float* shift, int32_t Bp, int32_t P,
+                                    int32_t G, float eps, msgm_stream_t stream);
 
 /* Batched fp32-MFMA GEMM with element strides:
  *   C[b](i,j) (+)= alpha ( sum_k A[b](i,k) B[b](k,j) + sum_k A2[b](i,k) B2[b](k,j) )

@@ -269,9 +269,16 @@ class VorticityUNet(nn.Module, FlatParamMixin):
         out = ops.groupnorm_dual_forward(h, gnm.weight.detach(), gnm.bias.detach(), Bp, P, C, G, dual, silu, stats=stats)
         return out, stats
 
-    def _gn_fold(self, gnm: nn.GroupNorm, x, Bp, P, C):
-        """GroupNorm as a per-(sample, channel) affine map for a conv that applies it while staging its input."""
-        return ops.groupnorm_affine(x, C, gnm.weight.detach(), gnm.bias.detach(), Bp, P, gnm.num_groups)
+    def _gn_fold(self, gnm: nn.GroupNorm, x, Bp, P, C, x1=None, C1=0):
+        """GroupNorm as a per-(sample, channel) affine map for a conv that applies it while staging its input.  When the
+        convolution(s) that produced x (and x1, the concatenated second source) left their per-channel sums on the tensor
+        (ConvOp.forward(stats=True)), the statistics come from those few KB instead of a pass over the tensor."""
+        cs = getattr(x, "_msgm_cs", None)
+        cs1 = getattr(x1, "_msgm_cs", None) if x1 is not None else None
+        if cs is not None and (x1 is None or cs1 is not None) and self._cs_on:
+            return ops.groupnorm_affine_cs(cs[0], cs[1], C, gnm.weight.detach(), gnm.bias.detach(), Bp, P, gnm.num_groups,
+                                           cs1=cs1[0] if cs1 is not None else None, S1=cs1[1] if cs1 is not None else 0, C1=C1)
+        return ops.groupnorm_affine(x, C, gnm.weight.detach(), gnm.bias.detach(), Bp, P, gnm.num_groups, x1=x1, C1=C1)
 
     def _res_fwd(self, r: _Res, x, N, Bp, H, W, semb, dual, tape, er):
         P = H * W
@@ -293,16 +300,17 @@ class VorticityUNet(nn.Module, FlatParamMixin):
             h0, s0 = x
             C0, C1 = r.split
             gnm = r.m.in_layers[0]
-            aff = ops.groupnorm_affine(h0, C0, gnm.weight.detach(), gnm.bias.detach(), Bp, P, gnm.num_groups, x1=s0, C1=C1)
+            aff = self._gn_fold(gnm, h0, Bp, P, C0, x1=s0, C1=C1)
             wn = getattr(self, "_wino", False)
-            h2, _, _ = r.conv1_2.forward([h0, s0], N, H, W, Bp, samp_bias=eo, emb_rows=er, in_affine=aff, in_act=1, wino=wn)
+            h2, _, _ = r.conv1_2.forward([h0, s0], N, H, W, Bp, samp_bias=eo, emb_rows=er, in_affine=aff, in_act=1, wino=wn,
+                                         stats=True)
             out, _, _ = r.skip_2.forward([h0, s0], N, H, W, Bp)
             if r.conv2.can_transform_input(N, H, W):
                 r.conv2.forward([h2], N, H, W, Bp, out=out, accumulate=True,
-                                in_affine=self._gn_fold(r.m.out_layers[0], h2, Bp, P, r.co), in_act=1, wino=wn)
+                                in_affine=self._gn_fold(r.m.out_layers[0], h2, Bp, P, r.co), in_act=1, wino=wn, stats=True)
             else:
                 h3, _ = self._gn(r.m.out_layers[0], h2, Bp, P, r.co, False, True, None)
-                r.conv2.forward([h3], N, H, W, Bp, out=out, accumulate=True, wino=wn)
+                r.conv2.forward([h3], N, H, W, Bp, out=out, accumulate=True, wino=wn, stats=True)
             return out
         fold = (not dual and tape is None and not os.environ.get("MSGM_NO_GN_FOLD")
                 and r.conv1.can_transform_input(N, H, W) and r.conv2.can_transform_input(N, H, W))
@@ -311,13 +319,13 @@ class VorticityUNet(nn.Module, FlatParamMixin):
             # is added in conv2's epilogue — the two normalised tensors and the separate add pass never exist
             wn = getattr(self, "_wino", False)
             h2, _, _ = r.conv1.forward([x], N, H, W, Bp, samp_bias=eo, emb_rows=er,
-                                       in_affine=self._gn_fold(r.m.in_layers[0], x, Bp, P, r.ci), in_act=1, wino=wn)
+                                       in_affine=self._gn_fold(r.m.in_layers[0], x, Bp, P, r.ci), in_act=1, wino=wn, stats=True)
             aff2 = self._gn_fold(r.m.out_layers[0], h2, Bp, P, r.co)
             if r.skip is not None:
                 out, _, _ = r.skip.forward([x], N, H, W, Bp)
-                r.conv2.forward([h2], N, H, W, Bp, out=out, accumulate=True, in_affine=aff2, in_act=1, wino=wn)
+                r.conv2.forward([h2], N, H, W, Bp, out=out, accumulate=True, in_affine=aff2, in_act=1, wino=wn, stats=True)
             else:
-                out, _, _ = r.conv2.forward([h2], N, H, W, Bp, residual=x, in_affine=aff2, in_act=1, wino=wn)
+                out, _, _ = r.conv2.forward([h2], N, H, W, Bp, residual=x, in_affine=aff2, in_act=1, wino=wn, stats=True)
             return out
         h1, st1 = self._gn(r.m.in_layers[0], x, Bp, P, r.ci, dual, True, tape)
         h2, _, _ = r.conv1.forward([h1], N, H, W, Bp, samp_bias=eo, emb_rows=er)
@@ -342,7 +350,7 @@ class VorticityUNet(nn.Module, FlatParamMixin):
                 hn, _ = self._gn(a.m.norm, x, Bp, T, C, False, False, None)
                 qkv, _, _ = a.qkv.forward([hn], N, 1, T, Bp)
             att = ops.attention_forward(qkv, torch.empty(N * T * C, device=dev), N, T, C, s2)
-            out, _, _ = a.proj.forward([att], N, 1, T, Bp, residual=x)    # x + proj(.) in the epilogue (unet.py:232)
+            out, _, _ = a.proj.forward([att], N, 1, T, Bp, residual=x, stats=True)    # x + proj(.) in the epilogue (unet.py:232)
             return out
         hn, st = self._gn(a.m.norm, x, Bp, T, C, dual, False, tape)
         qkv, _, _ = a.qkv.forward([hn], N, 1, T, Bp)                     # [N][T][3C]: q | k | v channel slices
@@ -389,6 +397,7 @@ class VorticityUNet(nn.Module, FlatParamMixin):
         # SiLU are applied in the halo staging (the staging, not the MFMA count, is what those launches wait for), i.e.
         # +1 % on the C5 step (tools/bench_wino.py) — not worth a second rounding path in the default sampler
         self._wino = not dual and tape is None and bool(os.environ.get("MSGM_WINO"))
+        self._cs_on = not os.environ.get("MSGM_NO_CHANSTATS")            # diagnostic A/B: GroupNorm statistics by a pass over the tensor
         if self._wino:
             x["set"].pack_wino()
         core = self.core
@@ -418,7 +427,7 @@ class VorticityUNet(nn.Module, FlatParamMixin):
                 if kind == "conv":
                     if tape is not None:
                         tape.append(("conv", o, h, H, W))
-                    h, H, W = o.forward([h], N, H, W, Bp)
+                    h, H, W = o.forward([h], N, H, W, Bp, stats=not dual and tape is None)
                     C = o.Cout
                 elif kind == "res":
                     h = self._res_fwd(o, h, N, Bp, H, W, semb, dual, tape, er)
@@ -428,7 +437,7 @@ class VorticityUNet(nn.Module, FlatParamMixin):
                 elif kind in ("down", "up"):
                     if tape is not None:
                         tape.append((kind, o, h, H, W))
-                    h, H, W = o.forward([h], N, H, W, Bp, wino=getattr(self, "_wino", False))
+                    h, H, W = o.forward([h], N, H, W, Bp, wino=getattr(self, "_wino", False), stats=not dual and tape is None)
             return h, C, H, W
 
         h, C = img, core.in_channels

@@ -33,7 +33,8 @@ class SdeT(C.Structure):
 class ConvFuseT(C.Structure):
     """msgm_conv_fuse_t (include/msgm_hip.h)."""
     _fields_ = [("residual", C.c_void_p), ("in_scale", C.c_void_p), ("in_shift", C.c_void_p), ("in_act", C.c_int32),
-                ("reserved", C.c_int32), ("tapmask_in", C.c_uint16 * 16), ("tapmask_out", C.c_uint16 * 8)]
+                ("reserved", C.c_int32), ("tapmask_in", C.c_uint16 * 16), ("tapmask_out", C.c_uint16 * 8),
+                ("chanstats", C.c_void_p)]
 
 
 class PackJobT(C.Structure):
@@ -86,6 +87,8 @@ SIGNATURES = {
     "msgm_conv_forward_wino": (C.c_int, [C.POINTER(ConvGeomT), _P, _I32, _P, _I32, _P, _I32, _I32, _I32, _P, _P, _I32, _I32, _P, _I32, C.POINTER(ConvFuseT), _P]),
     "msgm_conv_input_transform_supported": (C.c_int, [C.POINTER(ConvGeomT), _I32, _I32, _I32]),
     "msgm_groupnorm_affine": (C.c_int, [_P, _I32, _P, _I32, _P, _P, _P, _P, _I32, _I32, _I32, _F, _P, C.c_size_t, _P]),
+    "msgm_conv_chanstats_slots": (C.c_int32, [C.POINTER(ConvGeomT), _I32, _I32, _I32, _I32]),
+    "msgm_groupnorm_affine_chanstats": (C.c_int, [_P, _I32, _I32, _P, _I32, _I32, _P, _P, _P, _P, _I32, _I32, _I32, _F, _P]),
     "msgm_conv_wgrad": (C.c_int, [C.POINTER(ConvGeomT), _P, _P, _I32, _I32, _P, _I32, _I32, _I32, _P, _I32,
                                   C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), _P]),
     "msgm_conv_wgrad_workspace": (_SZ, [C.POINTER(ConvGeomT), _I32, _I32, _I32, _I32]),

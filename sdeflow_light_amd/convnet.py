@@ -221,10 +221,12 @@ class ConvOp:
     def forward(self, srcs: List[torch.Tensor], N: int, Hi: int, Wi: int, n_bias: int, emb: Optional[torch.Tensor] = None,
                 samp_bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, accumulate=False,
                 emb_rows: Optional[int] = None, residual: Optional[torch.Tensor] = None,
-                in_affine: Optional[tuple] = None, in_act: int = 0, wino: bool = False):
+                in_affine: Optional[tuple] = None, in_act: int = 0, wino: bool = False, stats: bool = False):
         """emb_rows: rows that carry an embedding / per-sample bias (n_bias by default; N when the embedding itself
         has a tangent — NormalizeLogRadius conditioning).  wino: take the Winograd F(2x2,3x3) forward kernel when this
-        op has its image (ConvOpSet.pack_wino) and the geometry allows it (sampler path)."""
+        op has its image (ConvOpSet.pack_wino) and the geometry allows it (sampler path).
+        stats: if the kernel serving this convolution can, leave the per-channel sums of the output on the returned
+        tensor as ``out._msgm_cs = (chanstats, slots)`` for the GroupNorm that reads it next."""
         geom, Ho, Wo = self._geom(N, Hi, Wi)
         wino = bool(wino and self.WpW is not None and
                     ops.conv_wino_supported(geom, self.srcC[0], self.srcC[1] if len(srcs) > 1 else 0, self.CoutP))
@@ -243,12 +245,20 @@ class ConvOp:
             sb = torch.empty(Bp * self.Cout, device=dev)
             ops.lincomb(sb, E[0], 1.0, E[1], 1.0, E[2], 1.0)
             self._E = E
+        cs, S = None, 0
+        out._msgm_cs = None                      # whatever was there described the values about to be overwritten
+        if stats and not wino and not self.embC:
+            S = ops.conv_chanstats_slots(geom, self.srcC[0], self.srcC[1] if len(srcs) > 1 else 0, self.Cout, self.CoutP)
+            if S > 0:
+                cs = torch.empty(N * S * 2 * self.Cout, device=dev)
         ops.conv_forward(geom, srcs[0], self.srcC[0], self.WpW if wino else self.Wp, self.Cout, out,
                          src1=srcs[1] if len(srcs) > 1 else None, C1=self.srcC[1] if len(srcs) > 1 else 0,
                          bias=self.bias.detach() if self.bias is not None else None, samp_bias=sb, n_bias=n_bias,
                          accumulate=accumulate, CoutP=self.CoutP, n_samp=er, residual=residual,
                          in_scale=in_affine[0] if in_affine is not None else None,
-                         in_shift=in_affine[1] if in_affine is not None else None, in_act=in_act, wino=wino)
+                         in_shift=in_affine[1] if in_affine is not None else None, in_act=in_act, wino=wino, chanstats=cs)
+        if cs is not None:
+            out._msgm_cs = (cs, S)
         if self.embC:
             # taps 0 / 2 fall on the zero padding at l = 0 / L-1 (rows that carry an embedding)
             ops.add_row(out, self._E[0], er, Ho * Wo, self.Cout, 0, -1.0)

@@ -56,7 +56,32 @@ struct ConvArgs {
   // tapmask_in[i]: per 32-channel input chunk (flattened over the sources), tapmask_out[y]: per output-channel block
   unsigned short tapmask_in[16];
   unsigned short tapmask_out[8];
+  // optional by-product (k_conv_tile, k_conv1x1): per-channel partial sums of the FINAL output values (after bias /
+  // accumulate / residual) for the GroupNorm that reads this output next — cstat[n][slot < cs_S][{sum, sum of squares}][Cout],
+  // one slot per (tile, wave) of a sample; the consumer adds the slots in slot order (k_gn_affine_cs)
+  float* cstat;
+  int cs_S;
 };
+
+// Sum over the 16 lanes of a DPP row (the 16 pixel lanes of one channel quad), fixed butterfly: every lane ends with it.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));  // row_mirror
+  return v;
+}
+// A wave's (sum, sum of squares) of 4 consecutive output channels over its pixels -> slot `slot` of sample n.
+__device__ __forceinline__ void cstat_store(const ConvArgs& A, int n, int slot, int co, f32x4 s, f32x4 ss, int il) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { s[r] = row16_sum(s[r]); ss[r] = row16_sum(ss[r]); }
+  if (il == 0) {
+    float* cp = A.cstat + (((size_t)n * A.cs_S + slot) * 2) * A.Cout + co;
+    *reinterpret_cast<f32x4*>(cp) = s;
+    *reinterpret_cast<f32x4*>(cp + A.Cout) = ss;
+  }
+}
+
 
 // input coordinate of output coordinate o for tap k; returns false when the tap falls outside
 __device__ __forceinline__ bool src_coord(const ConvGeom& g, int o, int k, int in_size_up, int stride, int pad, int& i) {
@@ -196,6 +221,9 @@ __global__ void __launch_bounds__(256) k_conv_gemm(ConvArgs A) {
   }
 
   // ---- epilogue: lane (position il of tile nt, q) holds channels co0+16mt+4q+r
+  f32x4 cs[MT], css[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) { cs[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; css[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     if (!pin[nt]) continue;
@@ -220,11 +248,19 @@ __global__ void __launch_bounds__(256) k_conv_gemm(ConvArgs A) {
         if (A.accumulate) v += *reinterpret_cast<const f32x4*>(op);
         if (A.residual) v += *reinterpret_cast<const f32x4*>(A.residual + (op - A.out));
         *reinterpret_cast<f32x4*>(op) = v;
+        cs[mt] += v; css[mt] += v * v;
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (co + r < A.Cout) op[r] = (A.accumulate ? op[r] + v[r] : v[r]) + (A.residual ? A.residual[(op - A.out) + r] : 0.f);
       }
+    }
+  }
+  if (A.cstat) {       // host: Ho*Wo % (16 NT) == 0 and Cout % 4 == 0, so the wave's pixels are one slot of one sample
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int co = co0 + 16 * mt + 4 * q;
+      if (co < A.Cout) cstat_store(A, m0 / HoWo, (m0 % HoWo) / (16 * NT), co, cs[mt], css[mt], il);
     }
   }
 }
@@ -313,14 +349,6 @@ __global__ void __launch_bounds__(256, CT_MINWG) k_conv_tile(ConvArgs A, int fli
     const int ty_i = t % tiles_y;
     n = t / tiles_y; y0 = ty_i * TH; x0 = tx_i * TW;
   };
-  // this thread's halo positions are the same for every tile: (row, column) inside the halo, packed, once
-  int hyx[MAXST];
-#pragma unroll
-  for (int k = 0; k < MAXST; ++k) {
-    const int hp = (tid + 256 * k) >> 3;
-    const int hy = hp / HW;
-    hyx[k] = (hy << 16) | (hp - hy * HW);
-  }
   auto stage_load = [&](f32x4* dst, int t, int s, int c0) {
     int n, y0, x0;
     tile_origin(t, n, y0, x0);
@@ -335,13 +363,19 @@ __global__ void __launch_bounds__(256, CT_MINWG) k_conv_tile(ConvArgs A, int fli
       ga = *reinterpret_cast<const f32x4*>(A.in_scale + o);
       gb = *reinterpret_cast<const f32x4*>(A.in_shift + o);
     }
+    // this thread's halo positions (row, column) are the same for every tile but are RE-derived per item (HW is a
+    // compile-time constant: a multiply-high each): kept in registers they were MAXST live values at the kernel's
+    // register peak (the epilogue) — the opaque copy of tid keeps the compiler from hoisting them back out of the loop
+    int tv = tid;
+    asm volatile("" : "+v"(tv));
 #pragma unroll
     for (int k = 0; k < MAXST; ++k) {
       const int idx = tid + 256 * k;
       f32x4 v = {0, 0, 0, 0};
       if (idx < n_items) {
         const int c4 = idx & 7;
-        const int hy = hyx[k] >> 16, hx = hyx[k] & 0xffff;
+        const int hp = (tv + 256 * k) >> 3;
+        const int hy = hp / HW, hx = hp - hy * HW;
         const int iy = y0 + hy - padH, ix = x0 + hx - padW;     // on the (2x nearest-upsampled, if ups) input grid
         const int c = c0 + 4 * c4;
 #ifdef CT_EXP_NOSTAGE    // diagnostic: no halo loads / index arithmetic
@@ -498,6 +532,7 @@ __global__ void __launch_bounds__(256, CT_MINWG) k_conv_tile(ConvArgs A, int fli
 #pragma unroll
             for (int r = 0; r < 4; ++r) if (co + r < A.Cout) add[r] += sbp[r];
         }
+        f32x4 cs = {0.f, 0.f, 0.f, 0.f}, css = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
           if (!((y0 + pty[pt] < g.Ho) && (x0 + ptx[pt] < g.Wo))) continue;
@@ -508,12 +543,14 @@ __global__ void __launch_bounds__(256, CT_MINWG) k_conv_tile(ConvArgs A, int fli
             if (A.accumulate) v += *reinterpret_cast<const f32x4*>(op);
             if (A.residual) v += *reinterpret_cast<const f32x4*>(A.residual + (op - A.out));
             *reinterpret_cast<f32x4*>(op) = v;
+            cs += v; css += v * v;
           } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
               if (co + r < A.Cout) op[r] = (A.accumulate ? op[r] + v[r] : v[r]) + (A.residual ? A.residual[(op - A.out) + r] : 0.f);
           }
         }
+        if (A.cstat) cstat_store(A, n, (tile - n * tiles_x * tiles_y) * 4 + w, co, cs, css, il);   // Cout % 4 == 0 (host)
       }
     }
     if (!more) break;
@@ -607,6 +644,7 @@ __global__ void __launch_bounds__(256) k_conv1x1(ConvArgs A, int P /* pixels per
     const int co = 16 * ct + 4 * q;
     if (co >= A.Cout) continue;
     const bool full = vec && (co + 3 < A.Cout);
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f}, css = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
       if (!pin[pt]) continue;
@@ -634,12 +672,15 @@ __global__ void __launch_bounds__(256) k_conv1x1(ConvArgs A, int P /* pixels per
         if (A.accumulate) v += *reinterpret_cast<const f32x4*>(op);
         if (A.residual) v += *reinterpret_cast<const f32x4*>(A.residual + (op - A.out));
         *reinterpret_cast<f32x4*>(op) = v;
+        cs += v; css += v * v;
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (co + r < A.Cout) op[r] = (A.accumulate ? op[r] + v[r] : v[r]) + (A.residual ? A.residual[(op - A.out) + r] : 0.f);
       }
     }
+    // host: P % (16 PT) == 0 and Cout % 4 == 0 when cstat is set, so the wave's pixels are one slot of one sample
+    if (A.cstat) cstat_store(A, (int)(m0 / P), (int)((m0 % P) / (16 * PT)), co, cs, css, il);
   }
 }
 
@@ -1398,6 +1439,7 @@ int msgm_conv_forward_wino(const msgm_conv_geom_t* geom, const float* src0, int3
   A.nsrc = src1 ? 2 : 1;
   A.Wp = WpW; A.Cout = Cout; A.CoutP = CoutP; A.Ktot = Ktot;
   A.bias = bias; A.samp_bias = samp_bias; A.n_bias = n_bias; A.n_samp = n_samp; A.out = out; A.accumulate = accumulate;
+  if (fuse && fuse->chanstats) return MSGM_E_UNSUPPORTED;       // no channel-statistics by-product in this kernel
   if (fuse) { A.residual = fuse->residual; A.in_scale = fuse->in_scale; A.in_shift = fuse->in_shift; A.in_act = fuse->in_act; }
   const int tiles_x = geom->Wo / 16, tiles_y = geom->Ho / 16;
   const int n_tiles = tiles_x * tiles_y * geom->N, gy = CoutP / 32;
@@ -1405,6 +1447,65 @@ int msgm_conv_forward_wino(const msgm_conv_geom_t* geom, const float* src0, int3
   dim3 grid((unsigned)(8 * gy * ((n_tiles + 7) / 8)));
   hipLaunchKernelGGL((k_conv_wino<2>), grid, dim3(256), lds, S(stream), A, tiles_x, tiles_y, n_tiles, gy, n_tiles);
   return msgm_check_launch();
+}
+
+// Which kernel serves a forward convolution, and with what tiling — ONE decision shared by the launcher and by
+// msgm_conv_chanstats_slots (the channel-statistics by-product is laid out per (tile, wave) of that tiling).
+struct ConvRoute {
+  int kind;                 // 0 implicit GEMM from L2, 1 pixel-stationary 1x1, 2 halo tile
+  int pt, kg;               // 1x1: 16-pixel tiles per wave, 16-channel input groups
+  bool wide, two_d; int nco, TH, TW, tiles_x, tiles_y;      // halo tile
+};
+static ConvRoute conv_route(const msgm_conv_geom_t* geom, int32_t C0, bool has1, int32_t C1, int32_t CoutP, bool masks) {
+  ConvRoute r{};
+  const int64_t Mtot = (int64_t)geom->N * geom->Ho * geom->Wo;
+  const bool fast = (C0 % 16 == 0) && (!has1 || C1 % 16 == 0);
+  const int Ktot = ((C0 + 15) / 16) * 16 + (has1 ? ((C1 + 15) / 16) * 16 : 0);
+  static const bool no1 = getenv("MSGM_NO_CONV1X1") != nullptr;            // diagnostic A/B
+  const int kg = Ktot / 16;
+  if (!no1 && geom->KH == 1 && geom->KW == 1 && geom->strideH == 1 && geom->strideW == 1 && geom->padH == 0 && geom->padW == 0 &&
+      !geom->ups && geom->Hi == geom->Ho && geom->Wi == geom->Wo && fast && !masks && Mtot >= 4096 &&
+      (kg == 2 || kg == 4 || kg == 6 || kg == 8 || kg == 12 || kg == 16)) {
+    r.kind = 1; r.kg = kg;
+    r.pt = kg <= 4 ? 4 : (kg <= 8 ? 2 : 1);                // resident activations: PT * KG float4 per lane (<= 64 registers)
+    return r;
+  }
+  static const float dummy = 0.f;
+  if (conv_tile_eligible(geom, C0, has1 ? &dummy : nullptr, C1, CoutP)) {
+    r.kind = 2;
+    r.two_d = geom->Ho > 1;
+    r.nco = (CoutP % 64 == 0) ? 4 : 2;
+    // 3-tap / 3x3 kernels: 256-pixel tiles (4 MFMA column tiles per wave, one LDS buffer) when the image has them —
+    // measured +10..27 % in 2-D and +3..8 % in 1-D over the 128-pixel double-buffered form (tools/exp_wide.py);
+    // 1x1 kernels (no tap reuse, HBM-bound) stay on the 128-pixel form, which measured equal or better
+    const bool no_wide = getenv("MSGM_NO_CONV_WIDE") != nullptr;            // diagnostic A/B
+    bool wide = geom->KW == 3 && !no_wide && (r.two_d ? (geom->Ho >= 16 && geom->Wo >= 16) : geom->Wo >= 256);
+    if (wide) {
+      // small launches (the 32-row per-GPU shard of C4): below two 256-pixel workgroups per CU the chip is not
+      // filled — 128-pixel tiles double the workgroup count (B = 32 step 26.3 -> 25.5 ms; no change at B >= 128)
+      const int64_t wtiles = (int64_t)geom->N * ((geom->Wo + (r.two_d ? 15 : 255)) / (r.two_d ? 16 : 256)) *
+                             (r.two_d ? (geom->Ho + 15) / 16 : 1) * (CoutP / (16 * r.nco));
+      if (wtiles < 512) wide = false;
+    }
+    r.wide = wide;
+    r.TH = r.two_d ? (wide ? 16 : 8) : 1; r.TW = r.two_d ? 16 : (wide ? 256 : 128);
+    r.tiles_x = (geom->Wo + r.TW - 1) / r.TW; r.tiles_y = (geom->Ho + r.TH - 1) / r.TH;
+    return r;
+  }
+  r.pt = (CoutP >= 64 && CoutP % 64 == 0) ? 2 : 4;         // NT of the k_conv_gemm<MT, NT> instantiation launched below
+  return r;
+}
+static int conv_route_slots(const ConvRoute& r, const msgm_conv_geom_t* geom, int32_t Cout) {
+  if (Cout % 4) return 0;
+  if (r.kind == 1) { const int P = geom->Ho * geom->Wo; return P % (16 * r.pt) == 0 ? P / (16 * r.pt) : 0; }
+  if (r.kind == 2) return r.tiles_x * r.tiles_y * 4;
+  const int P = geom->Ho * geom->Wo, px = 16 * r.pt;      // implicit GEMM: a wave owns 16 NT consecutive pixels
+  return P % px == 0 ? P / px : 0;
+}
+
+int32_t msgm_conv_chanstats_slots(const msgm_conv_geom_t* geom, int32_t C0, int32_t C1, int32_t Cout, int32_t CoutP) {
+  if (check_geom(geom) || C0 <= 0 || C1 < 0 || Cout <= 0 || CoutP < Cout || CoutP % 16) return 0;
+  return conv_route_slots(conv_route(geom, C0, C1 > 0, C1, CoutP, false), geom, Cout);
 }
 
 int msgm_conv_forward(const msgm_conv_geom_t* geom, const float* src0, int32_t C0, const float* src1, int32_t C1,
@@ -1441,52 +1542,38 @@ int msgm_conv_forward_fused(const msgm_conv_geom_t* geom, const float* src0, int
   }
   const int64_t Mtot = (int64_t)geom->N * geom->Ho * geom->Wo;
   const bool fast = (C0 % 16 == 0) && (!src1 || C1 % 16 == 0);
+  bool masks = false;
+  if (fuse) {
+    for (int i = 0; i < 16; ++i) masks = masks || fuse->tapmask_in[i];
+    for (int i = 0; i < 8; ++i) masks = masks || fuse->tapmask_out[i];
+  }
+  const ConvRoute rt = conv_route(geom, C0, src1 != nullptr, C1, CoutP, masks);
+  if (fuse && fuse->chanstats) {
+    A.cs_S = masks ? 0 : conv_route_slots(rt, geom, Cout);
+    if (A.cs_S == 0) return MSGM_E_UNSUPPORTED;            // ask msgm_conv_chanstats_slots() first
+    A.cstat = fuse->chanstats;
+  }
   // 1x1 stride-1 convolution (forward or dgrad): pixel-stationary streaming kernel, no LDS
-  {
-    static const bool no1 = getenv("MSGM_NO_CONV1X1") != nullptr;            // diagnostic A/B
-    const int kg = Ktot / 16;
-    bool masks = false;
-    if (fuse) {
-      for (int i = 0; i < 16; ++i) masks = masks || fuse->tapmask_in[i];
-      for (int i = 0; i < 8; ++i) masks = masks || fuse->tapmask_out[i];
-    }
-    if (!no1 && geom->KH == 1 && geom->KW == 1 && geom->strideH == 1 && geom->strideW == 1 && geom->padH == 0 && geom->padW == 0 &&
-        !geom->ups && geom->Hi == geom->Ho && geom->Wi == geom->Wo && fast && !masks && Mtot >= 4096 &&
-        (kg == 2 || kg == 4 || kg == 6 || kg == 8 || kg == 12 || kg == 16)) {
-      const int P = geom->Ho * geom->Wo;
+  if (rt.kind == 1) {
+    const int P = geom->Ho * geom->Wo;
 #define C1_LAUNCH(PT_, KG_)                                                                                          \
   hipLaunchKernelGGL((k_conv1x1<PT_, KG_>), dim3((unsigned)((Mtot + 64 * PT_ - 1) / (64 * PT_))), dim3(256), 0, S(stream), A, P, \
                      (long)Mtot)
-      switch (kg) {                                        // resident activations: PT * KG float4 per lane (<= 64 registers)
-        case 2: C1_LAUNCH(4, 2); break;
-        case 4: C1_LAUNCH(4, 4); break;
-        case 6: C1_LAUNCH(2, 6); break;
-        case 8: C1_LAUNCH(2, 8); break;
-        case 12: C1_LAUNCH(1, 12); break;
-        default: C1_LAUNCH(1, 16); break;
-      }
-#undef C1_LAUNCH
-      return msgm_check_launch();
+    switch (rt.kg) {
+      case 2: C1_LAUNCH(4, 2); break;
+      case 4: C1_LAUNCH(4, 4); break;
+      case 6: C1_LAUNCH(2, 6); break;
+      case 8: C1_LAUNCH(2, 8); break;
+      case 12: C1_LAUNCH(1, 12); break;
+      default: C1_LAUNCH(1, 16); break;
     }
+#undef C1_LAUNCH
+    return msgm_check_launch();
   }
   // stride-1 "same" convolution (or its dgrad) on a big enough image: halo-tile kernel
-  if (conv_tile_eligible(geom, C0, src1, C1, CoutP)) {
-    const bool two_d = geom->Ho > 1;
-    const int nco = (CoutP % 64 == 0) ? 4 : 2;
-    // 3-tap / 3x3 kernels: 256-pixel tiles (4 MFMA column tiles per wave, one LDS buffer) when the image has them —
-    // measured +10..27 % in 2-D and +3..8 % in 1-D over the 128-pixel double-buffered form (tools/exp_wide.py);
-    // 1x1 kernels (no tap reuse, HBM-bound) stay on the 128-pixel form, which measured equal or better
-    const bool no_wide = getenv("MSGM_NO_CONV_WIDE") != nullptr;            // diagnostic A/B
-    bool wide = geom->KW == 3 && !no_wide && (two_d ? (geom->Ho >= 16 && geom->Wo >= 16) : geom->Wo >= 256);
-    if (wide) {
-      // small launches (the 32-row per-GPU shard of C4): below two 256-pixel workgroups per CU the chip is not
-      // filled — 128-pixel tiles double the workgroup count (B = 32 step 26.3 -> 25.5 ms; no change at B >= 128)
-      const int64_t wtiles = (int64_t)geom->N * ((geom->Wo + (two_d ? 15 : 255)) / (two_d ? 16 : 256)) *
-                             (two_d ? (geom->Ho + 15) / 16 : 1) * (CoutP / (16 * nco));
-      if (wtiles < 512) wide = false;
-    }
-    const int TH = two_d ? (wide ? 16 : 8) : 1, TW = two_d ? 16 : (wide ? 256 : 128);
-    const int tiles_x = (geom->Wo + TW - 1) / TW, tiles_y = (geom->Ho + TH - 1) / TH;
+  if (rt.kind == 2) {
+    const bool two_d = rt.two_d, wide = rt.wide;
+    const int nco = rt.nco, TH = rt.TH, TW = rt.TW, tiles_x = rt.tiles_x, tiles_y = rt.tiles_y;
     const int halo = (TH + geom->KH - 1) * (TW + geom->KW - 1);
     const size_t lds = (size_t)(wide ? 1 : 2) * halo * CT_P * sizeof(float);
     const int n_tiles = tiles_x * tiles_y * geom->N, gy = CoutP / (16 * nco);

@@ -1001,6 +1001,49 @@ int msgm_groupnorm_affine(const float* x0, int32_t C0, const float* x1, int32_t 
   return msgm_check_launch();
 }
 
+// The same affine map from the per-channel partial sums a producing convolution left behind (msgm_conv_fuse_t.chanstats:
+// cs[n][slot][{sum, sum of squares}][Csrc], fp32 sums over one wave's 64..256 pixels): thread c adds the slots of its
+// channel in slot order in double, the channels of a group are combined in double — no pass over the tensor itself.
+// One block per sample; two sources = the decoder's cat([h, skip]) (each source has its own producer and slot count).
+__global__ void __launch_bounds__(256) k_gn_affine_cs(const float* __restrict__ cs0, int S0, int C0, const float* __restrict__ cs1,
+                                                      int S1, int C1, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, int P, int G, float eps,
+                                                      float* __restrict__ scale, float* __restrict__ shift) {
+  __shared__ double red[2][256];
+  const int b = blockIdx.x, c = threadIdx.x, C = C0 + C1, cpg = C / G;
+  if (c < C) {
+    const bool second = c >= C0;
+    const int Cs = second ? C1 : C0, S = second ? S1 : S0, cc = second ? c - C0 : c;
+    const float* p = (second ? cs1 : cs0) + (size_t)b * S * 2 * Cs + cc;
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < S; ++k) { s += (double)p[(size_t)(2 * k) * Cs]; ss += (double)p[(size_t)(2 * k + 1) * Cs]; }
+    red[0][c] = s; red[1][c] = ss;
+  }
+  __syncthreads();
+  if (c < C) {
+    const int g0 = (c / cpg) * cpg;
+    double a8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < cpg; ++k) { a8[0] += red[0][g0 + k]; a8[1] += red[1][g0 + k]; }
+    float mu, inv, md, a;
+    gn_stats(a8, (double)P * cpg, eps, mu, inv, md, a);
+    const float sc = inv * gamma[c];
+    scale[(size_t)b * C + c] = sc;
+    shift[(size_t)b * C + c] = beta[c] - mu * sc;
+  }
+}
+
+int msgm_groupnorm_affine_chanstats(const float* cs0, int32_t S0, int32_t C0, const float* cs1, int32_t S1, int32_t C1,
+                                    const float* gamma, const float* beta, float* scale, float* shift, int32_t Bp, int32_t P,
+                                    int32_t G, float eps, msgm_stream_t stream) {
+  if (!cs0 || !gamma || !beta || !scale || !shift || Bp <= 0 || P <= 0 || C0 <= 0 || S0 <= 0 || G <= 0) return MSGM_E_BADARG;
+  if (cs1 ? (C1 <= 0 || S1 <= 0) : (C1 != 0)) return MSGM_E_BADARG;
+  const int C = C0 + C1;
+  if (C % G || C > 256 || G > 64) return MSGM_E_UNSUPPORTED;
+  hipLaunchKernelGGL(k_gn_affine_cs, dim3(Bp), dim3(256), 0, S(stream), cs0, S0, C0, cs1, S1, C1, gamma, beta, P, G, eps, scale,
+                     shift);
+  return msgm_check_launch();
+}
+
 static int gn_backward_impl(const float* x, int32_t C0, const float* x1, int32_t C, const float* gamma, const float* beta,
                             const float* stats, const float* gout, float* gx, float* gx1, float* dgamma, float* dbeta, int32_t Bp,
                             int32_t P, int32_t G, int32_t silu, float eps, const float* residual, void* workspace,

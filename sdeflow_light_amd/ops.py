@@ -297,8 +297,11 @@ def conv_forward(geom: L.ConvGeomT, src0: torch.Tensor, C0: int, Wp: torch.Tenso
                  samp_bias: Optional[torch.Tensor] = None, n_bias: int = 0, accumulate: bool = False,
                  CoutP: Optional[int] = None, n_samp: Optional[int] = None, residual: Optional[torch.Tensor] = None,
                  in_scale: Optional[torch.Tensor] = None, in_shift: Optional[torch.Tensor] = None,
-                 in_act: int = 0, tapmask_in=None, tapmask_out=None, wino: bool = False) -> torch.Tensor:
+                 in_act: int = 0, tapmask_in=None, tapmask_out=None, wino: bool = False,
+                 chanstats: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[N][Ho][Wo][Cout] (+)= implicit-GEMM convolution of channels-last inputs (K6/K11).
+    chanstats [N][S][2][Cout] (S = conv_chanstats_slots(...) > 0): per-channel partial sums of the final output, for the
+    GroupNorm that reads it next (groupnorm_affine_cs).
     wino: Wp is the Winograd image [16][CoutP][Ktot] and the F(2x2,3x3) forward kernel runs (sampler path).
     residual: added in the epilogue.  in_scale / in_shift [N][C0+C1] (+ in_act=1: SiLU): the conv reads
     act(a x + b) — GroupNorm(+SiLU) folded into the input staging (see conv_input_transform_supported)."""
@@ -319,7 +322,7 @@ def conv_forward(geom: L.ConvGeomT, src0: torch.Tensor, C0: int, Wp: torch.Tenso
     if samp_bias is not None and samp_bias.numel() != n_samp * Cout:
         raise MsgmError("samp_bias must be [n_samp][Cout]")
     fuse = None
-    if residual is not None or in_scale is not None or tapmask_in or tapmask_out:
+    if residual is not None or in_scale is not None or tapmask_in or tapmask_out or chanstats is not None:
         ctot = C0 + (C1 if src1 is not None else 0)
         if residual is not None and residual.numel() != out.numel():
             raise MsgmError("residual must have the output's size")
@@ -327,6 +330,11 @@ def conv_forward(geom: L.ConvGeomT, src0: torch.Tensor, C0: int, Wp: torch.Tenso
                                                         (in_scale.numel() != geom.N * ctot or in_shift.numel() != geom.N * ctot)):
             raise MsgmError("in_scale / in_shift must both be [N][C0+C1]")
         fuse = L.ConvFuseT(ptr(residual), ptr(in_scale), ptr(in_shift), int(in_act), 0)
+        if chanstats is not None:
+            S = conv_chanstats_slots(geom, C0, C1 if src1 is not None else 0, Cout, CoutP)
+            if S <= 0 or chanstats.numel() < geom.N * S * 2 * Cout or chanstats.dtype != torch.float32:
+                raise MsgmError("chanstats: this convolution has no statistics by-product, or the buffer is too small")
+            fuse.chanstats = ptr(chanstats)
         for i, m in enumerate((tapmask_in or [])[:16]):      # structurally-zero weight blocks (tile kernel skips them)
             fuse.tapmask_in[i] = int(m)
         for i, m in enumerate((tapmask_out or [])[:8]):
@@ -342,6 +350,25 @@ def conv_forward(geom: L.ConvGeomT, src0: torch.Tensor, C0: int, Wp: torch.Tenso
                                         ptr(samp_bias), int(n_bias), int(n_samp), ptr(f32(out)), int(bool(accumulate)),
                                         fuse, stream()), "msgm_conv_forward")
     return out
+
+
+def conv_chanstats_slots(geom: L.ConvGeomT, C0: int, C1: int, Cout: int, CoutP: int) -> int:
+    """Slots per sample of the per-channel statistics by-product of this forward convolution (0 = it has none)."""
+    return int(lib().msgm_conv_chanstats_slots(geom, int(C0), int(C1), int(Cout), int(CoutP)))
+
+
+def groupnorm_affine_cs(cs0, S0, C0, gamma, beta, Bp, P, G, cs1=None, S1=0, C1=0, eps=1e-5):
+    """groupnorm_affine() from the producers' channel statistics (conv_forward(chanstats=)) instead of the tensors."""
+    C = C0 + (C1 if cs1 is not None else 0)
+    if cs0.numel() < Bp * S0 * 2 * C0 or (cs1 is not None and cs1.numel() < Bp * S1 * 2 * C1) or gamma.numel() != C or beta.numel() != C:
+        raise MsgmError("groupnorm_affine_cs: sizes")
+    scale = torch.empty(Bp * C, dtype=torch.float32, device=cs0.device)
+    shift = torch.empty(Bp * C, dtype=torch.float32, device=cs0.device)
+    check(lib().msgm_groupnorm_affine_chanstats(ptr(f32(cs0)), int(S0), int(C0), ptr(cs1), int(S1 if cs1 is not None else 0),
+                                                int(C1 if cs1 is not None else 0), ptr(f32(gamma)), ptr(f32(beta)), ptr(scale),
+                                                ptr(shift), int(Bp), int(P), int(G), float(eps), stream()),
+          "msgm_groupnorm_affine_chanstats")
+    return scale, shift
 
 
 def conv_input_transform_supported(geom: L.ConvGeomT, C0: int, C1: int, CoutP: int) -> bool:

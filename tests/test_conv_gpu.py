@@ -323,3 +323,78 @@ def test_winograd_forward_equals_direct_conv(N, H, Ci, Co, two, ups, aff):
     print(f"Winograd vs direct 3x3 conv N={N} {H}x{H} {C0}+{C1}->{Co} ups={ups} affine={aff}: rel-L2 {e:.2e}")
     assert e <= 2e-6
     assert not torch.equal(got, ref)                       # it really took the other kernel
+
+
+# ------------------------------------------------------------------ channel statistics as a by-product of the epilogue
+@pytest.mark.parametrize("N,Ci,C1,Co,H,W_,k,st,res,acc", [
+    (24, 64, 0, 64, 32, 32, 3, 1, True, False),     # 16x16 tiles, 4 channel tiles per wave; residual in the epilogue
+    (3, 32, 0, 32, 32, 32, 3, 1, False, True),      # small launch: 8x16 tiles; accumulate onto a skip-conv result
+    (20, 64, 32, 32, 64, 64, 3, 1, False, False),   # two sources (decoder), 32 output channels
+    (5, 64, 0, 64, 1, 1024, 1, 1, True, False),     # pixel-stationary 1x1 (attention proj_out + residual), PT = 4
+    (18, 128, 0, 128, 1, 256, 1, 1, True, False),   # 1x1 with 8 input groups, PT = 2
+    (2, 32, 0, 32, 1, 320, 3, 1, False, False),     # 1-D 3-tap, ragged last tile
+    (6, 64, 0, 64, 32, 32, 3, 2, False, False),     # Downsample (stride 2): implicit GEMM from L2, NT = 2
+    (4, 3, 0, 32, 64, 64, 3, 1, False, False),      # the input convolution (3 channels): implicit GEMM, NT = 4
+])
+def test_conv_channel_statistics_byproduct(N, Ci, C1, Co, H, W_, k, st, res, acc):
+    """msgm_conv_fuse_t.chanstats: the per-(sample, slot, channel) sums the conv epilogue leaves behind add up to the
+    sums of the FINAL output (bias, accumulate and residual included), and msgm_groupnorm_affine_chanstats gives the
+    (scale, shift) that msgm_groupnorm_affine computes by reading the tensor (model/unet.py:140-143: every GroupNorm
+    reads a conv output)."""
+    from sdeflow_light_amd import ops
+    torch.manual_seed(N + Ci + Co)
+    kk = (k, k) if H > 1 else (k,)
+    W = torch.randn(Co, Ci + C1, *kk) * 0.1
+    b = torch.randn(Co) * 0.3 + 0.5
+    op = mk(W, b, "conv", kk, st, (k - 1) // 2, [Ci] + ([C1] if C1 else []))
+    srcs = [torch.randn(N * H * W_ * Ci, device=DEV) + 0.3] + ([torch.randn(N * H * W_ * C1, device=DEV)] if C1 else [])
+    geom, Ho, Wo = op._geom(N, H, W_)
+    S = ops.conv_chanstats_slots(geom, Ci, C1, Co, op.CoutP)
+    assert S > 0
+    P = Ho * Wo
+    r = torch.randn(N * P * Co, device=DEV) if res else None
+    out = torch.randn(N * P * Co, device=DEV) if acc else None
+    out, _, _ = op.forward(srcs, N, H, W_, n_bias=N, residual=r, out=out, accumulate=acc, stats=True)
+    cs, S2 = out._msgm_cs
+    assert S2 == S and cs.numel() == N * S * 2 * Co
+    o = out.view(N, P, Co).double()
+    tot = cs.view(N, S, 2, Co).double().sum(1)
+    e1, e2 = rel_l2(tot[:, 0].cpu(), o.sum(1).cpu()), rel_l2(tot[:, 1].cpu(), (o * o).sum(1).cpu())
+    print(f"chanstats N={N} {Ci}+{C1}->{Co} {H}x{W_} k={k} stride {st} S={S}: sum rel-L2 {e1:.2e}, sum of squares {e2:.2e}")
+    assert e1 <= 2e-6 and e2 <= 2e-6
+    G = 32
+    gamma, beta = torch.randn(Co, device=DEV), torch.randn(Co, device=DEV)
+    sc0, sh0 = ops.groupnorm_affine(out, Co, gamma, beta, N, P, G)
+    sc1, sh1 = ops.groupnorm_affine_cs(cs, S, Co, gamma, beta, N, P, G)
+    e3, e4 = rel_l2(sc1.cpu(), sc0.cpu()), rel_l2(sh1.cpu(), sh0.cpu())
+    print(f"   GroupNorm affine from chanstats vs from the tensor: scale {e3:.2e}, shift {e4:.2e}")
+    assert e3 <= 2e-6 and e4 <= 2e-6
+    # a second forward without stats clears the description of the overwritten values
+    out2, _, _ = op.forward(srcs, N, H, W_, n_bias=N, out=out)
+    assert out2._msgm_cs is None
+
+
+def test_groupnorm_affine_chanstats_two_sources():
+    """The decoder's GroupNorm over cat([h, skip]) from the two producers' statistics (different slot counts, a group
+    straddling the two sources: 128 + 64 channels in 32 groups of 6)."""
+    from sdeflow_light_amd import ops
+    torch.manual_seed(4)
+    N, H = 6, 32
+    P = H * H
+    outs = []
+    for Ci, Co, k in ((64, 128, 1), (32, 64, 3)):
+        kk = (k, k) if k == 3 else (1,)
+        op = mk(torch.randn(Co, Ci, *kk) * 0.1, torch.randn(Co), "conv", kk, 1, (k - 1) // 2, [Ci])
+        hw = (H, H) if k == 3 else (1, P)
+        o, _, _ = op.forward([torch.randn(N * P * Ci, device=DEV)], N, hw[0], hw[1], n_bias=N, stats=True)
+        assert o._msgm_cs is not None
+        outs.append((o, Co))
+    (h, C0), (s, C1) = outs
+    assert h._msgm_cs[1] != s._msgm_cs[1]
+    gamma, beta = torch.randn(C0 + C1, device=DEV), torch.randn(C0 + C1, device=DEV)
+    sc0, sh0 = ops.groupnorm_affine(h, C0, gamma, beta, N, P, 32, x1=s, C1=C1)
+    sc1, sh1 = ops.groupnorm_affine_cs(h._msgm_cs[0], h._msgm_cs[1], C0, gamma, beta, N, P, 32, cs1=s._msgm_cs[0],
+                                       S1=s._msgm_cs[1], C1=C1)
+    e3, e4 = rel_l2(sc1.cpu(), sc0.cpu()), rel_l2(sh1.cpu(), sh0.cpu())
+    print(f"two-source GroupNorm affine from chanstats vs from the tensors: scale {e3:.2e}, shift {e4:.2e}")
+    assert e3 <= 2e-6 and e4 <= 2e-6
