@@ -326,6 +326,10 @@ typedef struct {
 } msgm_conv_fuse_t;
 int msgm_conv_input_transform_supported(const msgm_conv_geom_t* geom, int32_t C0, int32_t C1, int32_t CoutP);
 int32_t msgm_conv_chanstats_slots(const msgm_conv_geom_t* geom, int32_t C0, int32_t C1, int32_t Cout, int32_t CoutP);
+/* 1 if this forward convolution is the U-Net's output convolution shape (3x3 "same", 32 input channels, <= 4 output
+ * channels; model/unet.py:442-446) that the vector-ALU kernel serves — it also accepts the in_scale / in_shift input
+ * transform, although msgm_conv_input_transform_supported() (which does not see Cout) says no for CoutP = 16. */
+int msgm_conv_small_cout_supported(const msgm_conv_geom_t* geom, int32_t C0, int32_t C1, int32_t Cout);
 int msgm_conv_forward_fused(const msgm_conv_geom_t* geom, const float* src0, int32_t C0, const float* src1, int32_t C1,
                             const float* Wp, int32_t Cout, int32_t CoutP, int32_t Ktot, const float* bias,
                             const float* samp_bias, int32_t n_bias, int32_t n_samp, float* out, int32_t accumulate,

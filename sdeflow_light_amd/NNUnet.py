@@ -473,6 +473,10 @@ class VorticityUNet(nn.Module, FlatParamMixin):
             if tape is not None:
                 tape.append(("cat", C, Cs, H, W))
             h, C, H, W = run_block(blk, cat, C + Cs, H, W)
+        if not dual and tape is None and x["fin"].can_transform_input(N, H, W) and not os.environ.get("MSGM_NO_GN_FOLD"):
+            # sampler: the output GroupNorm + SiLU (model/unet.py:442-444) applied by the output conv while it stages its input
+            out, _, _ = x["fin"].forward([h], N, H, W, Bp, in_affine=self._gn_fold(core.out[0], h, Bp, H * W, C), in_act=1)
+            return out
         hf, stf = self._gn(core.out[0], h, Bp, H * W, C, dual, True, tape)
         if tape is not None:
             tape.append(("fin", h, stf, hf, H, W, C))

@@ -88,6 +88,7 @@ SIGNATURES = {
     "msgm_conv_input_transform_supported": (C.c_int, [C.POINTER(ConvGeomT), _I32, _I32, _I32]),
     "msgm_groupnorm_affine": (C.c_int, [_P, _I32, _P, _I32, _P, _P, _P, _P, _I32, _I32, _I32, _F, _P, C.c_size_t, _P]),
     "msgm_conv_chanstats_slots": (C.c_int32, [C.POINTER(ConvGeomT), _I32, _I32, _I32, _I32]),
+    "msgm_conv_small_cout_supported": (C.c_int, [C.POINTER(ConvGeomT), _I32, _I32, _I32]),
     "msgm_groupnorm_affine_chanstats": (C.c_int, [_P, _I32, _I32, _P, _I32, _I32, _P, _P, _P, _P, _I32, _I32, _I32, _F, _P]),
     "msgm_conv_wgrad": (C.c_int, [C.POINTER(ConvGeomT), _P, _P, _I32, _I32, _P, _I32, _I32, _I32, _P, _I32,
                                   C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), _P]),

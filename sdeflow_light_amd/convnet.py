@@ -215,7 +215,8 @@ class ConvOp:
     def can_transform_input(self, N: int, Hi: int, Wi: int) -> bool:
         """True when forward() can apply a per-(sample, channel) affine (+SiLU) to its input on the fly."""
         geom, _, _ = self._geom(N, Hi, Wi)
-        return ops.conv_input_transform_supported(geom, self.srcC[0], self.srcC[1] if len(self.srcC) > 1 else 0, self.CoutP)
+        return ops.conv_input_transform_supported(geom, self.srcC[0], self.srcC[1] if len(self.srcC) > 1 else 0, self.CoutP,
+                                                  Cout=self.Cout)
 
     # -------------------------------------------------------------- forward
     def forward(self, srcs: List[torch.Tensor], N: int, Hi: int, Wi: int, n_bias: int, emb: Optional[torch.Tensor] = None,

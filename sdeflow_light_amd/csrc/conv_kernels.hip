@@ -668,6 +668,9 @@ __global__ void __launch_bounds__(256) k_conv1x1(ConvArgs A, int P /* pixels per
 #ifdef C1_EXP_NOSTORE      // diagnostic: what the kernel costs without its output stores
       if (v[0] != 12345.678f) continue;
 #endif
+#ifdef C1_EXP_COALESCED    // diagnostic (WRONG results): the same bytes as fully coalesced 1-KB stores
+      op = A.out + ((size_t)(m0 / 16 + pt) * (A.Cout / 16) + ct) * 256 + lane * 4;
+#endif
       if (full) {
         if (A.accumulate) v += *reinterpret_cast<const f32x4*>(op);
         if (A.residual) v += *reinterpret_cast<const f32x4*>(A.residual + (op - A.out));
@@ -681,6 +684,153 @@ __global__ void __launch_bounds__(256) k_conv1x1(ConvArgs A, int P /* pixels per
     }
     // host: P % (16 PT) == 0 and Cout % 4 == 0 when cstat is set, so the wave's pixels are one slot of one sample
     if (A.cstat) cstat_store(A, (int)(m0 / P), (int)((m0 % P) / (16 * PT)), co, cs, css, il);
+  }
+}
+
+// ------------------------------------------------------------------ the U-Net's first and last 3x3 convolutions (vector ALU)
+// model/unet.py:353-359 (image channels -> model_channels) and :442-446 (model_channels -> image channels): 1 or 3 channels
+// on one side.  On the MFMA kernels those channels are padded to 16 (5x / 10x wasted matrix work) and the implicit GEMM
+// re-reads its input once per tap from L2: 0.91 ms and 0.78 ms per 1024-row sampler step for 7 + 7 GFLOP of useful work
+// (rocprofv3, C5).  Both are 864 multiply-adds per pixel — a job for the vector ALU with the weights in SCALAR registers
+// (uniform addresses: s_load), one thread per output pixel:
+//   k_conv3x3_cin_small : <= 4 input channels read straight from global memory / L1 (27 floats per pixel), CO accumulators;
+//                         optional channel-statistics by-product (full-wave DPP reduction);
+//   k_conv3x3_cout_small: <= 4 output channels; the 32-channel input halo tile is staged in LDS exactly as k_conv_tile does
+//                         (same fused GroupNorm + SiLU input transform), each thread reads its 9 x 32 inputs as ds_read_b128.
+// Forward only (mode 0); same bias / per-sample bias / accumulate / residual contract as the other forward kernels.
+__device__ __forceinline__ float wave64_sum_to_last(float v) {        // lane 63 ends with the sum over the wave
+  v = row16_sum(v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));   // row_bcast:15
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false));   // row_bcast:31
+  return v;
+}
+
+template <int CO>
+__global__ void __launch_bounds__(256) k_conv3x3_cin_small(ConvArgs A, long Mtot) {
+  const ConvGeom g = A.g;
+  const int P = g.Ho * g.Wo, Cin = A.C[0];
+  const long m = (long)blockIdx.x * 256 + threadIdx.x;
+  const bool live = m < Mtot;
+  const long mm = live ? m : Mtot - 1;
+  const int n = (int)(mm / P), r = (int)(mm - (long)n * P), y = r / g.Wo, x = r - y * g.Wo;
+  const float* src = A.src[0] + (size_t)n * g.Hi * g.Wi * Cin;
+  float acc[CO];
+#pragma unroll
+  for (int co = 0; co < CO; ++co) acc[co] = 0.f;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
+    const bool ok = iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi;
+    const float* px = src + ((size_t)(ok ? iy : 0) * g.Wi + (ok ? ix : 0)) * Cin;
+    const float* wt = A.Wp + (size_t)tap * A.CoutP * A.Ktot;           // W[tap][co][c] at wt[co * Ktot + c]: uniform
+    for (int c = 0; c < Cin; ++c) {
+      const float xv = ok ? px[c] : 0.f;
+#pragma unroll
+      for (int co = 0; co < CO; ++co) acc[co] = __builtin_fmaf(xv, wt[(size_t)co * A.Ktot + c], acc[co]);
+    }
+  }
+  const bool primal = n < A.n_bias && A.bias;
+  float* op = A.out + (size_t)mm * CO;
+#pragma unroll
+  for (int c4 = 0; c4 < CO / 4; ++c4) {
+    f32x4 v = {acc[4 * c4], acc[4 * c4 + 1], acc[4 * c4 + 2], acc[4 * c4 + 3]};
+    if (primal) v += *reinterpret_cast<const f32x4*>(A.bias + 4 * c4);
+    if (A.samp_bias && n < A.n_samp) v += *reinterpret_cast<const f32x4*>(A.samp_bias + (size_t)n * CO + 4 * c4);
+    if (live) {
+      if (A.accumulate) v += *reinterpret_cast<const f32x4*>(op + 4 * c4);
+      if (A.residual) v += *reinterpret_cast<const f32x4*>(A.residual + (size_t)mm * CO + 4 * c4);
+      *reinterpret_cast<f32x4*>(op + 4 * c4) = v;
+    } else {
+      v = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[4 * c4 + k] = v[k];
+  }
+  if (A.cstat) {       // host: P % 64 == 0, so a wave's 64 pixels are one slot of one sample
+    const int lane = threadIdx.x & 63;
+    float* cp = A.cstat + (((size_t)n * A.cs_S + (r >> 6)) * 2) * CO;
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+      const float s = wave64_sum_to_last(acc[co]), ss = wave64_sum_to_last(acc[co] * acc[co]);
+      if (lane == 63) { cp[co] = s; cp[CO + co] = ss; }
+    }
+  }
+}
+
+template <int CO>
+__global__ void __launch_bounds__(256) k_conv3x3_cout_small(ConvArgs A, int tiles_x, int tiles_y) {
+  extern __shared__ __attribute__((aligned(16))) float cs_lds[];      // [18 * 18][CT_P]
+  const ConvGeom g = A.g;
+  const int tid = threadIdx.x;
+  constexpr int HW = 18, n_items = HW * HW * 8;
+  int t = blockIdx.x;
+  const int tx_i = t % tiles_x; t /= tiles_x;
+  const int ty_i = t % tiles_y, n = t / tiles_y, y0 = ty_i * 16, x0 = tx_i * 16;
+  const float* base = A.src[0] + (size_t)n * g.Hi * g.Wi * 32;
+  // ---- halo tile of the 32 input channels, GroupNorm(+SiLU) applied while staging (zero padding stays zero)
+  f32x4 ga = {1.f, 1.f, 1.f, 1.f}, gb = {0.f, 0.f, 0.f, 0.f};
+  const int c4 = tid & 7;
+  if (A.in_scale) {
+    ga = *reinterpret_cast<const f32x4*>(A.in_scale + (size_t)n * 32 + 4 * c4);
+    gb = *reinterpret_cast<const f32x4*>(A.in_shift + (size_t)n * 32 + 4 * c4);
+  }
+#pragma unroll
+  for (int k = 0; k < (n_items + 255) / 256; ++k) {
+    const int idx = tid + 256 * k;
+    if (idx < n_items) {
+      const int hp = idx >> 3, hy = hp / HW, hx = hp - hy * HW;
+      const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi) {
+        v = *reinterpret_cast<const f32x4*>(base + ((size_t)iy * g.Wi + ix) * 32 + 4 * c4);
+        if (A.in_scale) {
+          v = v * ga + gb;
+          if (A.in_act == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[r]));
+          }
+        }
+      }
+      *reinterpret_cast<f32x4*>(cs_lds + hp * CT_P + 4 * c4) = v;
+    }
+  }
+  __syncthreads();
+  const int py = tid >> 4, px = tid & 15;
+  float acc[CO];
+#pragma unroll
+  for (int co = 0; co < CO; ++co) acc[co] = 0.f;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const float* xp = cs_lds + ((py + tap / 3) * HW + px + tap % 3) * CT_P;
+    const float* wt = A.Wp + (size_t)tap * A.CoutP * A.Ktot;           // W[tap][co][c] at wt[co * Ktot + c]: uniform
+#pragma unroll
+    for (int q4 = 0; q4 < 8; ++q4) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(xp + 4 * q4);
+#pragma unroll
+      for (int co = 0; co < CO; ++co) {
+        const float* w = wt + (size_t)co * A.Ktot + 4 * q4;
+        acc[co] = __builtin_fmaf(xv[0], w[0], acc[co]); acc[co] = __builtin_fmaf(xv[1], w[1], acc[co]);
+        acc[co] = __builtin_fmaf(xv[2], w[2], acc[co]); acc[co] = __builtin_fmaf(xv[3], w[3], acc[co]);
+      }
+    }
+    // pin the accumulators at the tap boundary: left alone the compiler runs each output channel's 288-FMA chain on its
+    // own, which needs all 72 LDS reads (288 registers) live at once
+#pragma unroll
+    for (int co = 0; co < CO; ++co) asm volatile("" : "+v"(acc[co]));
+  }
+  const int oy = y0 + py, ox = x0 + px;
+  if (oy < g.Ho && ox < g.Wo) {
+    const size_t m = ((size_t)n * g.Ho + oy) * g.Wo + ox;
+    float* op = A.out + m * CO;
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+      float v = acc[co];
+      if (n < A.n_bias && A.bias) v += A.bias[co];
+      if (A.samp_bias && n < A.n_samp) v += A.samp_bias[(size_t)n * CO + co];
+      if (A.accumulate) v += op[co];
+      if (A.residual) v += A.residual[m * CO + co];
+      op[co] = v;
+    }
   }
 }
 
@@ -1452,13 +1602,25 @@ int msgm_conv_forward_wino(const msgm_conv_geom_t* geom, const float* src0, int3
 // Which kernel serves a forward convolution, and with what tiling — ONE decision shared by the launcher and by
 // msgm_conv_chanstats_slots (the channel-statistics by-product is laid out per (tile, wave) of that tiling).
 struct ConvRoute {
-  int kind;                 // 0 implicit GEMM from L2, 1 pixel-stationary 1x1, 2 halo tile
+  int kind;                 // 0 implicit GEMM from L2, 1 pixel-stationary 1x1, 2 halo tile, 3 / 4 vector-ALU first / last conv
   int pt, kg;               // 1x1: 16-pixel tiles per wave, 16-channel input groups
   bool wide, two_d; int nco, TH, TW, tiles_x, tiles_y;      // halo tile
 };
-static ConvRoute conv_route(const msgm_conv_geom_t* geom, int32_t C0, bool has1, int32_t C1, int32_t CoutP, bool masks) {
+// first / last convolution of the U-Net: 3x3 "same", one source, <= 4 channels on one side and 32 on the other
+static bool conv_small_shape(const msgm_conv_geom_t* geom, bool has1, bool masks) {
+  static const bool off = getenv("MSGM_NO_CONV_SMALL") != nullptr;         // diagnostic A/B
+  return !off && geom->mode == 0 && geom->KH == 3 && geom->KW == 3 && geom->strideH == 1 && geom->strideW == 1 &&
+         geom->padH == 1 && geom->padW == 1 && !geom->ups && geom->Hi == geom->Ho && geom->Wi == geom->Wo && geom->Ho > 1 &&
+         !has1 && !masks;
+}
+static ConvRoute conv_route(const msgm_conv_geom_t* geom, int32_t C0, bool has1, int32_t C1, int32_t Cout, int32_t CoutP,
+                            bool masks) {
   ConvRoute r{};
   const int64_t Mtot = (int64_t)geom->N * geom->Ho * geom->Wo;
+  if (conv_small_shape(geom, has1, masks)) {
+    if (C0 <= 4 && Cout == 32 && CoutP == 32) { r.kind = 3; return r; }
+    if (C0 == 32 && Cout <= 4) { r.kind = 4; return r; }
+  }
   const bool fast = (C0 % 16 == 0) && (!has1 || C1 % 16 == 0);
   const int Ktot = ((C0 + 15) / 16) * 16 + (has1 ? ((C1 + 15) / 16) * 16 : 0);
   static const bool no1 = getenv("MSGM_NO_CONV1X1") != nullptr;            // diagnostic A/B
@@ -1499,13 +1661,20 @@ static int conv_route_slots(const ConvRoute& r, const msgm_conv_geom_t* geom, in
   if (Cout % 4) return 0;
   if (r.kind == 1) { const int P = geom->Ho * geom->Wo; return P % (16 * r.pt) == 0 ? P / (16 * r.pt) : 0; }
   if (r.kind == 2) return r.tiles_x * r.tiles_y * 4;
+  if (r.kind == 3) { const int P = geom->Ho * geom->Wo; return P % 64 == 0 ? P / 64 : 0; }
+  if (r.kind == 4) return 0;
   const int P = geom->Ho * geom->Wo, px = 16 * r.pt;      // implicit GEMM: a wave owns 16 NT consecutive pixels
   return P % px == 0 ? P / px : 0;
 }
 
 int32_t msgm_conv_chanstats_slots(const msgm_conv_geom_t* geom, int32_t C0, int32_t C1, int32_t Cout, int32_t CoutP) {
   if (check_geom(geom) || C0 <= 0 || C1 < 0 || Cout <= 0 || CoutP < Cout || CoutP % 16) return 0;
-  return conv_route_slots(conv_route(geom, C0, C1 > 0, C1, CoutP, false), geom, Cout);
+  return conv_route_slots(conv_route(geom, C0, C1 > 0, C1, Cout, CoutP, false), geom, Cout);
+}
+
+int msgm_conv_small_cout_supported(const msgm_conv_geom_t* geom, int32_t C0, int32_t C1, int32_t Cout) {
+  if (check_geom(geom) || C1 != 0) return 0;
+  return conv_route(geom, C0, false, 0, Cout, 16, false).kind == 4 ? 1 : 0;
 }
 
 int msgm_conv_forward(const msgm_conv_geom_t* geom, const float* src0, int32_t C0, const float* src1, int32_t C1,
@@ -1524,10 +1693,16 @@ int msgm_conv_forward_fused(const msgm_conv_geom_t* geom, const float* src0, int
   if (rc) return rc;
   if (fuse && ((fuse->in_scale == nullptr) != (fuse->in_shift == nullptr) || (fuse->in_act != 0 && fuse->in_act != 1)))
     return MSGM_E_BADARG;
-  if (fuse && fuse->in_scale && !conv_tile_eligible(geom, C0, src1, C1, CoutP)) return MSGM_E_UNSUPPORTED;
   if (!src0 || !Wp || !out || C0 <= 0 || Cout <= 0 || (src1 && C1 <= 0)) return MSGM_E_BADARG;
   const int k0 = ((C0 + 15) / 16) * 16, k1 = src1 ? ((C1 + 15) / 16) * 16 : 0;
   if (Ktot != k0 + k1 || CoutP % 16 || CoutP < Cout) return MSGM_E_BADARG;
+  bool masks = false;
+  if (fuse) {
+    for (int i = 0; i < 16; ++i) masks = masks || fuse->tapmask_in[i];
+    for (int i = 0; i < 8; ++i) masks = masks || fuse->tapmask_out[i];
+  }
+  const ConvRoute rt = conv_route(geom, C0, src1 != nullptr, C1, Cout, CoutP, masks);
+  if (fuse && fuse->in_scale && rt.kind != 4 && !conv_tile_eligible(geom, C0, src1, C1, CoutP)) return MSGM_E_UNSUPPORTED;
   ConvArgs A{};
   A.g = to_geom(geom);
   A.src[0] = src0; A.C[0] = C0; A.koff[0] = 0;
@@ -1542,16 +1717,27 @@ int msgm_conv_forward_fused(const msgm_conv_geom_t* geom, const float* src0, int
   }
   const int64_t Mtot = (int64_t)geom->N * geom->Ho * geom->Wo;
   const bool fast = (C0 % 16 == 0) && (!src1 || C1 % 16 == 0);
-  bool masks = false;
-  if (fuse) {
-    for (int i = 0; i < 16; ++i) masks = masks || fuse->tapmask_in[i];
-    for (int i = 0; i < 8; ++i) masks = masks || fuse->tapmask_out[i];
-  }
-  const ConvRoute rt = conv_route(geom, C0, src1 != nullptr, C1, CoutP, masks);
   if (fuse && fuse->chanstats) {
     A.cs_S = masks ? 0 : conv_route_slots(rt, geom, Cout);
     if (A.cs_S == 0) return MSGM_E_UNSUPPORTED;            // ask msgm_conv_chanstats_slots() first
     A.cstat = fuse->chanstats;
+  }
+  // the U-Net's first / last 3x3 convolution: vector ALU, weights in scalar registers
+  if (rt.kind == 3) {
+    hipLaunchKernelGGL((k_conv3x3_cin_small<32>), dim3((unsigned)((Mtot + 255) / 256)), dim3(256), 0, S(stream), A, (long)Mtot);
+    return msgm_check_launch();
+  }
+  if (rt.kind == 4) {
+    const int tiles_x = (geom->Wo + 15) / 16, tiles_y = (geom->Ho + 15) / 16;
+    const dim3 grid((unsigned)(tiles_x * tiles_y * geom->N));
+    const size_t lds = (size_t)18 * 18 * CT_P * sizeof(float);
+    switch (Cout) {
+      case 1: hipLaunchKernelGGL((k_conv3x3_cout_small<1>), grid, dim3(256), lds, S(stream), A, tiles_x, tiles_y); break;
+      case 2: hipLaunchKernelGGL((k_conv3x3_cout_small<2>), grid, dim3(256), lds, S(stream), A, tiles_x, tiles_y); break;
+      case 3: hipLaunchKernelGGL((k_conv3x3_cout_small<3>), grid, dim3(256), lds, S(stream), A, tiles_x, tiles_y); break;
+      default: hipLaunchKernelGGL((k_conv3x3_cout_small<4>), grid, dim3(256), lds, S(stream), A, tiles_x, tiles_y); break;
+    }
+    return msgm_check_launch();
   }
   // 1x1 stride-1 convolution (forward or dgrad): pixel-stationary streaming kernel, no LDS
   if (rt.kind == 1) {

@@ -371,7 +371,9 @@ def groupnorm_affine_cs(cs0, S0, C0, gamma, beta, Bp, P, G, cs1=None, S1=0, C1=0
     return scale, shift
 
 
-def conv_input_transform_supported(geom: L.ConvGeomT, C0: int, C1: int, CoutP: int) -> bool:
+def conv_input_transform_supported(geom: L.ConvGeomT, C0: int, C1: int, CoutP: int, Cout: Optional[int] = None) -> bool:
+    if Cout is not None and lib().msgm_conv_small_cout_supported(geom, int(C0), int(C1), int(Cout)):
+        return True
     return bool(lib().msgm_conv_input_transform_supported(geom, int(C0), int(C1), int(CoutP)))
 
 

@@ -398,3 +398,56 @@ def test_groupnorm_affine_chanstats_two_sources():
     e3, e4 = rel_l2(sc1.cpu(), sc0.cpu()), rel_l2(sh1.cpu(), sh0.cpu())
     print(f"two-source GroupNorm affine from chanstats vs from the tensors: scale {e3:.2e}, shift {e4:.2e}")
     assert e3 <= 2e-6 and e4 <= 2e-6
+
+
+# ------------------------------------------------------------------ the U-Net's input / output convolutions (vector-ALU kernels)
+@pytest.mark.parametrize("N,nb,Cin,H,W_", [(5, 3, 3, 32, 32), (4, 4, 1, 20, 24), (3, 2, 3, 64, 64)])
+def test_unet_input_conv_small_cin(N, nb, Cin, H, W_):
+    """model/unet.py:353-359, conv3x3(image channels -> 32) on k_conv3x3_cin_small vs F.conv2d (bias on the first nb rows
+    only: the tangent rows of the dual batch carry none); with MSGM_NO_CONV_SMALL the MFMA implicit GEMM served it."""
+    torch.manual_seed(N + Cin + H)
+    x = torch.randn(N, Cin, H, W_)
+    w, b = torch.randn(32, Cin, 3, 3) * 0.3, torch.randn(32)
+    ref = F.conv2d(x, w, None, 1, 1)
+    ref[:nb] += b[None, :, None, None]
+    op = mk(w, b, "conv", (3, 3), 1, 1, [Cin])
+    out, _, _ = op.forward([cl2(x).reshape(-1).to(DEV)], N, H, W_, n_bias=nb, stats=True)
+    e = rel_l2(out.view(N, H, W_, 32).cpu(), cl2(ref))
+    print(f"input conv {Cin}->32 {H}x{W_}: rel-L2 {e:.2e}")
+    assert e <= 2e-7
+    if (H * W_) % 64 == 0:                                  # statistics by-product: one slot per 64 pixels
+        cs, S = out._msgm_cs
+        assert S == H * W_ // 64
+        o = out.view(N, H * W_, 32).double()
+        tot = cs.view(N, S, 2, 32).double().sum(1)
+        assert rel_l2(tot[:, 0].cpu(), o.sum(1).cpu()) <= 2e-6 and rel_l2(tot[:, 1].cpu(), (o * o).sum(1).cpu()) <= 2e-6
+    else:
+        assert out._msgm_cs is None
+    r = torch.randn(N * H * W_ * 32, device=DEV)
+    out2, _, _ = op.forward([cl2(x).reshape(-1).to(DEV)], N, H, W_, n_bias=nb, residual=r)
+    assert rel_l2((out2 - r).cpu(), out.cpu()) <= 1e-6
+
+
+@pytest.mark.parametrize("N,nb,Cout,H,W_,aff", [(5, 3, 3, 32, 32, True), (4, 4, 1, 20, 24, True), (3, 3, 3, 64, 64, False)])
+def test_unet_output_conv_small_cout(N, nb, Cout, H, W_, aff):
+    """model/unet.py:442-446, GroupNorm -> SiLU -> conv3x3(32 -> image channels) on k_conv3x3_cout_small (GroupNorm + SiLU
+    applied while the halo tile is staged) vs plain PyTorch fp32."""
+    from sdeflow_light_amd import ops
+    torch.manual_seed(N + Cout + H)
+    x = torch.randn(N, 32, H, W_) * 1.5 + 0.3
+    gam, bet = torch.randn(32) * 0.5 + 1.0, torch.randn(32) * 0.2
+    w, b = torch.randn(Cout, 32, 3, 3) * 0.1, torch.randn(Cout)
+    h = F.silu(F.group_norm(x, 32, gam, bet, 1e-5)) if aff else x
+    ref = F.conv2d(h, w, None, 1, 1)
+    ref[:nb] += b[None, :, None, None]
+    op = mk(w, b, "conv", (3, 3), 1, 1, [32])
+    assert op.can_transform_input(N, H, W_)
+    xs = cl2(x).reshape(-1).to(DEV)
+    ab = ops.groupnorm_affine(xs, 32, gam.to(DEV), bet.to(DEV), N, H * W_, 32) if aff else None
+    out, _, _ = op.forward([xs], N, H, W_, n_bias=nb, in_affine=ab, in_act=1 if aff else 0)
+    e = rel_l2(out.view(N, H, W_, Cout).cpu(), cl2(ref))
+    print(f"output conv 32->{Cout} {H}x{W_} (GroupNorm+SiLU folded: {aff}): rel-L2 {e:.2e}")
+    assert e <= 1e-6
+    out2 = torch.ones(N * H * W_ * Cout, device=DEV)
+    op.forward([xs], N, H, W_, n_bias=nb, in_affine=ab, in_act=1 if aff else 0, out=out2, accumulate=True)
+    assert rel_l2((out2 - 1.0).cpu(), out.cpu()) <= 1e-6
