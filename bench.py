@@ -12,7 +12,7 @@ over the ranks, fp32.
            ranks; blocks repeat until >= 1 s has been timed and the MEDIAN block is reported.
 On the same JSON line:
   sample_steps_per_s  C5: reverse-SDE Euler-Maruyama steps/s for 8192 samples of the same net (rows split over the
-                      ranks, 1024-row chunks, ONE hipGraph-captured step replayed --sample-steps times per chunk);
+                      ranks, chunks of <= 4096 rows, ONE hipGraph-captured step replayed --sample-steps times per chunk);
   roofline            the dominant kernel of the C4 step, timed live with per-launch HIP events on the launch stream
                       (+ the other heavy kernels and the whole-step fraction);
   cpu_baseline        the CPU oracle on this host's cores at a reduced batch (rank 0, N=1 only);
@@ -44,7 +44,8 @@ PEAK_F32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_* = fp32 
 UNET_FWD_FLOP = {"c3": 0.4554e9, "c4": 5.974e9 + 9.4e6, "c5": 5.974e9 + 9.4e6}    # per sample, SURVEY.md App. A
 GLOBAL_BATCH = {"c2": B_C2, "c3": 4096, "c4": 256}
 SAMPLE_ROWS = 8192
-CHUNK = 1024
+CHUNK = 4096        # rows per sampler launch: a rank's share of the 8192 rows if smaller (8 ranks: 1024); measured
+                    # 92.6 / 94.2 / 95.2 algorithmic TFLOP/s per EM step at 1024 / 2048 / 4096 rows (tools/time_unet2d.py)
 
 
 # ----------------------------------------------------------------------------------------------------- launcher
@@ -252,7 +253,7 @@ def leg_train_unet(workload, a, rank, world, dev):
 
 
 def leg_sample_unet(gen, d, a, rank, world, dev):
-    """C5: EM sampling of 8192 rows split over the ranks, ONE captured step replayed per 1024-row chunk."""
+    """C5: EM sampling of 8192 rows split over the ranks, ONE captured step replayed per chunk of <= 4096 rows."""
     import torch
     from sdeflow_light_amd import parallel
     from sdeflow_light_amd.sde_scheme import GraphedStepSampler
