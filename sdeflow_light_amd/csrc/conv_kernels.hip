@@ -582,7 +582,7 @@ __global__ void __launch_bounds__(256, CT_MINWG) k_conv_tile(ConvArgs A, int fli
 // Same fused options as k_conv_tile: second source (concatenated K), per-(sample, channel) input affine (+SiLU), bias,
 // per-sample bias, accumulate, residual.  Also the dgrad of the same convolution (with the Wd image).
 template <int PT, int KG>     // PT pixel tiles of 16 per wave; KG = 16-channel groups of the whole (concatenated) input
-__global__ void __launch_bounds__(256) k_conv1x1(ConvArgs A, int P /* pixels per sample */, long Mtot) {
+__global__ void __launch_bounds__(256) k_conv1x1(ConvArgs A, int P /* pixels per sample */, long Mtot, int ct_per) {
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, il = lane & 15, q = lane >> 4;
   const long m0 = ((long)blockIdx.x * 4 + w) * (16 * PT);
   if (m0 >= Mtot) return;                                  // no barriers in this kernel
@@ -620,12 +620,14 @@ __global__ void __launch_bounds__(256) k_conv1x1(ConvArgs A, int P /* pixels per
     }
   }
   // ---- output-channel tiles: weights streamed one (tile, group) pair ahead
-  const int ntile = (A.Cout + 15) >> 4;
+  // small launches (the 32-row per-GPU shard of C4) spread the output-channel tiles over blockIdx.y as well: a wave that
+  // walked over all of them alone would leave most of the chip idle (1x1 convs at B = 32 ran at 0.3-0.6 of their B = 256 rate)
+  const int ct0 = blockIdx.y * ct_per, ntile = min((A.Cout + 15) >> 4, ct0 + ct_per);
   const float* wrow = A.Wp + (size_t)il * A.Ktot + 4 * q;   // row co = 16*ct + il, k = 16*g + 4*q (sources are 16-padded in K)
   const size_t tile_stride = (size_t)16 * A.Ktot;
-  f32x4 an = *reinterpret_cast<const f32x4*>(wrow);
+  f32x4 an = *reinterpret_cast<const f32x4*>(wrow + (size_t)ct0 * tile_stride);
   const bool vec = (A.Cout & 3) == 0;
-  for (int ct = 0; ct < ntile; ++ct) {
+  for (int ct = ct0; ct < ntile; ++ct) {
     f32x4 acc[PT];
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) acc[pt] = f32x4{0, 0, 0, 0};
@@ -1451,11 +1453,30 @@ __global__ void k_act_dual_bwd(const float* __restrict__ z, float* __restrict__ 
 // out[map(e)] (+)= sum_slot part[slot * stride + e] — the deterministic replacement of float atomics (no run-to-run
 // difference in the weight / bias gradients).  map: wgrad image element e = (tap*CoutP + co)*C + c ->
 // dWp[(tap*CoutP + co)*Ktot + koff + c] when Ktot > 0, identity otherwise.
+// A second, identity-mapped element range [n_elem, n_elem + n_elem2) of the same slots (the bias gradient that the tiled
+// wgrad leaves behind its weight image) is reduced into out2 by the trailing workgroups of the SAME launch.
 __global__ void __launch_bounds__(256) k_slot_reduce(const float* __restrict__ part, int nslots, long stride, long n_elem,
                                                       float* __restrict__ out, int C, int Ktot, int koff, int accumulate,
-                                                      int rowsP, int rows) {
+                                                      int rowsP, int rows, long n_elem2, float* __restrict__ out2) {
   __shared__ float red[8][32];
   const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const long nb1 = (n_elem + 31) / 32;
+  if ((long)blockIdx.x >= nb1) {                       // workgroup-uniform
+    const long e2 = ((long)blockIdx.x - nb1) * 32 + el;
+    const bool ok2 = e2 < n_elem2;
+    float t2 = 0.f;
+    if (ok2)
+      for (int s = sl; s < nslots; s += 8) t2 += part[(size_t)s * stride + n_elem + e2];
+    red[sl][el] = t2;
+    __syncthreads();
+    if (sl == 0 && ok2) {
+      float r = red[0][el];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) r += red[k][el];
+      out2[e2] = accumulate ? out2[e2] + r : r;
+    }
+    return;
+  }
   const long e = (long)blockIdx.x * 32 + el;
   // padding rows (co >= Cout of a [taps][CoutP][C] image) are never written by the producers
   const bool ok = e < n_elem && (rowsP == 0 || (int)((e / C) % rowsP) < rows);
@@ -1742,9 +1763,13 @@ int msgm_conv_forward_fused(const msgm_conv_geom_t* geom, const float* src0, int
   // 1x1 stride-1 convolution (forward or dgrad): pixel-stationary streaming kernel, no LDS
   if (rt.kind == 1) {
     const int P = geom->Ho * geom->Wo;
+    const int ntile = (Cout + 15) / 16;
+    const long wgs = (Mtot + 64 * rt.pt - 1) / (64 * rt.pt);
+    int split = wgs >= 768 ? 1 : (int)((768 + wgs - 1) / wgs);          // aim at >= 3 workgroups per CU
+    if (split > ntile) split = ntile;
+    const int ct_per = (ntile + split - 1) / split, gy = (ntile + ct_per - 1) / ct_per;
 #define C1_LAUNCH(PT_, KG_)                                                                                          \
-  hipLaunchKernelGGL((k_conv1x1<PT_, KG_>), dim3((unsigned)((Mtot + 64 * PT_ - 1) / (64 * PT_))), dim3(256), 0, S(stream), A, P, \
-                     (long)Mtot)
+  hipLaunchKernelGGL((k_conv1x1<PT_, KG_>), dim3((unsigned)wgs, (unsigned)gy), dim3(256), 0, S(stream), A, P, (long)Mtot, ct_per)
     switch (rt.kg) {
       case 2: C1_LAUNCH(4, 2); break;
       case 4: C1_LAUNCH(4, 4); break;
@@ -1900,11 +1925,9 @@ static int wgrad_impl(const msgm_conv_geom_t* geom, const float* gy, const float
   }
   const int taps = geom->KH * geom->KW;
   auto reduce_slabs = [&](int nslots, bool with_bias) {     // deterministic mode: slabs -> dWp (+ dbias), slot order
-    hipLaunchKernelGGL(k_slot_reduce, dim3((unsigned)((img + 31) / 32)), dim3(256), 0, S(stream), (const float*)ws, nslots,
-                       A.slab_stride, img, dWp, C, Ktot, koff, 1, CoutP, Cout);
-    if (with_bias)
-      hipLaunchKernelGGL(k_slot_reduce, dim3((unsigned)((Cout + 31) / 32)), dim3(256), 0, S(stream), (const float*)ws + img, nslots,
-                         A.slab_stride, (long)Cout, dbias, 1, 0, 0, 1, 0, 0);
+    const long nb = (img + 31) / 32 + (with_bias ? (Cout + 31) / 32 : 0);
+    hipLaunchKernelGGL(k_slot_reduce, dim3((unsigned)nb), dim3(256), 0, S(stream), (const float*)ws, nslots, A.slab_stride, img,
+                       dWp, C, Ktot, koff, 1, CoutP, Cout, with_bias ? (long)Cout : 0L, dbias);
   };
   if (pl.tile) {
     const bool two_d = geom->Ho > 1;
@@ -1943,7 +1966,7 @@ static int wgrad_impl(const msgm_conv_geom_t* geom, const float* gy, const float
       float* part = ws + (size_t)nchunks * A.slab_stride;   // [bias_slots][Cout] partials, then slot-ordered sum
       hipLaunchKernelGGL(k_colsum, dim3(1, (unsigned)pl.bias_slots), dim3(256), 0, S(stream), gy, part, (int)Pb, Cout, (int)pl.bias_chunk, 2);
       hipLaunchKernelGGL(k_slot_reduce, dim3((unsigned)((Cout + 31) / 32)), dim3(256), 0, S(stream), (const float*)part,
-                         (int)pl.bias_slots, (long)Cout, (long)Cout, dbias, 1, 0, 0, 1, 0, 0);
+                         (int)pl.bias_slots, (long)Cout, (long)Cout, dbias, 1, 0, 0, 1, 0, 0, 0L, (float*)nullptr);
     } else {
       hipLaunchKernelGGL(k_colsum, dim3(1, (unsigned)pl.bias_slots), dim3(256), 0, S(stream), gy, dbias, (int)Pb, Cout, (int)pl.bias_chunk, 1);
     }
@@ -1963,11 +1986,10 @@ int msgm_pack_weight(const float* W, float* Wp, int32_t rows, int32_t ncols, int
 // table is static (parameter buckets and packed images do not move), so the host uploads it once.
 __global__ void __launch_bounds__(256) k_pack_batched(const msgm_pack_job_t* __restrict__ jobs, int unpack) {
   const msgm_pack_job_t J = jobs[blockIdx.y];
-  const int64_t tot = (int64_t)J.taps * J.rows * J.ncols;
-  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < tot; e += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(e % J.ncols);
-    const int r = (int)((e / J.ncols) % J.rows);
-    const int t = (int)(e / ((int64_t)J.ncols * J.rows));
+  const int tot = J.taps * J.rows * J.ncols, per_tap = J.ncols * J.rows;        // 32-bit divisions: a packed image has far fewer than 2^31 elements
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += gridDim.x * blockDim.x) {
+    const int t = e / per_tap, rc = e - t * per_tap;
+    const int r = rc / J.ncols, c = rc - r * J.ncols;
     float* w = J.W + r * J.sr + (J.col_off + c) * J.sc + t * J.st;
     float* p = J.Wp + ((int64_t)t * J.rowsP + r) * J.Ktot + J.kp_off + c;
     if (!unpack) *p = *w;
@@ -1978,7 +2000,7 @@ __global__ void __launch_bounds__(256) k_pack_batched(const msgm_pack_job_t* __r
 
 int msgm_pack_weights_batched(const msgm_pack_job_t* jobs, int32_t n_jobs, int32_t unpack, msgm_stream_t stream) {
   if (!jobs || n_jobs <= 0) return MSGM_E_BADARG;
-  hipLaunchKernelGGL(k_pack_batched, dim3(8, (unsigned)n_jobs), dim3(256), 0, S(stream), jobs, unpack);
+  hipLaunchKernelGGL(k_pack_batched, dim3(32, (unsigned)n_jobs), dim3(256), 0, S(stream), jobs, unpack);
   return msgm_check_launch();
 }
 
@@ -2047,7 +2069,7 @@ int msgm_colsum_det(const float* x, float* Sout, int32_t N, int32_t P, int32_t C
   hipLaunchKernelGGL(k_colsum, dim3(N, nch), dim3(256), 0, S(stream), x, part, P, C, chunk, 2);
   const long n_elem = (long)N * C;
   hipLaunchKernelGGL(k_slot_reduce, dim3((unsigned)((n_elem + 31) / 32)), dim3(256), 0, S(stream), (const float*)part, nch, n_elem,
-                     n_elem, Sout, 1, 0, 0, 0, 0, 0);
+                     n_elem, Sout, 1, 0, 0, 0, 0, 0, 0L, (float*)nullptr);
   return msgm_check_launch();
 }
 

@@ -351,26 +351,30 @@ __global__ void __launch_bounds__(256) k_gn_bwd_reduce(GnArgs A) {
   if (tid < C) { float t = 0.f; for (int p = 0; p < PL; ++p) t += red[p * C + tid]; A.pslots[(nslots + slot) * C + tid] = t; }
 }
 
-// backward moments of every (sample, group): the chunk slots in chunk order -> accf
-__global__ void __launch_bounds__(256) k_gn_bwd_finalize(GnArgs A) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= A.Bp * A.G) return;
-  double a8[8];
-  gn_sum_slots(A, i / A.G, i % A.G, 5, a8);
-  double* o = A.accf + (size_t)i * 8;
-#pragma unroll
-  for (int m = 0; m < 5; ++m) o[m] = a8[m];
-}
-
 // dgamma[c] += sum over the (sample, chunk) slots, dbeta alike (blockIdx.y = 0 / 1): 32 channels x 32 slot slices per
 // workgroup (1024 threads: the grid is only C/32 x 2 workgroups, so the parallelism has to come from inside), every
 // slice walks its slots in order and the 32 slices are added in order — no atomics, same bits every run.
+// The first nb_fin workgroups of the SAME launch do k_gn_bwd_finalize's job (one launch less per GroupNorm backward: at
+// the 32-row shard of C4 these few-microsecond launches add up to a tenth of the step).
 __global__ void __launch_bounds__(1024) k_gn_param_reduce(const float* __restrict__ pslots, size_t nslots, int C,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, GnArgs A,
+                                                           int nb_fin, int nbc) {
   __shared__ float red[32][32];
+  if ((int)blockIdx.x < nb_fin) {                      // workgroup-uniform
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    if (i < A.Bp * A.G) {
+      double a8[8];
+      gn_sum_slots(A, i / A.G, i % A.G, 5, a8);
+      double* o = A.accf + (size_t)i * 8;
+#pragma unroll
+      for (int m = 0; m < 5; ++m) o[m] = a8[m];
+    }
+    return;
+  }
+  const int bid = blockIdx.x - nb_fin, bx = bid % nbc, by = bid / nbc;
   const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
-  const float* p = pslots + (size_t)blockIdx.y * nslots * C;
+  const int c = bx * 32 + cl;
+  const float* p = pslots + (size_t)by * nslots * C;
   float t = 0.f;
   if (c < C)
     for (size_t s = sl; s < nslots; s += 32) t += p[s * C + c];
@@ -380,7 +384,7 @@ __global__ void __launch_bounds__(1024) k_gn_param_reduce(const float* __restric
     float r = red[0][cl];
 #pragma unroll
     for (int k = 1; k < 32; ++k) r += red[k][cl];
-    float* dst = blockIdx.y == 0 ? dgamma : dbeta;
+    float* dst = by == 0 ? dgamma : dbeta;
     dst[c] += r;
   }
 }
@@ -1064,9 +1068,9 @@ static int gn_backward_impl(const float* x, int32_t C0, const float* x1, int32_t
   A.resid = residual;
   if (C % 4 == 0) hipLaunchKernelGGL(k_gn_bwd_reduce<true>, dim3(Bp, nch), dim3(256), 0, S(stream), A);
   else hipLaunchKernelGGL(k_gn_bwd_reduce<false>, dim3(Bp, nch), dim3(256), 0, S(stream), A);
-  hipLaunchKernelGGL(k_gn_bwd_finalize, dim3((Bp * G + 255) / 256), dim3(256), 0, S(stream), A);
-  hipLaunchKernelGGL(k_gn_param_reduce, dim3((C + 31) / 32, 2), dim3(1024), 0, S(stream), (const float*)A.pslots,
-                     (size_t)Bp * nch, C, dgamma, dbeta);
+  const int nb_fin = (Bp * G + 1023) / 1024, nbc = (C + 31) / 32;
+  hipLaunchKernelGGL(k_gn_param_reduce, dim3(nb_fin + 2 * nbc), dim3(1024), 0, S(stream), (const float*)A.pslots,
+                     (size_t)Bp * nch, C, dgamma, dbeta, A, nb_fin, nbc);
   const int nap = gn_chunks_apply(Bp, P, &A.chunk);
   if (C % 4 == 0) hipLaunchKernelGGL(k_gn_bwd_apply<true>, dim3(nap, Bp), dim3(256), 0, S(stream), A);
   else hipLaunchKernelGGL(k_gn_bwd_apply<false>, dim3(nap, Bp), dim3(256), 0, S(stream), A);
