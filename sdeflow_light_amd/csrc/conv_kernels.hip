@@ -1673,6 +1673,10 @@ static ConvRoute conv_route(const msgm_conv_geom_t* geom, int32_t C0, bool has1,
     r.wide = wide;
     r.TH = r.two_d ? (wide ? 16 : 8) : 1; r.TW = r.two_d ? 16 : (wide ? 256 : 128);
     r.tiles_x = (geom->Wo + r.TW - 1) / r.TW; r.tiles_y = (geom->Ho + r.TH - 1) / r.TH;
+    // still fewer than two workgroups per CU (the 16x16 layers of the 32-row shard: 128 tiles x 2 channel blocks): 32
+    // instead of 64 output channels per workgroup doubles the count; the input tile is then staged twice, from L2
+    static const bool no_split = getenv("MSGM_NO_CONV_COSPLIT") != nullptr;  // diagnostic A/B
+    if (!wide && r.nco == 4 && !no_split && (int64_t)geom->N * r.tiles_x * r.tiles_y * (CoutP / 64) < 512) r.nco = 2;
     return r;
   }
   r.pt = (CoutP >= 64 && CoutP % 64 == 0) ? 2 : 4;         // NT of the k_conv_gemm<MT, NT> instantiation launched below
