@@ -21,7 +21,9 @@ On the same JSON line:
 
 `--gpus N` with N > 1 and no torchrun environment: this process touches no GPU and starts N ranks itself
 (`python -m torch.distributed.run ... bench.py --gpus N ...`), relaying their output; under the driver's own
-torch.distributed.run launch the ranks run directly.  MSGM_DIST_BACKEND=gloo lets several ranks share one GPU.
+torch.distributed.run launch the ranks run directly.  MSGM_DIST_BACKEND=gloo lets several ranks share one GPU;
+MSGM_FORCE_DIST=1 sends a ONE-rank run through the multi-rank code path (process group, graph up to the collective, RCCL
+all-reduce of the gradient bucket): a rehearsal of the N > 1 path with the real backend on a one-GPU box.
 """
 from __future__ import annotations
 
@@ -291,7 +293,7 @@ def leg_mlp(a, rank, world, dev, steps=200, sample_steps=200):
     gen = build_mlp(dev)
     flat, _ = gen.a.flat_parameters()
     parallel.broadcast_(flat, 0)
-    tr = MLPScoreTrainer(gen, B_C2, lr=1e-3, world=world, use_graph=(world == 1), seed=1, row_base=rank * B_C2)
+    tr = MLPScoreTrainer(gen, B_C2, lr=1e-3, world=world, use_graph=not parallel.multi(world), seed=1, row_base=rank * B_C2)
     tr.set_data(gaussian_mixture_2d(B_C2, seed=1234 + rank, device=dev))
     med, blocks = timed_blocks(tr.step, steps, 20, dev)
     per_step = med / steps
@@ -482,7 +484,7 @@ def worker(a):
     if rank == 0:
         print(json.dumps(out), flush=True)
     parallel.barrier()
-    if world > 1:
+    if parallel.multi(world):
         import torch.distributed as dist
         dist.destroy_process_group()
 

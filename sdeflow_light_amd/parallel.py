@@ -27,9 +27,25 @@ def local_device(local: int) -> torch.device:
     return torch.device("cuda", local % max(torch.cuda.device_count(), 1))
 
 
+def forced() -> bool:
+    """MSGM_FORCE_DIST=1: take the multi-rank code path (process group, graph that ends before the collective, RCCL
+    all-reduce of the gradient bucket) even with ONE rank — a rehearsal of the N > 1 path with the real backend on a
+    one-GPU box.  The arithmetic is the one-rank run's (sum over one rank, x 1/1)."""
+    return bool(os.environ.get("MSGM_FORCE_DIST"))
+
+
+def multi(world: int) -> bool:
+    """Does a run of this world size go through the collectives?"""
+    return world > 1 or forced()
+
+
+def _active() -> bool:
+    return dist.is_initialized() and (dist.get_world_size() > 1 or forced())
+
+
 def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
     rank, local, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if multi(world) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -57,19 +73,19 @@ def shard_rows(n_global: int, rank: int, world: int) -> Tuple[int, int]:
 def allreduce_sum_(bucket: torch.Tensor, async_op: bool = False):
     """In-place sum all-reduce of the flat gradient bucket (0.135 / 3.3 / 16 MB:
     latency-bound over xGMI, so ONE collective per step, never per tensor)."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         return dist.all_reduce(bucket, op=dist.ReduceOp.SUM, async_op=async_op)
     return None
 
 
 def broadcast_(bucket: torch.Tensor, src: int = 0):
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.broadcast(bucket, src=src)
 
 
 def gather_rows(local: torch.Tensor, n_global: int) -> torch.Tensor:
     """Concatenate per-rank row shards (sizes from ``shard_rows``) on every rank."""
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not _active():
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
     sizes = [shard_rows(n_global, r, world) for r in range(world)]
@@ -82,7 +98,7 @@ def gather_rows(local: torch.Tensor, n_global: int) -> torch.Tensor:
 
 
 def max_over_ranks(value: float, device) -> float:
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not _active():
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -90,5 +106,5 @@ def max_over_ranks(value: float, device) -> float:
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.barrier()

@@ -92,7 +92,7 @@ class MLPScoreTrainer(_TrainerState):
         self.st = base.struct()
         self.inv_batch = 1.0 / (batch_local * world)        # mean over the GLOBAL batch
         self.graph = None
-        self.use_graph = use_graph and world == 1
+        self.use_graph = use_graph and not parallel.multi(world)
 
     def _body(self):
         """3 launches on one GPU: prep (K1 + probe + step tick) -> fused SSM kernel ->
@@ -107,7 +107,7 @@ class MLPScoreTrainer(_TrainerState):
                                            self.st, self.inv_batch, None, self.ws.data_ptr(), self.ws.numel() * 4,
                                            C.byref(nsl), s), "msgm_mlp_ssm_partial")
         pre = int(self.net.pre is not None)
-        if self.world == 1:
+        if not parallel.multi(self.world):
             ops.check(lib.msgm_mlp_ssm_reduce_adam(self.d, pre, self.ws.data_ptr(), nsl.value, self.inv_batch,
                                                    self.gflat.data_ptr(), self.loss.data_ptr(), self.flat.data_ptr(),
                                                    self.m.data_ptr(), self.v.data_ptr(), self.lr, 0.9, 0.999, 1e-8,
@@ -204,7 +204,7 @@ class UNetScoreTrainer(_TrainerState):
         self.rng.advance(1)
 
     def _collective_update(self):
-        if self.world > 1:
+        if parallel.multi(self.world):
             parallel.allreduce_sum_(self.gbuf)       # ONE collective: flat gradient bucket + the loss scalar
         self._update()
 
@@ -221,10 +221,10 @@ class UNetScoreTrainer(_TrainerState):
         self._collective_update()
         torch.cuda.synchronize(self.dev)
         self.graph = ops.new_graph()
-        mode = "global" if self.world == 1 else "thread_local"      # a collective backend's watchdog thread must not
+        mode = "global" if not parallel.multi(self.world) else "thread_local"      # a collective backend's watchdog thread must not
         with torch.cuda.graph(self.graph, capture_error_mode=mode):  # invalidate the capture
             self._fwd_bwd()
-            if self.world == 1:
+            if not parallel.multi(self.world):
                 self._update()
 
     def step(self):
@@ -236,6 +236,6 @@ class UNetScoreTrainer(_TrainerState):
             self.capture()                           # performs this call's step eagerly
             return self.loss
         self.graph.replay()
-        if self.world > 1:
+        if parallel.multi(self.world):
             self._collective_update()
         return self.loss

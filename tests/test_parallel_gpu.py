@@ -145,3 +145,67 @@ def test_sharded_run_draws_and_computes_what_the_single_gpu_run_does():
         print(f"rank {r}: 2-rank vs 1-rank parameters after 3 steps rel-L2 {e:.2e}; losses {l2} vs {losses}")
         assert e <= 1e-6
         assert all(abs(a - b) <= 1e-5 * max(1.0, abs(b)) for a, b in zip(l2, losses))
+
+
+def _rccl_worker(port, forced, q):
+    """One rank; with MSGM_FORCE_DIST the trainer goes through the multi-rank code path on a REAL RCCL communicator."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    os.environ.pop("MSGM_DIST_BACKEND", None)
+    if forced:
+        os.environ["MSGM_FORCE_DIST"] = "1"
+    import torch.distributed as dist
+    from sdeflow_light_amd import parallel
+    from sdeflow_light_amd.SDEs import SGMsde, PluginReverseSDE
+    from sdeflow_light_amd.train import UNetScoreTrainer
+    from sdeflow_light_amd.NNUnet import VorticityUNet
+    from oracle.det_params import load_det_
+    parallel.init_distributed()
+    assert dist.is_initialized() == bool(forced)
+    if forced:
+        assert dist.get_backend() == "nccl"
+    dev = torch.device("cuda", 0)
+    net = VorticityUNet(base_channels=32, channel_mults=(1, 2), num_res_blocks=1, in_space=16, attention_resolutions=(2,),
+                        flatten_order="F")
+    load_det_(net)
+    net = net.to(dev)
+    T = torch.nn.Parameter(torch.FloatTensor([1.0]), requires_grad=False)
+    gen = PluginReverseSDE(SGMsde(T=T, num_steps_forward=16, device=dev), net, T, deviceReverseSDE=dev).to(dev)
+    tr = UNetScoreTrainer(gen, 8, 256, lr=1e-3, world=1, seed=3)
+    torch.manual_seed(5)
+    tr.set_data(torch.randn(8, 256, device=dev))
+    losses = [float(tr.step()) for _ in range(4)]
+    kinds = ops_kinds(tr)
+    flat, _ = net.flat_parameters()
+    q.put((losses, flat.detach().cpu().numpy().tobytes(), kinds, parallel.multi(1)))
+    if forced:
+        parallel.barrier()
+        dist.destroy_process_group()
+
+
+def ops_kinds(tr):
+    from sdeflow_light_amd import ops
+    return ops.graph_node_kinds(tr.graph)
+
+
+@pytest.mark.timeout(600)
+def test_multi_rank_code_path_on_a_real_rccl_communicator():
+    """RCCL needs one GPU per rank, so the 2-rank tests above run over gloo.  Here ONE rank is sent through the same
+    multi-rank code path (MSGM_FORCE_DIST=1: process group with device_id, hipGraph captured in thread_local mode while
+    the backend's watchdog thread is alive, graph replay -> RCCL all-reduce of the [gradients | loss] bucket -> Adam
+    outside the graph) with backend "nccl" = RCCL, and must reproduce the plain one-rank run (whole step inside the
+    graph) bit for bit: a sum over one rank and x 1/1 change nothing."""
+    ctx = mp.get_context("spawn")
+    res = {}
+    for forced in (False, True):
+        q = ctx.Queue()
+        p = ctx.Process(target=_rccl_worker, args=(_free_port(), forced, q))
+        p.start()
+        res[forced] = q.get(timeout=540)
+        p.join(60)
+        assert p.exitcode == 0
+    (l0, b0, k0, m0), (l1, b1, k1, m1) = res[False], res[True]
+    assert (m0, m1) == (False, True)
+    assert l0 == l1 and b0 == b1
+    # the forced run's graph ends before the collective: it lacks the Adam / Philox-advance nodes of the one-rank graph
+    assert set(k0) == set(k1) == {"kernel"} and k1["kernel"] < k0["kernel"]
+    print(f"one rank through RCCL == plain run bit for bit; graph nodes {k0['kernel']} (whole step) vs {k1['kernel']} (up to the collective)")
