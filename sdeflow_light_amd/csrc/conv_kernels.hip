@@ -1676,7 +1676,8 @@ static ConvRoute conv_route(const msgm_conv_geom_t* geom, int32_t C0, bool has1,
     // still fewer than two workgroups per CU (the 16x16 layers of the 32-row shard: 128 tiles x 2 channel blocks): 32
     // instead of 64 output channels per workgroup doubles the count; the input tile is then staged twice, from L2
     static const bool no_split = getenv("MSGM_NO_CONV_COSPLIT") != nullptr;  // diagnostic A/B
-    if (!wide && r.nco == 4 && !no_split && (int64_t)geom->N * r.tiles_x * r.tiles_y * (CoutP / 64) < 512) r.nco = 2;
+    // (not with tap masks: tapmask_out is indexed by the 64-channel block when CoutP % 64 == 0)
+    if (!wide && r.nco == 4 && !no_split && !masks && (int64_t)geom->N * r.tiles_x * r.tiles_y * (CoutP / 64) < 512) r.nco = 2;
     return r;
   }
   r.pt = (CoutP >= 64 && CoutP % 64 == 0) ? 2 : 4;         // NT of the k_conv_gemm<MT, NT> instantiation launched below
