@@ -581,111 +581,133 @@ __global__ void __launch_bounds__(256, CT_MINWG) k_conv_tile(ConvArgs A, int fli
 // per 16-byte weight load, no LDS, no barrier, every activation byte read once, every output byte written once.
 // Same fused options as k_conv_tile: second source (concatenated K), per-(sample, channel) input affine (+SiLU), bias,
 // per-sample bias, accumulate, residual.  Also the dgrad of the same convolution (with the Wd image).
-template <int PT, int KG>     // PT pixel tiles of 16 per wave; KG = 16-channel groups of the whole (concatenated) input
+// The loop over the output-channel tiles is STRAIGHT-LINE code: on gfx950 loads and stores retire through one in-order
+// counter (vmcnt), so a wait for a load also waits for every store issued before it, and a conditional load (or any
+// control flow around a memory operation) makes the compiler fall back to "wait for everything".  The first version of
+// this kernel had both — per-tile conditional bias / weight loads — and its MFMA time and its store time simply added up
+// (64 -> 192 channels at 1024 x 1024 pixels: 0.27 ms without the stores, 0.46 ms with them).  Here every per-tile load
+// (weight ring, bias + per-sample bias, residual) is unconditional (clamped index or a 0/1 factor), is issued a tile
+// ahead, BEFORE the previous tile's stores, and nothing in the loop waits on a store.
+// What is left (diagnostic builds -DC1_EXP_NOMFMA / -DC1_EXP_COALESCED / -DC1_EXP_NOSTORE, 64 -> 192 channels): the memory
+// streams alone take 0.35 ms with these 64-byte-per-pixel store segments (0.27 ms if every store wrote 1 KB contiguous), the
+// MFMAs alone 0.27 ms, both together 0.43 ms — three waves per SIMD do not overlap the two completely.
+// Host-side contract (conv_route): Cout % 16 == 0, P % (16 PT) == 0 (a wave's pixels belong to one sample), C0 % 16 == 0
+// (and C1), at most one of accumulate / residual (EXTRA = 1: one more addend read per output element).
+template <int PT, int KG, int EXTRA>     // PT pixel tiles of 16 per wave; KG = 16-channel groups of the (concatenated) input
 __global__ void __launch_bounds__(256) k_conv1x1(ConvArgs A, int P /* pixels per sample */, long Mtot, int ct_per) {
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, il = lane & 15, q = lane >> 4;
   const long m0 = ((long)blockIdx.x * 4 + w) * (16 * PT);
   if (m0 >= Mtot) return;                                  // no barriers in this kernel
-  const int g0 = (A.C[0] + 15) >> 4;                       // groups of the first source
+  const int n = __builtin_amdgcn_readfirstlane((int)(m0 / P));      // wave-uniform
+  const int g0 = A.C[0] >> 4;                              // groups of the first source
   const int ctot = A.C[0] + (A.nsrc > 1 ? A.C[1] : 0);
   // ---- activations of this wave's pixels: B fragments, resident
   f32x4 b[PT][KG];
-  long pm[PT];
-  bool pin[PT];
 #pragma unroll
   for (int pt = 0; pt < PT; ++pt) {
-    long m = m0 + 16 * pt + il;
-    pin[pt] = m < Mtot;
-    if (!pin[pt]) m = Mtot - 1;
-    pm[pt] = m;
-    const int n = (int)(m / P);
+    const long m = m0 + 16 * pt + il;
 #pragma unroll
     for (int g = 0; g < KG; ++g) {
       const bool second = g >= g0;
       const int c = (second ? 16 * (g - g0) : 16 * g) + 4 * q;           // channel inside its source
       const int C = second ? A.C[1] : A.C[0];
-      f32x4 v = {0, 0, 0, 0};
-      if (c < C) {
-        v = *reinterpret_cast<const f32x4*>((second ? A.src[1] : A.src[0]) + (size_t)m * C + c);
-        if (A.in_scale) {
-          const size_t o = (size_t)n * ctot + (second ? A.C[0] : 0) + c;
-          v = v * *reinterpret_cast<const f32x4*>(A.in_scale + o) + *reinterpret_cast<const f32x4*>(A.in_shift + o);
-          if (A.in_act == 1) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[r]));
-          }
-        }
-      }
-      b[pt][g] = v;
+      b[pt][g] = *reinterpret_cast<const f32x4*>((second ? A.src[1] : A.src[0]) + (size_t)m * C + c);
     }
   }
-  // ---- output-channel tiles: weights streamed one (tile, group) pair ahead
-  // small launches (the 32-row per-GPU shard of C4) spread the output-channel tiles over blockIdx.y as well: a wave that
-  // walked over all of them alone would leave most of the chip idle (1x1 convs at B = 32 ran at 0.3-0.6 of their B = 256 rate)
-  const int ct0 = blockIdx.y * ct_per, ntile = min((A.Cout + 15) >> 4, ct0 + ct_per);
+  if (A.in_scale) {             // folded GroupNorm(+SiLU): per-(sample, channel) affine — after ALL the loads are in flight
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+      const bool second = g >= g0;
+      const size_t o = (size_t)n * ctot + (second ? A.C[0] + 16 * (g - g0) : 16 * g) + 4 * q;
+      const f32x4 ga = *reinterpret_cast<const f32x4*>(A.in_scale + o), gb = *reinterpret_cast<const f32x4*>(A.in_shift + o);
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) {
+        f32x4 v = b[pt][g] * ga + gb;
+        if (A.in_act == 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[r]));
+        }
+        b[pt][g] = v;
+      }
+    }
+  }
+  // ---- output-channel tiles.  Small launches (the 32-row per-GPU shard of C4) spread the tiles over blockIdx.y as well: a
+  // wave that walked over all of them alone would leave most of the chip idle
+  const int ct0 = blockIdx.y * ct_per, ntile = min(A.Cout >> 4, ct0 + ct_per);
   const float* wrow = A.Wp + (size_t)il * A.Ktot + 4 * q;   // row co = 16*ct + il, k = 16*g + 4*q (sources are 16-padded in K)
   const size_t tile_stride = (size_t)16 * A.Ktot;
-  f32x4 an = *reinterpret_cast<const f32x4*>(wrow + (size_t)ct0 * tile_stride);
-  const bool vec = (A.Cout & 3) == 0;
+  constexpr int D = (KG % 4 == 0) ? 4 : 2;                  // weight ring: D (tile, group) pairs ahead; D divides KG
+  static_assert(KG % D == 0 && D <= KG, "ring slots must line up from one tile to the next");
+  f32x4 an[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) an[d] = *reinterpret_cast<const f32x4*>(wrow + (size_t)ct0 * tile_stride + 16 * d);
+  // bias (primal rows) + per-sample bias of this lane's 4 channels, one tile ahead; absent terms read a valid dummy address
+  // (the weight image) and are multiplied by 0
+  const bool has_b = A.bias && n < A.n_bias, has_s = A.samp_bias && n < A.n_samp;
+  const float fb = has_b ? 1.f : 0.f, fs = has_s ? 1.f : 0.f;
+  const float* bp = has_b ? A.bias + 4 * q : A.Wp;
+  const float* sp = has_s ? A.samp_bias + (size_t)n * A.Cout + 4 * q : A.Wp;
+  const int bstep = has_b ? 16 : 0, sstep = has_s ? 16 : 0;
+  f32x4 add_n = *reinterpret_cast<const f32x4*>(bp + (size_t)ct0 * bstep) * fb + *reinterpret_cast<const f32x4*>(sp + (size_t)ct0 * sstep) * fs;
+  const float* ex = EXTRA ? (A.residual ? A.residual : A.out) : nullptr;
+  const size_t orow = (size_t)(m0 + il) * A.Cout + 4 * q;   // element offset of (pixel il of tile 0, channel 4q) in out
+  const size_t ptstep = (size_t)16 * A.Cout;
+  f32x4 ex_n[EXTRA ? PT : 1];
+  if (EXTRA) {
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) ex_n[pt] = *reinterpret_cast<const f32x4*>(ex + orow + pt * ptstep + 16 * ct0);
+  }
   for (int ct = ct0; ct < ntile; ++ct) {
+    const int ctn = min(ct + 1, ntile - 1);                 // the last tile re-requests itself: no branch around a load
     f32x4 acc[PT];
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) acc[pt] = f32x4{0, 0, 0, 0};
+    const f32x4 add = add_n;
+    f32x4 exv[EXTRA ? PT : 1];
+    if (EXTRA) {
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) exv[pt] = ex_n[pt];
+    }
 #pragma unroll
     for (int g = 0; g < KG; ++g) {
-      const f32x4 a = an;
-      // next pair: (ct, g+1) or (ct+1, 0); the K offset of group g is 16*g (koff[1] = 16*g0 for the second source)
-      const int ng = (g + 1 < KG) ? g + 1 : 0, nct = (g + 1 < KG) ? ct : ct + 1;
-      if (nct < ntile) an = *reinterpret_cast<const f32x4*>(wrow + (size_t)nct * tile_stride + 16 * ng);
+      const f32x4 a = an[g % D];
+      // pair D ahead: (ct, g + D) or (ct + 1, g + D - KG); the K offset of group g is 16*g (koff[1] = 16*g0, second source)
+      const int ng = (g + D < KG) ? g + D : g + D - KG, nct = (g + D < KG) ? ct : ctn;
+      an[g % D] = *reinterpret_cast<const f32x4*>(wrow + (size_t)nct * tile_stride + 16 * ng);
+      if (g == 0) {                                          // next tile's addends, requested before this tile's stores
+        add_n = *reinterpret_cast<const f32x4*>(bp + (size_t)ctn * bstep) * fb + *reinterpret_cast<const f32x4*>(sp + (size_t)ctn * sstep) * fs;
+        if (EXTRA) {
+#pragma unroll
+          for (int pt = 0; pt < PT; ++pt) ex_n[pt] = *reinterpret_cast<const f32x4*>(ex + orow + pt * ptstep + 16 * ctn);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);     // keep the requests HERE, D pairs ahead of their use (the scheduler sinks them)
+#ifdef C1_EXP_NOMFMA       // diagnostic (WRONG results): the kernel's memory streams without its matrix work
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt) acc[pt] += a * b[pt][g];
+#else
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) acc[pt] = mfma16c(a[r], b[pt][g][r], acc[pt]);
+#endif
     }
     // ---- epilogue of this tile: lane (pixel il of tile pt, channels 16ct + 4q .. +3)
-    const int co = 16 * ct + 4 * q;
-    if (co >= A.Cout) continue;
-    const bool full = vec && (co + 3 < A.Cout);
     f32x4 cs = {0.f, 0.f, 0.f, 0.f}, css = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
-      if (!pin[pt]) continue;
-      const int n = (int)(pm[pt] / P);
-      f32x4 add = {0.f, 0.f, 0.f, 0.f};
-      if (n < A.n_bias && A.bias) {
-        if (full) add = *reinterpret_cast<const f32x4*>(A.bias + co);
-        else
-#pragma unroll
-          for (int r = 0; r < 4; ++r) if (co + r < A.Cout) add[r] = A.bias[co + r];
-      }
-      if (A.samp_bias && n < A.n_samp) {
-        const float* sbp = A.samp_bias + (size_t)n * A.Cout + co;
-        if (full) add += *reinterpret_cast<const f32x4*>(sbp);
-        else
-#pragma unroll
-          for (int r = 0; r < 4; ++r) if (co + r < A.Cout) add[r] += sbp[r];
-      }
       f32x4 v = acc[pt] + add;
-      float* op = A.out + (size_t)pm[pt] * A.Cout + co;
-#ifdef C1_EXP_NOSTORE      // diagnostic: what the kernel costs without its output stores
-      if (v[0] != 12345.678f) continue;
+      if (EXTRA) v += exv[pt];
+#if defined(C1_EXP_NOSTORE)    // diagnostic: what the kernel costs without its output stores
+      if (v[0] == 12345.678f) *reinterpret_cast<f32x4*>(A.out + orow + pt * ptstep + 16 * ct) = v;
+#elif defined(C1_EXP_COALESCED)    // diagnostic (WRONG results): the same bytes as fully coalesced 1-KB stores
+      *reinterpret_cast<f32x4*>(A.out + ((size_t)(m0 / 16 + pt) * (A.Cout / 16) + ct) * 256 + lane * 4) = v;
+#else
+      *reinterpret_cast<f32x4*>(A.out + orow + pt * ptstep + 16 * ct) = v;
 #endif
-#ifdef C1_EXP_COALESCED    // diagnostic (WRONG results): the same bytes as fully coalesced 1-KB stores
-      op = A.out + ((size_t)(m0 / 16 + pt) * (A.Cout / 16) + ct) * 256 + lane * 4;
-#endif
-      if (full) {
-        if (A.accumulate) v += *reinterpret_cast<const f32x4*>(op);
-        if (A.residual) v += *reinterpret_cast<const f32x4*>(A.residual + (op - A.out));
-        *reinterpret_cast<f32x4*>(op) = v;
-        cs += v; css += v * v;
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (co + r < A.Cout) op[r] = (A.accumulate ? op[r] + v[r] : v[r]) + (A.residual ? A.residual[(op - A.out) + r] : 0.f);
-      }
+      cs += v; css += v * v;
     }
-    // host: P % (16 PT) == 0 and Cout % 4 == 0 when cstat is set, so the wave's pixels are one slot of one sample
-    if (A.cstat) cstat_store(A, (int)(m0 / P), (int)((m0 % P) / (16 * PT)), co, cs, css, il);
+    if (A.cstat) cstat_store(A, n, (int)((m0 % P) / (16 * PT)), 16 * ct + 4 * q, cs, css, il);
   }
 }
 
@@ -1635,7 +1657,7 @@ static bool conv_small_shape(const msgm_conv_geom_t* geom, bool has1, bool masks
          !has1 && !masks;
 }
 static ConvRoute conv_route(const msgm_conv_geom_t* geom, int32_t C0, bool has1, int32_t C1, int32_t Cout, int32_t CoutP,
-                            bool masks) {
+                            bool masks, bool both_extra = false /* accumulate AND residual */) {
   ConvRoute r{};
   const int64_t Mtot = (int64_t)geom->N * geom->Ho * geom->Wo;
   if (conv_small_shape(geom, has1, masks)) {
@@ -1648,10 +1670,11 @@ static ConvRoute conv_route(const msgm_conv_geom_t* geom, int32_t C0, bool has1,
   const int kg = Ktot / 16;
   if (!no1 && geom->KH == 1 && geom->KW == 1 && geom->strideH == 1 && geom->strideW == 1 && geom->padH == 0 && geom->padW == 0 &&
       !geom->ups && geom->Hi == geom->Ho && geom->Wi == geom->Wo && fast && !masks && Mtot >= 4096 &&
-      (kg == 2 || kg == 4 || kg == 6 || kg == 8 || kg == 12 || kg == 16)) {
-    r.kind = 1; r.kg = kg;
-    r.pt = kg <= 4 ? 4 : (kg <= 8 ? 2 : 1);                // resident activations: PT * KG float4 per lane (<= 64 registers)
-    return r;
+      (kg == 2 || kg == 4 || kg == 6 || kg == 8 || kg == 12 || kg == 16) && Cout % 16 == 0 && !both_extra) {
+    // resident activations: PT * KG float4 per lane (<= 64 registers).  Fewer pixels per wave (more waves per SIMD) measured
+    // equal at 64 input channels and 1.4x slower at 128 (tools/bench_1x1.py)
+    const int pt = kg <= 4 ? 4 : (kg <= 8 ? 2 : 1);
+    if ((geom->Ho * geom->Wo) % (16 * pt) == 0) { r.kind = 1; r.kg = kg; r.pt = pt; return r; }
   }
   static const float dummy = 0.f;
   if (conv_tile_eligible(geom, C0, has1 ? &dummy : nullptr, C1, CoutP)) {
@@ -1727,7 +1750,8 @@ int msgm_conv_forward_fused(const msgm_conv_geom_t* geom, const float* src0, int
     for (int i = 0; i < 16; ++i) masks = masks || fuse->tapmask_in[i];
     for (int i = 0; i < 8; ++i) masks = masks || fuse->tapmask_out[i];
   }
-  const ConvRoute rt = conv_route(geom, C0, src1 != nullptr, C1, Cout, CoutP, masks);
+  const bool both_extra = accumulate && fuse && fuse->residual;
+  const ConvRoute rt = conv_route(geom, C0, src1 != nullptr, C1, Cout, CoutP, masks, both_extra);
   if (fuse && fuse->in_scale && rt.kind != 4 && !conv_tile_eligible(geom, C0, src1, C1, CoutP)) return MSGM_E_UNSUPPORTED;
   ConvArgs A{};
   A.g = to_geom(geom);
@@ -1745,7 +1769,8 @@ int msgm_conv_forward_fused(const msgm_conv_geom_t* geom, const float* src0, int
   const bool fast = (C0 % 16 == 0) && (!src1 || C1 % 16 == 0);
   if (fuse && fuse->chanstats) {
     A.cs_S = masks ? 0 : conv_route_slots(rt, geom, Cout);
-    if (A.cs_S == 0) return MSGM_E_UNSUPPORTED;            // ask msgm_conv_chanstats_slots() first
+    // the caller sized the buffer from msgm_conv_chanstats_slots(), which sees neither masks nor accumulate + residual
+    if (A.cs_S == 0 || A.cs_S != msgm_conv_chanstats_slots(geom, C0, src1 ? C1 : 0, Cout, CoutP)) return MSGM_E_UNSUPPORTED;
     A.cstat = fuse->chanstats;
   }
   // the U-Net's first / last 3x3 convolution: vector ALU, weights in scalar registers
@@ -1773,8 +1798,12 @@ int msgm_conv_forward_fused(const msgm_conv_geom_t* geom, const float* src0, int
     int split = wgs >= 768 ? 1 : (int)((768 + wgs - 1) / wgs);          // aim at >= 3 workgroups per CU
     if (split > ntile) split = ntile;
     const int ct_per = (ntile + split - 1) / split, gy = (ntile + ct_per - 1) / ct_per;
+    const bool extra = accumulate || (fuse && fuse->residual);
 #define C1_LAUNCH(PT_, KG_)                                                                                          \
-  hipLaunchKernelGGL((k_conv1x1<PT_, KG_>), dim3((unsigned)wgs, (unsigned)gy), dim3(256), 0, S(stream), A, P, (long)Mtot, ct_per)
+  do {                                                                                                               \
+    if (extra) hipLaunchKernelGGL((k_conv1x1<PT_, KG_, 1>), dim3((unsigned)wgs, (unsigned)gy), dim3(256), 0, S(stream), A, P, (long)Mtot, ct_per); \
+    else hipLaunchKernelGGL((k_conv1x1<PT_, KG_, 0>), dim3((unsigned)wgs, (unsigned)gy), dim3(256), 0, S(stream), A, P, (long)Mtot, ct_per); \
+  } while (0)
     switch (rt.kg) {
       case 2: C1_LAUNCH(4, 2); break;
       case 4: C1_LAUNCH(4, 4); break;
