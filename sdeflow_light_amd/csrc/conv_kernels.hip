@@ -295,7 +295,10 @@ template <int TH, int TW, int NCO, int KS, int PT = 2, bool DB = true>
 #ifndef CT_MINWG
 #define CT_MINWG 1
 #endif
-__global__ void __launch_bounds__(256, CT_MINWG) k_conv_tile(ConvArgs A, int flip, int tiles_x, int tiles_y, int tiles_per_wg, int n_tiles,
+#ifndef CT_WIDE_MINWG
+#define CT_WIDE_MINWG 1
+#endif
+__global__ void __launch_bounds__(256, (PT == 4 && !DB && NCO == 4) ? CT_WIDE_MINWG : CT_MINWG) k_conv_tile(ConvArgs A, int flip, int tiles_x, int tiles_y, int tiles_per_wg, int n_tiles,
                                                              int n_cob, int n_tgrp) {
   extern __shared__ __attribute__((aligned(16))) float ct_lds[];
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, il = lane & 15, q = lane >> 4;
@@ -323,12 +326,12 @@ __global__ void __launch_bounds__(256, CT_MINWG) k_conv_tile(ConvArgs A, int fli
   if (t_beg >= t_end) return;
   static_assert(TH * TW == 64 * PT, "tile = 4 waves x PT MFMA column tiles");
   // this lane's PT output pixels inside a tile
-  int pty[PT], ptx[PT];
-#pragma unroll
-  for (int pt = 0; pt < PT; ++pt) {
-    const int p = 16 * PT * w + 16 * pt + il;
-    pty[pt] = p / TW; ptx[pt] = p - pty[pt] * TW;
-  }
+  // pixel pt of this lane: p = 16 PT w + 16 pt + il.  For 16-wide tiles that is row PT w + pt (wave-uniform), column il;
+  // for 1-row tiles row 0, column p.  Derived where used (no per-pt registers kept across the kernel).
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  auto pty_of = [&](int pt) __attribute__((always_inline)) { return TH == 1 ? 0 : PT * wu + pt; };
+  auto ptx_of = [&](int pt) __attribute__((always_inline)) { return TH == 1 ? 16 * PT * wu + 16 * pt + il : il; };
+  static_assert(TH == 1 || TW == 16, "2-D tiles are 16 pixels wide");
   f32x4 acc[NCO][PT];
 
   // chunk list: (source, channel offset), flattened
@@ -339,7 +342,8 @@ __global__ void __launch_bounds__(256, CT_MINWG) k_conv_tile(ConvArgs A, int fli
 
   // ---- staging: halo pixel hp, 16-B column c4 (8 per pixel)
   constexpr int MAXST = (halo * (CT_KC / 4) + 255) / 256;
-  f32x4 st[MAXST];
+  constexpr int HALF = MAXST;          // (staging in two halves measured no register gain: the epilogue is the peak)
+  f32x4 st[HALF];
   constexpr int n_items = halo * (CT_KC / 4);
   const int padH = g.padH, padW = g.padW;
   const int up = g.ups ? 1 : 0;          // Upsample folded into the gather (model/unet.py:60-73)
@@ -349,7 +353,7 @@ __global__ void __launch_bounds__(256, CT_MINWG) k_conv_tile(ConvArgs A, int fli
     const int ty_i = t % tiles_y;
     n = t / tiles_y; y0 = ty_i * TH; x0 = tx_i * TW;
   };
-  auto stage_load = [&](f32x4* dst, int t, int s, int c0) {
+  auto stage_load = [&](f32x4* dst, int t, int s, int c0, int K0, int K1) __attribute__((always_inline)) {
     int n, y0, x0;
     tile_origin(t, n, y0, x0);
     const int C = A.C[s];
@@ -369,7 +373,7 @@ __global__ void __launch_bounds__(256, CT_MINWG) k_conv_tile(ConvArgs A, int fli
     int tv = tid;
     asm volatile("" : "+v"(tv));
 #pragma unroll
-    for (int k = 0; k < MAXST; ++k) {
+    for (int k = K0; k < K1; ++k) {
       const int idx = tid + 256 * k;
       f32x4 v = {0, 0, 0, 0};
       if (idx < n_items) {
@@ -393,7 +397,7 @@ __global__ void __launch_bounds__(256, CT_MINWG) k_conv_tile(ConvArgs A, int fli
           }
         }
       }
-      dst[k] = v;
+      dst[k - K0] = v;
     }
   };
   // item after (t_, s_, c_); returns whether (t_, s_, c_) is the last chunk of its tile
@@ -404,12 +408,17 @@ __global__ void __launch_bounds__(256, CT_MINWG) k_conv_tile(ConvArgs A, int fli
     if (last) { nt = t_ + 1; ns_ = 0; nc_ = 0; }
     return last;
   };
-  auto stage_store = [&](float* buf) {
+  auto stage_store = [&](float* buf, int K0, int K1) __attribute__((always_inline)) {
+    int tv = tid;
+    asm volatile("" : "+v"(tv));                            // LDS addresses re-derived per item, not kept in registers
 #pragma unroll
-    for (int k = 0; k < MAXST; ++k) {
-      const int idx = tid + 256 * k;
-      if (idx < n_items) *reinterpret_cast<f32x4*>(buf + (idx >> 3) * CT_P + 4 * (idx & 7)) = st[k];
+    for (int k = K0; k < K1; ++k) {
+      const int idx = tv + 256 * k;
+      if (idx < n_items) *reinterpret_cast<f32x4*>(buf + (idx >> 3) * CT_P + 4 * (idx & 7)) = st[k - K0];
     }
+  };
+  auto stage_all = [&](float* buf, int t, int s, int c0) __attribute__((always_inline)) {     // global -> registers -> LDS
+    stage_load(st, t, s, c0, 0, MAXST); stage_store(buf, 0, MAXST);
   };
 
   const size_t a_co_stride = (size_t)16 * A.Ktot;
@@ -432,15 +441,14 @@ __global__ void __launch_bounds__(256, CT_MINWG) k_conv_tile(ConvArgs A, int fli
     if (tm0) fetch_w(wptr(0, 0) + (size_t)(__ffs(tm0) - 1) * A.CoutP * A.Ktot);
   }
   int tile = t_beg, cs = 0, cc = 0;      // current item: tile, source cs, chunk index cc within it
-  stage_load(st, tile, 0, 0);
-  stage_store(cur);
+  stage_all(cur, tile, 0, 0);
   __syncthreads();
   for (;;) {
     // next item
     int ntile, ns, nc;
     const bool last_chunk = advance(tile, cs, cc, ntile, ns, nc);
     const bool more = ntile < t_end;
-    if (DB && more) stage_load(st, ntile, ns, nc * CT_KC);
+    if (DB && more) stage_load(st, ntile, ns, nc * CT_KC, 0, MAXST);
     if (cs == 0 && cc == 0) {
 #pragma unroll
       for (int c = 0; c < NCO; ++c)
@@ -486,7 +494,7 @@ __global__ void __launch_bounds__(256, CT_MINWG) k_conv_tile(ConvArgs A, int fli
 #ifndef CT_EXP_NOLDS    // diagnostic: -DCT_EXP_NOLDS feeds the MFMAs from registers (no activation reads)
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt)
-        b[pt] = *reinterpret_cast<const f32x4*>(cur + ((pty[pt] + oy) * HW + ptx[pt] + ox) * CT_P + 16 * grp + 4 * q);
+        b[pt] = *reinterpret_cast<const f32x4*>(cur + ((pty_of(pt) + oy) * HW + ptx_of(pt) + ox) * CT_P + 16 * grp + 4 * q);
 #else
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt) b[pt] = a[pt % NCO];
@@ -535,8 +543,8 @@ __global__ void __launch_bounds__(256, CT_MINWG) k_conv_tile(ConvArgs A, int fli
         f32x4 cs = {0.f, 0.f, 0.f, 0.f}, css = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
-          if (!((y0 + pty[pt] < g.Ho) && (x0 + ptx[pt] < g.Wo))) continue;
-          const size_t m = ((size_t)n * g.Ho + y0 + pty[pt]) * g.Wo + x0 + ptx[pt];
+          if (!((y0 + pty_of(pt) < g.Ho) && (x0 + ptx_of(pt) < g.Wo))) continue;
+          const size_t m = ((size_t)n * g.Ho + y0 + pty_of(pt)) * g.Wo + x0 + ptx_of(pt);
           f32x4 v = acc[c][pt] + add;
           float* op = A.out + m * A.Cout + co;
           if (full) {
@@ -556,13 +564,12 @@ __global__ void __launch_bounds__(256, CT_MINWG) k_conv_tile(ConvArgs A, int fli
     if (!more) break;
     if (!DB) {             // one LDS buffer: the next item is fetched after this one's MFMAs (other workgroups cover it)
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      stage_load(st, ntile, ns, nc * CT_KC);
-      stage_store(cur);
+      stage_all(cur, ntile, ns, nc * CT_KC);
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       tile = ntile; cs = ns; cc = nc;
       continue;
     }
-    stage_store(nxt);
+    stage_store(nxt, 0, MAXST);
     // LDS hand-off only: __syncthreads() would also drain vmcnt, i.e. wait for this tile's output stores to land
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     float* t = cur; cur = nxt; nxt = t;
