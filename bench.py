@@ -362,13 +362,15 @@ def kernel_probes(dev, Bp):
                 (f"k_attn_dual_fwd<{C // 16}> T={T} C={C}, batch {Bp} (msgm_attention_dual_forward)", 6 * prod,
                  lambda: ops.attention_dual_forward(qkv, Bp, T, C, s2), (qkv,))]
 
-    # order = share of the C4 step in the committed rocprofv3 kernel stats (profiles/r02/c4_b256_kernel_stats_v3.csv):
-    # the single largest kernel is the fused attention backward (19 %), then the 3x3 halo-tile conv (17 %), the tiled
-    # wgrad (12 %) and the attention forward (8 %)
+    # shares of the C4 step in the committed rocprofv3 kernel stats (profiles/r02/c4_b256_train_kernel_stats_v6.csv, training
+    # steps only): the fused attention backward CALL (main kernel 15.9 % + slab reduce 2.0 % + delta 0.2 %) and the 3x3
+    # halo-tile conv in its 64-channel form (19.3 % over all its shapes, forward and dgrad; + 7.8 % in the 32-channel form)
+    # are the two largest, then the tiled 3x3 wgrad (13.7 %) and the attention forward (6.6 %).  The attention backward is
+    # reported as THE roofline entry: it is one shape, so its live timing can be checked against the rocprofv3 average.
     probes += attn(1024, 64)
     probes.append(conv(32, 64, 64))
     probes.append(wgrad(32, 64, 64))
-    share = {"k_attn_dual_bwd": 0.190, "k_attn_dual_fwd": 0.079, "k_conv_tile": 0.172, "k_wgrad_tile": 0.122}
+    share = {"k_attn_dual_bwd": 0.180, "k_attn_dual_fwd": 0.066, "k_conv_tile": 0.193, "k_wgrad_tile": 0.137}
     pmc = {}
     pj = os.path.join(ROOT, "profiles", "r02", "pmc_attention_bp256.json")
     if os.path.exists(pj):

@@ -34,6 +34,8 @@ if not os.environ.get("EM_ONLY"):
     dt = (time.perf_counter() - t0) / steps
     print(f"B={B} train step {dt*1e3:.1f} ms  loss {float(l):.4f} -> {6*5.974e9*B/dt/1e12:.1f} TFLOP/s (algorithmic) "
           f"mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
+if os.environ.get("TRAIN_ONLY"):
+    sys.exit(0)
 x = torch.randn(B, d, device=dev)
 st = gen.base_sde.struct()
 rng = gen.base_sde.philox(dev)
