@@ -17,8 +17,10 @@ dev = torch.device("cuda")
 torch.manual_seed(0)
 net = VorticityUNet(base_channels=32, channel_mults=(1, 2, 4), num_res_blocks=2, in_space=S_, attention_resolutions=(2, 4),
                     flatten_order="F", channels=Cc).to(dev)
-from oracle.det_params import load_det_
-load_det_(net.core)          # non-zero "zero-init" layers so every kernel does real work
+with torch.no_grad():        # non-zero "zero-init" layers (model/nn_utils.py:151-157) so every kernel does real work
+    for prm in net.parameters():
+        if float(prm.abs().sum()) == 0.0:
+            prm.normal_(0.0, 0.02)
 T = torch.nn.Parameter(torch.FloatTensor([1.0]), requires_grad=False)
 gen = PluginReverseSDE(SGMsde(T=T, num_steps_forward=16, device=dev), net, T, deviceReverseSDE=dev).to(dev)
 if not os.environ.get("EM_ONLY"):
