@@ -451,3 +451,55 @@ def test_unet_output_conv_small_cout(N, nb, Cout, H, W_, aff):
     out2 = torch.ones(N * H * W_ * Cout, device=DEV)
     op.forward([xs], N, H, W_, n_bias=nb, in_affine=ab, in_act=1 if aff else 0, out=out2, accumulate=True)
     assert rel_l2((out2 - 1.0).cpu(), out.cpu()) <= 1e-6
+
+
+@pytest.mark.parametrize("N,C0,C1,Cout,T,aff,extra", [(20, 64, 0, 192, 256, True, None),        # qkv with the folded GroupNorm
+                                                        (6, 64, 0, 64, 1024, False, "residual"),   # proj_out + x
+                                                        (24, 128, 64, 128, 256, False, None),      # decoder skip conv, two sources
+                                                        (10, 128, 0, 384, 512, True, "accumulate"),
+                                                        (3, 32, 0, 32, 4096, False, "residual")])
+def test_pixel_stationary_1x1_kernel(N, C0, C1, Cout, T, aff, extra):
+    """k_conv1x1 (1x1 convolutions with >= 4096 pixels: qkv / proj_out / skip convs, model/unet.py:216-232,158) with its
+    fused options — folded GroupNorm(+SiLU) on the input, second source, residual / accumulate in the epilogue, per-sample
+    bias on the primal rows — against plain PyTorch fp32, and against the halo-tile kernel that served these shapes
+    before (MSGM_NO_CONV1X1 is read once per process, so that comparison lives in tools/bench_1x1.py)."""
+    from sdeflow_light_amd import ops
+    torch.manual_seed(N + C0 + Cout)
+    C = C0 + C1
+    x = torch.randn(N, C, T) * 1.3 + 0.2
+    w, b = torch.randn(Cout, C, 1) * 0.1, torch.randn(Cout)
+    nb = N - 2                                               # the last two rows play tangent rows: no bias
+    sb = torch.randn(nb, Cout)
+    h = x
+    ab = None
+    if aff:
+        G = 32
+        gam, bet = torch.randn(C) * 0.5 + 1.0, torch.randn(C) * 0.2
+        h = F.silu(F.group_norm(x, G, gam, bet, 1e-5))
+    ref = F.conv1d(h, w, None)
+    ref[:nb] += (b[None, :] + sb)[:, :, None]
+    op = mk(w, b, "conv", (1,), 1, 0, [C0] + ([C1] if C1 else []))
+    x0 = cl1(x[:, :C0]).reshape(-1).to(DEV)
+    x1 = cl1(x[:, C0:]).reshape(-1).to(DEV) if C1 else None
+    if aff:
+        ab = ops.groupnorm_affine(x0, C0, gam.to(DEV), bet.to(DEV), N, T, G, x1=x1, C1=C1)
+    srcs = [x0] + ([x1] if C1 else [])
+    kw = dict(n_bias=nb, samp_bias=sb.reshape(-1).to(DEV), emb_rows=nb, in_affine=ab, in_act=1 if aff else 0)
+    if extra == "residual":
+        r = torch.randn(N, Cout, T)
+        out, _, _ = op.forward(srcs, N, 1, T, residual=cl1(r).reshape(-1).to(DEV), stats=True, **kw)
+        ref = ref + r
+    elif extra == "accumulate":
+        r = torch.randn(N, Cout, T)
+        out = cl1(r).reshape(-1).to(DEV).clone()
+        op.forward(srcs, N, 1, T, out=out, accumulate=True, stats=True, **kw)
+        ref = ref + r
+    else:
+        out, _, _ = op.forward(srcs, N, 1, T, stats=True, **kw)
+    e = rel_l2(out.view(N, T, Cout).cpu(), cl1(ref))
+    print(f"1x1 {C0}+{C1}->{Cout} T={T} N={N} affine={aff} {extra}: rel-L2 {e:.2e}")
+    assert e <= 4e-7                                         # measured 0.6-1.5e-7
+    cs, S = out._msgm_cs                                     # and the statistics by-product describes the final values
+    o = out.view(N, T, Cout).double()
+    tot = cs.view(N, S, 2, Cout).double().sum(1)
+    assert rel_l2(tot[:, 0].cpu(), o.sum(1).cpu()) <= 2e-6 and rel_l2(tot[:, 1].cpu(), (o * o).sum(1).cpu()) <= 2e-6
