@@ -1664,7 +1664,7 @@ static bool conv_small_shape(const msgm_conv_geom_t* geom, bool has1, bool masks
          !has1 && !masks;
 }
 static ConvRoute conv_route(const msgm_conv_geom_t* geom, int32_t C0, bool has1, int32_t C1, int32_t Cout, int32_t CoutP,
-                            bool masks, bool both_extra = false /* accumulate AND residual */) {
+                            bool masks, bool both_extra = false /* accumulate AND residual */, bool any_size = false) {
   ConvRoute r{};
   const int64_t Mtot = (int64_t)geom->N * geom->Ho * geom->Wo;
   if (conv_small_shape(geom, has1, masks)) {
@@ -1676,7 +1676,7 @@ static ConvRoute conv_route(const msgm_conv_geom_t* geom, int32_t C0, bool has1,
   static const bool no1 = getenv("MSGM_NO_CONV1X1") != nullptr;            // diagnostic A/B
   const int kg = Ktot / 16;
   if (!no1 && geom->KH == 1 && geom->KW == 1 && geom->strideH == 1 && geom->strideW == 1 && geom->padH == 0 && geom->padW == 0 &&
-      !geom->ups && geom->Hi == geom->Ho && geom->Wi == geom->Wo && fast && !masks && Mtot >= 4096 &&
+      !geom->ups && geom->Hi == geom->Ho && geom->Wi == geom->Wo && fast && !masks && (Mtot >= 4096 || any_size) &&
       (kg == 2 || kg == 4 || kg == 6 || kg == 8 || kg == 12 || kg == 16) && Cout % 16 == 0 && !both_extra) {
     // resident activations: PT * KG float4 per lane (<= 64 registers).  Fewer pixels per wave (more waves per SIMD) measured
     // equal at 64 input channels and 1.4x slower at 128 (tools/bench_1x1.py)
@@ -1758,7 +1758,20 @@ int msgm_conv_forward_fused(const msgm_conv_geom_t* geom, const float* src0, int
     for (int i = 0; i < 8; ++i) masks = masks || fuse->tapmask_out[i];
   }
   const bool both_extra = accumulate && fuse && fuse->residual;
-  const ConvRoute rt = conv_route(geom, C0, src1 != nullptr, C1, Cout, CoutP, masks, both_extra);
+  // A Linear layer (H = W = 1: the embedding / time MLPs, model/unet.py:334-340,128-134) whose rows all take the same bias
+  // path is the 1x1 convolution of ONE sample with N pixels: that shape takes the pixel-stationary kernel (a few
+  // microseconds at N = 32..1024 rows) instead of the implicit GEMM's chain of L2 round trips (18-37 us, 49 launches per
+  // training step at the 32-row shard).
+  msgm_conv_geom_t lin = *geom;
+  const bool as_pixels = geom->Hi == 1 && geom->Wi == 1 && geom->Ho == 1 && geom->Wo == 1 && geom->KH == 1 && geom->KW == 1 &&
+                         geom->N >= 32 && !samp_bias && (!bias || n_bias >= geom->N) && !(fuse && (fuse->in_scale || fuse->chanstats)) &&
+                         !getenv("MSGM_NO_LINEAR_AS_PIXELS");
+  if (as_pixels) {
+    lin.Wi = lin.Wo = geom->N; lin.N = 1; lin.mode = 0;
+    const ConvRoute rl = conv_route(&lin, C0, src1 != nullptr, C1, Cout, CoutP, masks, both_extra, true);
+    if (rl.kind == 1) { geom = &lin; n_bias = bias ? 1 : 0; n_samp = 0; }
+  }
+  const ConvRoute rt = conv_route(geom, C0, src1 != nullptr, C1, Cout, CoutP, masks, both_extra, geom == &lin);
   if (fuse && fuse->in_scale && rt.kind != 4 && !conv_tile_eligible(geom, C0, src1, C1, CoutP)) return MSGM_E_UNSUPPORTED;
   ConvArgs A{};
   A.g = to_geom(geom);
