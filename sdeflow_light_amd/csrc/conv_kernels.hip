@@ -344,6 +344,9 @@ __global__ void __launch_bounds__(256, (PT == 4 && !DB && NCO == 4) ? CT_WIDE_MI
   constexpr int MAXST = (halo * (CT_KC / 4) + 255) / 256;
   constexpr int HALF = MAXST;          // (staging in two halves measured no register gain: the epilogue is the peak)
   f32x4 st[HALF];
+  f32x4 st_ga, st_gb;                    // the staged item's input affine and which of its elements are real pixels
+  unsigned st_valid = 0;
+  long st_aoff = -1;
   constexpr int n_items = halo * (CT_KC / 4);
   const int padH = g.padH, padW = g.padW;
   const int up = g.ups ? 1 : 0;          // Upsample folded into the gather (model/unet.py:60-73)
@@ -359,14 +362,17 @@ __global__ void __launch_bounds__(256, (PT == 4 && !DB && NCO == 4) ? CT_WIDE_MI
     const int C = A.C[s];
     const float* base = A.src[s] + (size_t)n * g.Hi * g.Wi * C;
     // folded GroupNorm(+SiLU): this thread's 4 channels are the same for every k (256 % 8 == 0), so a and b are
-    // fetched once per staged chunk; zero padding stays zero (the transform is applied to real pixels only)
-    f32x4 ga = {1.f, 1.f, 1.f, 1.f}, gb = {0.f, 0.f, 0.f, 0.f};
+    // fetched once per staged chunk.  They are APPLIED in stage_store, after all the halo loads of the item are in
+    // flight: applied here, inside the bounds check of each load, every load waited for the previous one's data (11
+    // serialised round trips per item: +10 % on the 32-channel layers of the sampler, tools/bench_conv_epi.py).
+    // (double-buffered form: only their offset is kept across the MFMAs of the previous item — 8 registers less there)
     const int cq = c0 + 4 * (tid & 7);
-    if (A.in_scale && cq < C) {
-      const size_t o = (size_t)n * ctot_all + (s ? A.C[0] : 0) + cq;
-      ga = *reinterpret_cast<const f32x4*>(A.in_scale + o);
-      gb = *reinterpret_cast<const f32x4*>(A.in_shift + o);
+    st_aoff = (A.in_scale && cq < C) ? (long)n * ctot_all + (s ? A.C[0] : 0) + cq : -1;
+    if (!DB) {
+      st_ga = f32x4{1.f, 1.f, 1.f, 1.f}; st_gb = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (st_aoff >= 0) { st_ga = *reinterpret_cast<const f32x4*>(A.in_scale + st_aoff); st_gb = *reinterpret_cast<const f32x4*>(A.in_shift + st_aoff); }
     }
+    unsigned valid = 0;
     // this thread's halo positions (row, column) are the same for every tile but are RE-derived per item (HW is a
     // compile-time constant: a multiply-high each): kept in registers they were MAXST live values at the kernel's
     // register peak (the epilogue) — the opaque copy of tid keeps the compiler from hoisting them back out of the loop
@@ -388,17 +394,12 @@ __global__ void __launch_bounds__(256, (PT == 4 && !DB && NCO == 4) ? CT_WIDE_MI
         if (iy >= 0 && iy < (g.Hi << up) && ix >= 0 && ix < (g.Wi << up) && c < C) {
 #endif
           v = *reinterpret_cast<const f32x4*>(base + ((size_t)(iy >> up) * g.Wi + (ix >> up)) * C + c);
-          if (A.in_scale) {
-            v = v * ga + gb;
-            if (A.in_act == 1) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[r]));
-            }
-          }
+          valid |= 1u << k;                                    // a real pixel: zero padding stays zero
         }
       }
       dst[k - K0] = v;
     }
+    st_valid = valid;
   };
   // item after (t_, s_, c_); returns whether (t_, s_, c_) is the last chunk of its tile
   auto advance = [&](int t_, int s_, int c_, int& nt, int& ns_, int& nc_) {
@@ -411,6 +412,23 @@ __global__ void __launch_bounds__(256, (PT == 4 && !DB && NCO == 4) ? CT_WIDE_MI
   auto stage_store = [&](float* buf, int K0, int K1) __attribute__((always_inline)) {
     int tv = tid;
     asm volatile("" : "+v"(tv));                            // LDS addresses re-derived per item, not kept in registers
+    if (A.in_scale) {
+      if (DB) {
+        st_ga = f32x4{1.f, 1.f, 1.f, 1.f}; st_gb = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (st_aoff >= 0) { st_ga = *reinterpret_cast<const f32x4*>(A.in_scale + st_aoff); st_gb = *reinterpret_cast<const f32x4*>(A.in_shift + st_aoff); }
+      }
+#pragma unroll
+      for (int k = K0; k < K1; ++k) {
+        if ((st_valid >> k) & 1u) {
+          f32x4 v = st[k - K0] * st_ga + st_gb;
+          if (A.in_act == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[r]));
+          }
+          st[k - K0] = v;
+        }
+      }
+    }
 #pragma unroll
     for (int k = K0; k < K1; ++k) {
       const int idx = tv + 256 * k;

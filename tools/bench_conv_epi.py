@@ -30,3 +30,16 @@ for (H, Ci, Co) in ((32, 64, 64), (64, 32, 32), (16, 128, 128)):
     r["accumulate"] = timeit(lambda: ops.conv_forward(geom, x, Ci, Wp, Co, out, n_bias=N, accumulate=True))
     r["residual+stats"] = timeit(lambda: ops.conv_forward(geom, x, Ci, Wp, Co, out, n_bias=N, residual=res, chanstats=cs))
     print(f"3x3 {Ci}->{Co} @{H}x{H} N={N}: " + "  ".join(f"{k} {v*1e3:.3f} ms ({fl/v/1e12:.0f} TF/s)" for k, v in r.items()))
+print("--- input transform (GroupNorm affine + SiLU applied while staging) ---")
+for (H, Ci, Co) in ((32, 64, 64), (64, 32, 32), (16, 128, 128), (64, 96, 32)):
+    x = torch.randn(N * H * H * Ci, device=dev)
+    Wp = torch.randn(9 * ops.pad16(Co) * ops.pad16(Ci), device=dev) * 0.05
+    out = torch.zeros(N * H * H * Co, device=dev)
+    sc, sh = torch.rand(N * Ci, device=dev) + 0.5, torch.randn(N * Ci, device=dev)
+    geom = ops.conv_geom(N, H, H, H, H, 3, 3, 1, 1)
+    fl = 2 * 9 * Ci * Co * N * H * H
+    r = {}
+    r["plain"] = timeit(lambda: ops.conv_forward(geom, x, Ci, Wp, Co, out, n_bias=N))
+    r["affine"] = timeit(lambda: ops.conv_forward(geom, x, Ci, Wp, Co, out, n_bias=N, in_scale=sc, in_shift=sh, in_act=0))
+    r["affine+SiLU"] = timeit(lambda: ops.conv_forward(geom, x, Ci, Wp, Co, out, n_bias=N, in_scale=sc, in_shift=sh, in_act=1))
+    print(f"3x3 {Ci}->{Co} @{H}x{H} N={N}: " + "  ".join(f"{k} {v*1e3:.3f} ms ({fl/v/1e12:.0f} TF/s)" for k, v in r.items()))
