@@ -392,11 +392,12 @@ class VorticityUNet(nn.Module, FlatParamMixin):
         logr: [log r ; rdot/r] (N,) with NormalizeLogRadius conditioning."""
         x = self._build()
         x["set"].pack()
-        # sampler path (no tangent, nothing kept): with MSGM_WINO=1 the 3x3 stride-1 convolutions take the Winograd
-        # F(2x2,3x3) forward kernel.  Opt-in: measured 1.11-1.20x on plain convolutions but only 1.01-1.07x once GroupNorm +
-        # SiLU are applied in the halo staging (the staging, not the MFMA count, is what those launches wait for), i.e.
-        # +1 % on the C5 step (tools/bench_wino.py) — not worth a second rounding path in the default sampler
-        self._wino = not dual and tape is None and bool(os.environ.get("MSGM_WINO"))
+        # sampler path (no tangent, nothing kept): the 3x3 stride-1 convolutions on 16-multiple images take the Winograd
+        # F(2x2,3x3) forward kernel — 2.25x fewer MFMAs, all fp32, 1.13-1.26x the direct kernel with the folded GroupNorm +
+        # SiLU staging (tools/bench_wino.py), same fused options and statistics by-product; it differs from the direct form
+        # by the rounding of its transforms (2-6e-7 per conv) and every sampler parity test runs through it.
+        # MSGM_NO_WINO=1 keeps the direct kernels (A/B).  The training path always uses the direct kernels.
+        self._wino = not dual and tape is None and not os.environ.get("MSGM_NO_WINO")
         self._cs_on = not os.environ.get("MSGM_NO_CHANSTATS")            # diagnostic A/B: GroupNorm statistics by a pass over the tensor
         if self._wino:
             x["set"].pack_wino()

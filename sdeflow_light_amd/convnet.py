@@ -248,8 +248,9 @@ class ConvOp:
             self._E = E
         cs, S = None, 0
         out._msgm_cs = None                      # whatever was there described the values about to be overwritten
-        if stats and not wino and not self.embC:
-            S = ops.conv_chanstats_slots(geom, self.srcC[0], self.srcC[1] if len(srcs) > 1 else 0, self.Cout, self.CoutP)
+        if stats and not self.embC:
+            S = ((Ho // 16) * (Wo // 16) * 4 if wino and self.Cout % 4 == 0 else 0 if wino else
+                 ops.conv_chanstats_slots(geom, self.srcC[0], self.srcC[1] if len(srcs) > 1 else 0, self.Cout, self.CoutP))
             if S > 0:
                 cs = torch.empty(N * S * 2 * self.Cout, device=dev)
         ops.conv_forward(geom, srcs[0], self.srcC[0], self.WpW if wino else self.Wp, self.Cout, out,

@@ -940,8 +940,9 @@ __global__ void __launch_bounds__(256, 2) k_conv_wino(ConvArgs A, int tiles_x, i
       gb = *reinterpret_cast<const f32x4*>(A.in_shift + o);
     }
     f32x4 st[MAXST];
+    unsigned valid = 0;
 #pragma unroll
-    for (int k = 0; k < MAXST; ++k) {
+    for (int k = 0; k < MAXST; ++k) {                       // all the loads first (see k_conv_tile's stage_load)
       const int idx = tid + 256 * k;
       f32x4 v = {0, 0, 0, 0};
       if (idx < n_items) {
@@ -950,16 +951,23 @@ __global__ void __launch_bounds__(256, 2) k_conv_wino(ConvArgs A, int tiles_x, i
         const int c = c0 + 4 * (idx & 7);
         if (iy >= 0 && iy < (g.Hi << up) && ix >= 0 && ix < (g.Wi << up) && c < C) {
           v = *reinterpret_cast<const f32x4*>(base + ((size_t)(iy >> up) * g.Wi + (ix >> up)) * C + c);
-          if (A.in_scale) {
-            v = v * ga + gb;
-            if (A.in_act == 1) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[r]));
-            }
-          }
+          valid |= 1u << k;
         }
       }
       st[k] = v;
+    }
+    if (A.in_scale) {
+#pragma unroll
+      for (int k = 0; k < MAXST; ++k) {
+        if ((valid >> k) & 1u) {
+          f32x4 v = st[k] * ga + gb;
+          if (A.in_act == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[r]));
+          }
+          st[k] = v;
+        }
+      }
     }
 #pragma unroll
     for (int k = 0; k < MAXST; ++k) {
@@ -1057,6 +1065,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_wino(ConvArgs A, int tiles_x, i
     f32x4 Y[2][2];
     Y[0][0] = t0[0] + t0[1] + t0[2]; Y[0][1] = t0[1] - t0[2] - t0[3];
     Y[1][0] = t1[0] + t1[1] + t1[2]; Y[1][1] = t1[1] - t1[2] - t1[3];
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f}, css = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
@@ -1070,12 +1079,15 @@ __global__ void __launch_bounds__(256, 2) k_conv_wino(ConvArgs A, int tiles_x, i
           if (A.accumulate) v += *reinterpret_cast<const f32x4*>(op);
           if (A.residual) v += *reinterpret_cast<const f32x4*>(A.residual + (op - A.out));
           *reinterpret_cast<f32x4*>(op) = v;
+          cs += v; css += v * v;
         } else {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             if (co + r < A.Cout) op[r] = (A.accumulate ? op[r] + v[r] : v[r]) + (A.residual ? A.residual[(op - A.out) + r] : 0.f);
         }
       }
+    // the wave's 16 Winograd tiles = 64 pixels: one statistics slot, as the direct kernel's 16x16 tiles (Cout % 4 == 0, host)
+    if (A.cstat) cstat_store(A, n, (tile - n * tiles_x * tiles_y) * 4 + w, co, cs, css, il);
   }
 }
 
@@ -1657,9 +1669,10 @@ int msgm_conv_forward_wino(const msgm_conv_geom_t* geom, const float* src0, int3
   A.nsrc = src1 ? 2 : 1;
   A.Wp = WpW; A.Cout = Cout; A.CoutP = CoutP; A.Ktot = Ktot;
   A.bias = bias; A.samp_bias = samp_bias; A.n_bias = n_bias; A.n_samp = n_samp; A.out = out; A.accumulate = accumulate;
-  if (fuse && fuse->chanstats) return MSGM_E_UNSUPPORTED;       // no channel-statistics by-product in this kernel
+  if (fuse && fuse->chanstats && (Cout & 3)) return MSGM_E_UNSUPPORTED;
   if (fuse) { A.residual = fuse->residual; A.in_scale = fuse->in_scale; A.in_shift = fuse->in_shift; A.in_act = fuse->in_act; }
   const int tiles_x = geom->Wo / 16, tiles_y = geom->Ho / 16;
+  if (fuse && fuse->chanstats) { A.cstat = fuse->chanstats; A.cs_S = tiles_x * tiles_y * 4; }   // [N][Ho/16 * Wo/16 * 4][2][Cout]
   const int n_tiles = tiles_x * tiles_y * geom->N, gy = CoutP / 32;
   const size_t lds = (size_t)18 * 18 * CT_P * sizeof(float);
   dim3 grid((unsigned)(8 * gy * ((n_tiles + 7) / 8)));

@@ -331,7 +331,8 @@ def conv_forward(geom: L.ConvGeomT, src0: torch.Tensor, C0: int, Wp: torch.Tenso
             raise MsgmError("in_scale / in_shift must both be [N][C0+C1]")
         fuse = L.ConvFuseT(ptr(residual), ptr(in_scale), ptr(in_shift), int(in_act), 0)
         if chanstats is not None:
-            S = conv_chanstats_slots(geom, C0, C1 if src1 is not None else 0, Cout, CoutP)
+            S = ((geom.Ho // 16) * (geom.Wo // 16) * 4 if wino else
+                 conv_chanstats_slots(geom, C0, C1 if src1 is not None else 0, Cout, CoutP))
             if S <= 0 or chanstats.numel() < geom.N * S * 2 * Cout or chanstats.dtype != torch.float32:
                 raise MsgmError("chanstats: this convolution has no statistics by-product, or the buffer is too small")
             fuse.chanstats = ptr(chanstats)

@@ -318,11 +318,16 @@ def test_winograd_forward_equals_direct_conv(N, H, Ci, Co, two, ups, aff):
     in_aff = (1 + 0.3 * torch.randn(N * (C0 + C1), device=dev), 0.2 * torch.randn(N * (C0 + C1), device=dev)) if aff else None
     kw = dict(samp_bias=sb, residual=res, in_affine=in_aff, in_act=1 if aff else 0)
     ref, _, _ = op.forward(srcs, N, Hi, Hi, N, **kw)
-    got, _, _ = op.forward(srcs, N, Hi, Hi, N, wino=True, **kw)
+    got, _, _ = op.forward(srcs, N, Hi, Hi, N, wino=True, stats=True, **kw)
     e = rel_l2(got.cpu(), ref.cpu())
     print(f"Winograd vs direct 3x3 conv N={N} {H}x{H} {C0}+{C1}->{Co} ups={ups} affine={aff}: rel-L2 {e:.2e}")
     assert e <= 2e-6
     assert not torch.equal(got, ref)                       # it really took the other kernel
+    cs, S = got._msgm_cs                                   # its statistics by-product: one slot per (16x16 tile, wave)
+    assert S == (H // 16) ** 2 * 4
+    o = got.view(N, H * H, Co).double()
+    tot = cs.view(N, S, 2, Co).double().sum(1)
+    assert rel_l2(tot[:, 0].cpu(), o.sum(1).cpu()) <= 2e-6 and rel_l2(tot[:, 1].cpu(), (o * o).sum(1).cpu()) <= 2e-6
 
 
 # ------------------------------------------------------------------ channel statistics as a by-product of the epilogue
