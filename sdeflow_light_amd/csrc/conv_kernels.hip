@@ -823,24 +823,36 @@ __global__ void __launch_bounds__(256) k_conv3x3_cout_small(ConvArgs A, int tile
     ga = *reinterpret_cast<const f32x4*>(A.in_scale + (size_t)n * 32 + 4 * c4);
     gb = *reinterpret_cast<const f32x4*>(A.in_shift + (size_t)n * 32 + 4 * c4);
   }
+  constexpr int NST = (n_items + 255) / 256;
+  f32x4 st[NST];
+  unsigned valid = 0;
 #pragma unroll
-  for (int k = 0; k < (n_items + 255) / 256; ++k) {
+  for (int k = 0; k < NST; ++k) {                           // all the loads first, then the transform (see k_conv_tile)
     const int idx = tid + 256 * k;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (idx < n_items) {
       const int hp = idx >> 3, hy = hp / HW, hx = hp - hy * HW;
       const int iy = y0 + hy - 1, ix = x0 + hx - 1;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi) {
         v = *reinterpret_cast<const f32x4*>(base + ((size_t)iy * g.Wi + ix) * 32 + 4 * c4);
-        if (A.in_scale) {
-          v = v * ga + gb;
-          if (A.in_act == 1) {
+        valid |= 1u << k;
+      }
+    }
+    st[k] = v;
+  }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[r]));
-          }
+  for (int k = 0; k < NST; ++k) {
+    const int idx = tid + 256 * k;
+    if (idx < n_items) {
+      f32x4 v = st[k];
+      if (A.in_scale && ((valid >> k) & 1u)) {
+        v = v * ga + gb;
+        if (A.in_act == 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[r]));
         }
       }
-      *reinterpret_cast<f32x4*>(cs_lds + hp * CT_P + 4 * c4) = v;
+      *reinterpret_cast<f32x4*>(cs_lds + (idx >> 3) * CT_P + 4 * c4) = v;
     }
   }
   __syncthreads();
