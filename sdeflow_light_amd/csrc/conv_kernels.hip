@@ -1246,7 +1246,10 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(WgradArgs A) {
 #ifndef WT_DBUF
 #define WT_DBUF(TAPS) ((TAPS) == 9)
 #endif
-template <int TH, int TW, int TAPS>
+// RAG: channel counts that are not multiples of 4 (the U-Net's input conv has 1 or 3 input channels, its output conv 1 or 3
+// output channels): the staging loads go element by element with a channel mask instead of 16 bytes at a time.  Those two
+// layers ran on k_conv_wgrad at 1.2 ms each per C4 step (rocprofv3), 1.8 % of it.
+template <int TH, int TW, int TAPS, bool RAG = false>
 __global__ void __launch_bounds__(256, 2) k_wgrad_tile(WgradArgs A, int tiles_x, int tiles_y, int tiles_per_wg, int n_tiles) {
   extern __shared__ __attribute__((aligned(16))) float wt_lds[];
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, il = lane & 15, q = lane >> 4;
@@ -1288,8 +1291,14 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_tile(WgradArgs A, int tiles_x,
       const int py = p / TW, px = p - py * TW;
       const int oy = y0 + py, ox = x0 + px, co = co0 + 4 * c4;
       f32x4 v = {0, 0, 0, 0};
-      if (oy < g.Ho && ox < g.Wo && co < A.Cout)
-        v = *reinterpret_cast<const f32x4*>(A.gy + (((size_t)n * g.Ho + oy) * g.Wo + ox) * A.Cout + co);
+      if (oy < g.Ho && ox < g.Wo && co < A.Cout) {
+        const float* gp = A.gy + (((size_t)n * g.Ho + oy) * g.Wo + ox) * A.Cout + co;
+        if (!RAG) v = *reinterpret_cast<const f32x4*>(gp);
+        else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (co + r < A.Cout) v[r] = gp[r];
+        }
+      }
       sg[k] = v;
     }
 #pragma unroll
@@ -1300,8 +1309,14 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_tile(WgradArgs A, int tiles_x,
         const int hp = idx >> 3, c4 = idx & 7;
         const int hy = hp / HW, hx = hp - hy * HW;
         const int iy = y0 + hy - g.padH, ix = x0 + hx - g.padW, c = c0 + 4 * c4;   // on the 2x grid if ups
-        if (iy >= 0 && iy < (g.Hi << up) && ix >= 0 && ix < (g.Wi << up) && c < A.C)
-          v = *reinterpret_cast<const f32x4*>(A.src + (((size_t)n * g.Hi + (iy >> up)) * g.Wi + (ix >> up)) * A.C + c);
+        if (iy >= 0 && iy < (g.Hi << up) && ix >= 0 && ix < (g.Wi << up) && c < A.C) {
+          const float* sp = A.src + (((size_t)n * g.Hi + (iy >> up)) * g.Wi + (ix >> up)) * A.C + c;
+          if (!RAG) v = *reinterpret_cast<const f32x4*>(sp);
+          else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (c + r < A.C) v[r] = sp[r];
+          }
+        }
       }
       si[k] = v;
     }
@@ -1937,7 +1952,8 @@ static WgradPlan wgrad_plan(const msgm_conv_geom_t* geom, int C, int Cout, int n
   const bool same = geom->mode == 0 && geom->strideH == 1 && geom->strideW == 1 && (geom->Hi << ups_sh) == geom->Ho &&
                     (geom->Wi << ups_sh) == geom->Wo && (geom->KH & 1) && (geom->KW & 1) && geom->padH == (geom->KH - 1) / 2 &&
                     geom->padW == (geom->KW - 1) / 2 && geom->KH <= 3 && geom->KW <= 3;
-  p.tile = same && C % 4 == 0 && Cout % 4 == 0 && (int64_t)geom->Ho * geom->Wo >= 64 &&
+  const bool aligned = C % 4 == 0 && Cout % 4 == 0;      // otherwise only the 2-D 3x3 form has the element-wise staging (RAG)
+  p.tile = same && (aligned || (taps == 9 && geom->Ho > 1 && !getenv("MSGM_NO_WGRAD_RAG"))) && (int64_t)geom->Ho * geom->Wo >= 64 &&
            (taps == 1 || taps == 3 || (taps == 9 && geom->Ho > 1)) && (geom->Ho > 1 || geom->KH == 1) && !getenv("MSGM_NO_WGRAD_TILE");
   if (p.tile) {
     const bool two_d = geom->Ho > 1;
@@ -2036,19 +2052,25 @@ static int wgrad_impl(const msgm_conv_geom_t* geom, const float* gy, const float
     if (lds < 4096 * sizeof(float)) lds = 4096 * sizeof(float);
     dim3 grid((unsigned)wgs, (unsigned)yblocks);
     // more than 64 KB of dynamic LDS has to be opted into per kernel (160 KB per CU on gfx950)
-#define WT_LAUNCH(TH_, TW_, TP_)                                                                                     \
+#define WT_LAUNCH(TH_, TW_, TP_) WT_LAUNCH2(TH_, TW_, TP_, false)
+#define WT_LAUNCH2(TH_, TW_, TP_, RAG_)                                                                              \
   do {                                                                                                               \
     static const int once = [] {                                                                                     \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_tile<TH_, TW_, TP_>),                         \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_tile<TH_, TW_, TP_, RAG_>),                   \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                             \
       return 0;                                                                                                      \
     }();                                                                                                             \
     (void)once;                                                                                                      \
-    hipLaunchKernelGGL((k_wgrad_tile<TH_, TW_, TP_>), grid, dim3(256), lds, S(stream), A, tiles_x, tiles_y, per, n_tiles); \
+    hipLaunchKernelGGL((k_wgrad_tile<TH_, TW_, TP_, RAG_>), grid, dim3(256), lds, S(stream), A, tiles_x, tiles_y, per, n_tiles); \
   } while (0)
-    if (two_d) { if (taps == 9) WT_LAUNCH(8, 16, 9); else if (taps == 3) WT_LAUNCH(8, 16, 3); else WT_LAUNCH(8, 16, 1); }
+    const bool rag = (C & 3) || (Cout & 3);
+    if (two_d) {
+      if (taps == 9) { if (rag) WT_LAUNCH2(8, 16, 9, true); else WT_LAUNCH(8, 16, 9); }
+      else if (taps == 3) WT_LAUNCH(8, 16, 3); else WT_LAUNCH(8, 16, 1);
+    }
     else { if (taps == 3) WT_LAUNCH(1, 128, 3); else WT_LAUNCH(1, 128, 1); }
 #undef WT_LAUNCH
+#undef WT_LAUNCH2
     if (det) reduce_slabs(wgs, dbias != nullptr);
     return msgm_check_launch();
   }
