@@ -771,7 +771,8 @@ __global__ void __launch_bounds__(256) k_conv3x3_cin_small(ConvArgs A, long Mtot
     const int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
     const bool ok = iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi;
     const float* px = src + ((size_t)(ok ? iy : 0) * g.Wi + (ok ? ix : 0)) * Cin;
-    const float* wt = A.Wp + (size_t)tap * A.CoutP * A.Ktot;           // W[tap][co][c] at wt[co * Ktot + c]: uniform
+    // mode 1 = the transposed gather i = o + pad - k (dgrad of the same convolution with the Wd image): tap 8 - t's weights
+    const float* wt = A.Wp + (size_t)(g.mode ? 8 - tap : tap) * A.CoutP * A.Ktot;   // W[tap][co][c] at wt[co * Ktot + c]: uniform
     for (int c = 0; c < Cin; ++c) {
       const float xv = ok ? px[c] : 0.f;
 #pragma unroll
@@ -1717,7 +1718,7 @@ struct ConvRoute {
 // first / last convolution of the U-Net: 3x3 "same", one source, <= 4 channels on one side and 32 on the other
 static bool conv_small_shape(const msgm_conv_geom_t* geom, bool has1, bool masks) {
   static const bool off = getenv("MSGM_NO_CONV_SMALL") != nullptr;         // diagnostic A/B
-  return !off && geom->mode == 0 && geom->KH == 3 && geom->KW == 3 && geom->strideH == 1 && geom->strideW == 1 &&
+  return !off && geom->KH == 3 && geom->KW == 3 && geom->strideH == 1 && geom->strideW == 1 &&
          geom->padH == 1 && geom->padW == 1 && !geom->ups && geom->Hi == geom->Ho && geom->Wi == geom->Wo && geom->Ho > 1 &&
          !has1 && !masks;
 }
@@ -1726,8 +1727,8 @@ static ConvRoute conv_route(const msgm_conv_geom_t* geom, int32_t C0, bool has1,
   ConvRoute r{};
   const int64_t Mtot = (int64_t)geom->N * geom->Ho * geom->Wo;
   if (conv_small_shape(geom, has1, masks)) {
-    if (C0 <= 4 && Cout == 32 && CoutP == 32) { r.kind = 3; return r; }
-    if (C0 == 32 && Cout <= 4) { r.kind = 4; return r; }
+    if (C0 <= 4 && Cout == 32 && CoutP == 32) { r.kind = 3; return r; }      // forward, or (mode 1) the dgrad of the output conv
+    if (C0 == 32 && Cout <= 4 && geom->mode == 0) { r.kind = 4; return r; }
   }
   const bool fast = (C0 % 16 == 0) && (!has1 || C1 % 16 == 0);
   const int Ktot = ((C0 + 15) / 16) * 16 + (has1 ? ((C1 + 15) / 16) * 16 : 0);
