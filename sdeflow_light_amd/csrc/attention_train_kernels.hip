@@ -396,8 +396,12 @@ __global__ void __launch_bounds__(512) k_attn_dual_bwd(const float* __restrict__
       const size_t row = (size_t)qb * QB + 16 * qs + il;
       float* sp = slab + (((size_t)smp * nkb + kb) * T + row) * C + 16 * kg + 4 * q;
       float* sdp = slab + (((size_t)(Bp + smp) * nkb + kb) * T + row) * C + 16 * kg + 4 * q;
+#ifdef ATT_EXP_NODQ           // diagnostic (WRONG results): what the query-gradient slab stores cost inside the loop
+      if (dq[0] == 12345.678f) { *reinterpret_cast<f32x4*>(sp) = dq; *reinterpret_cast<f32x4*>(sdp) = dqd; }
+#else
       *reinterpret_cast<f32x4*>(sp) = dq;
       *reinterpret_cast<f32x4*>(sdp) = dqd;
+#endif
     }
   }
   // ---- the two query halves of each key group meet through LDS; scaled key / value gradients leave the chip
