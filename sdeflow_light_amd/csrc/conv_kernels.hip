@@ -618,11 +618,17 @@ __global__ void __launch_bounds__(256, (PT == 4 && !DB && NCO == 4) ? CT_WIDE_MI
 // MFMAs alone 0.27 ms, both together 0.43 ms — three waves per SIMD do not overlap the two completely.
 // Host-side contract (conv_route): Cout % 16 == 0, P % (16 PT) == 0 (a wave's pixels belong to one sample), C0 % 16 == 0
 // (and C1), at most one of accumulate / residual (EXTRA = 1: one more addend read per output element).
+#define C1_LP 36       // LDS pitch of a pixel's 32 channels (floats): 16 consecutive pixels land on distinct banks for 16-B accesses
 template <int PT, int KG, int EXTRA>     // PT pixel tiles of 16 per wave; KG = 16-channel groups of the (concatenated) input
 __global__ void __launch_bounds__(256) k_conv1x1(ConvArgs A, int P /* pixels per sample */, long Mtot, int ct_per) {
+  // full-line output stores through LDS pay with 64 pixels per wave (64-channel inputs: -7..-13 %), not with 32 or 16
+  // (128+ channels: +0..5 %, measured) — those keep the direct stores
+  constexpr bool LDS_OUT = PT == 4;
+  __shared__ __attribute__((aligned(16))) float c1_lds[4][LDS_OUT ? 16 * PT * C1_LP : 4];     // per wave: [16 PT pixels][32 channels]
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, il = lane & 15, q = lane >> 4;
   const long m0 = ((long)blockIdx.x * 4 + w) * (16 * PT);
   if (m0 >= Mtot) return;                                  // no barriers in this kernel
+  float* wl = c1_lds[w];
   const int n = __builtin_amdgcn_readfirstlane((int)(m0 / P));      // wave-uniform
   const int g0 = A.C[0] >> 4;                              // groups of the first source
   const int ctot = A.C[0] + (A.nsrc > 1 ? A.C[1] : 0);
@@ -717,8 +723,14 @@ __global__ void __launch_bounds__(256) k_conv1x1(ConvArgs A, int P /* pixels per
         for (int pt = 0; pt < PT; ++pt) acc[pt] = mfma16c(a[r], b[pt][g][r], acc[pt]);
 #endif
     }
-    // ---- epilogue of this tile: lane (pixel il of tile pt, channels 16ct + 4q .. +3)
+    // ---- epilogue of this tile: lane (pixel il of tile pt, channels 16ct + 4q .. +3).
+    // Output stores go out as FULL 128-byte lines: two consecutive channel tiles (32 channels = 128 bytes per pixel) meet in
+    // a wave-private LDS image [16 PT pixels][32 channels] and leave as rows — 8 lanes per pixel, 8 complete lines per store
+    // instruction instead of 16 half lines (the kernel's memory streams alone: 0.35 -> 0.27 ms for 64 -> 192 channels).
+    // A trailing unpaired tile is stored directly.
     f32x4 cs = {0.f, 0.f, 0.f, 0.f}, css = {0.f, 0.f, 0.f, 0.f};
+    const int half = (ct - ct0) & 1;
+    const bool paired = LDS_OUT && (half == 1 || ct + 1 < ntile);        // wave-uniform
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
       f32x4 v = acc[pt] + add;
@@ -728,10 +740,23 @@ __global__ void __launch_bounds__(256) k_conv1x1(ConvArgs A, int P /* pixels per
 #elif defined(C1_EXP_COALESCED)    // diagnostic (WRONG results): the same bytes as fully coalesced 1-KB stores
       *reinterpret_cast<f32x4*>(A.out + ((size_t)(m0 / 16 + pt) * (A.Cout / 16) + ct) * 256 + lane * 4) = v;
 #else
-      *reinterpret_cast<f32x4*>(A.out + orow + pt * ptstep + 16 * ct) = v;
+      if (paired) *reinterpret_cast<f32x4*>(wl + (16 * pt + il) * C1_LP + 16 * half + 4 * q) = v;
+      else *reinterpret_cast<f32x4*>(A.out + orow + pt * ptstep + 16 * ct) = v;
 #endif
       cs += v; css += v * v;
     }
+#if !defined(C1_EXP_NOSTORE) && !defined(C1_EXP_COALESCED)
+    if (LDS_OUT && half == 1) {                             // both halves are in LDS: rows out, 8 pixels per instruction
+      const size_t obase = (size_t)m0 * A.Cout + 16 * (ct - 1) + 4 * (lane & 7);
+#pragma unroll
+      for (int j = 0; j < 2 * PT; ++j) {
+        const int px = 8 * j + (lane >> 3);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(wl + px * C1_LP + 4 * (lane & 7));
+        *reinterpret_cast<f32x4*>(A.out + obase + (size_t)px * A.Cout) = v;
+        if (j & 1) __builtin_amdgcn_sched_barrier(0);      // two rows in flight, not all 2 PT (registers)
+      }
+    }
+#endif
     if (A.cstat) cstat_store(A, n, (int)((m0 % P) / (16 * PT)), 16 * ct + 4 * q, cs, css, il);
   }
 }
