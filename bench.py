@@ -378,6 +378,13 @@ def kernel_probes(dev, Bp):
             pmc = json.load(open(pj))["kernels"]
         except Exception:
             pmc = {}
+    pmc2 = {}
+    pj2 = os.path.join(ROOT, "profiles", "r02", "pmc_conv_probes.json")     # the conv / wgrad probe shape (tools/probe_conv.py)
+    if os.path.exists(pj2):
+        try:
+            pmc2 = json.load(open(pj2))["kernels"]
+        except Exception:
+            pmc2 = {}
     res = []
     for name, flop, fn, keep in probes:
         tk = time_kernel_events(fn, 20, dev)
@@ -400,6 +407,14 @@ def kernel_probes(dev, Bp):
             if t and t[0]:
                 r["traffic"] = float(t[0])
                 r["traffic_source"] = "profiles/r02/pmc_attention_bp256.json (PMC pass, not measured in this run); algorithmic 0.54 GB"
+        if name.startswith(("k_conv_tile", "k_wgrad_tile")) and Bp == 256:
+            key = "void k_conv_tile<16, 16, 4, 3, 4, false> grid=524288" if name.startswith("k_conv_tile") else "void k_wgrad_tile<8, 16, 9, false> grid=262144"
+            t = pmc2.get(key, {}).get("hbm_bytes")
+            if t:
+                r["traffic"] = float(t)
+                r["traffic_source"] = ("profiles/r02/pmc_conv_probes.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/probe_conv.py, "
+                                       "2 x FETCH + WRITE; not measured in this run); algorithmic 0.27 GB (input + output / gradient once; the "
+                                       "wgrad reads each operand once per 32-channel block of the other: 2x at 64 channels)")
         res.append(r)
         del keep
     return res
