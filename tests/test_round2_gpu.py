@@ -42,7 +42,7 @@ def per_tensor_check(named_grads, ref, tol, floor_frac=1e-3, what=""):
 
 
 # ------------------------------------------------------------------------------------------ (a) trajectories
-@pytest.mark.parametrize("tag,steps,tol", [("em", 8, 8e-6), ("rk4", 4, 8e-6), ("heun", 4, 8e-6)])
+@pytest.mark.parametrize("tag,steps,tol", [("em", 8, 1e-5), ("rk4", 4, 1e-5), ("heun", 4, 1e-5)])   # measured 5.4-6.6e-6 (Winograd sampler)
 def test_unet2d_reverse_sde_trajectory_vs_reference(tag, steps, tol):
     from sdeflow_light_amd import sde_scheme as SS
     g = load_golden("g16_round2")
@@ -287,4 +287,4 @@ def test_unet2d_long_reverse_sde_run_vs_oracle():
         ref = S.euler_maruyama(proc, x0, steps, z, keep_all=True, include_t0=True)
     e = [rel_l2(xs[i], ref[i]) for i in (1, 16, 32, 64, 96, 128)]
     print("HIP vs oracle, 128-step U-Net EM, rel-L2 at steps 1,16,32,64,96,128: " + " ".join(f"{v:.1e}" for v in e))
-    assert max(e) <= 4e-6                                       # measured 1.5e-06 (north_star bound on the sampler output: 1e-4)
+    assert max(e) <= 6e-6          # measured 3.5e-06 with the Winograd sampler, 1.5e-06 with the direct kernels (north_star bound: 1e-4)
