@@ -603,7 +603,9 @@ __device__ __forceinline__ void bl_load(f32x4 (&dst)[2], const float* base, long
       const int row = (tid >> 3) + 32 * ps, k4 = tid & 7;
       if (row0 + row < rmax) v = *reinterpret_cast<const f32x4*>(base + (size_t)(row0 + row) * sRow + k0 + 4 * k4);
     } else {
-      const int kk = (tid >> 4) + 16 * ps, r4 = tid & 15;
+      // lanes run along k (32 consecutive k of one row quad): the transposed LDS store below then hits 32 distinct banks per
+      // half wave (with lanes along the rows it was an 8-way conflict: PMC LDSBankConflict 27-37 % in these kernels)
+      const int kk = tid & 31, r4 = (tid >> 5) + 8 * ps;
       if (row0 + 4 * r4 < rmax) v = *reinterpret_cast<const f32x4*>(base + (size_t)(k0 + kk) * sK + row0 + 4 * r4);
     }
     dst[ps] = v;
@@ -617,7 +619,7 @@ __device__ __forceinline__ void bl_store(float* L, const f32x4 (&src)[2], int ti
       const int row = (tid >> 3) + 32 * ps, k4 = tid & 7;
       *reinterpret_cast<f32x4*>(L + row * BL_P + 4 * k4) = src[ps];
     } else {
-      const int kk = (tid >> 4) + 16 * ps, r4 = tid & 15;
+      const int kk = tid & 31, r4 = (tid >> 5) + 8 * ps;
 #pragma unroll
       for (int r = 0; r < 4; ++r) L[(4 * r4 + r) * BL_P + kk] = src[ps][r];
     }
