@@ -9,6 +9,7 @@
 // Activations are channels-last [N][P][C]; the forward-mode tangent is the second
 // half of the batch (rows n >= Bp).
 #include "common.h"
+#include <stdlib.h>
 
 __device__ __forceinline__ f32x4 mfma16u(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -918,13 +919,17 @@ static int gn_chunks(int Bp, int P, int* chunk, int* sub) {
   // fp32 partial sums run over the SAME sub-chunks of a sample whatever the batch size (32 per sample, >= 64 pixels
   // each) and are combined in double: a row's statistics — bit for bit — do not depend on how many other rows share
   // the launch, so a row's result is the same in a 32-row shard and in the 256-row batch (tests/test_fullsize_gpu.py).
-  // How many consecutive sub-chunks one workgroup takes is free: enough workgroups to fill 256 CUs a few times over.
+  // How many consecutive sub-chunks one workgroup takes is free (the test pairs of test_fullsize_gpu.py hold bit for bit;
+  // across very different batch sizes the double-precision regrouping could move a float by an ulp).
   int c = (P + 31) / 32;
   if (c < 64) c = 64;
   if (c > P) c = P;
   *sub = c;
   const int nsub = (P + c - 1) / c;
-  int want = (1024 + Bp - 1) / Bp;            // workgroups per sample
+  // ~512 workgroups in all: every workgroup ends with a fixed tail (LDS group sums of up to 5 moments + the parameter
+  // partials), so fewer, fatter workgroups win — measured 1024 -> 512: B = 32 step 23.5 -> 23.1 ms, B = 256 129.7 -> 128.8 ms
+  static const int target = getenv("MSGM_GN_WGS") ? atoi(getenv("MSGM_GN_WGS")) : 512;
+  int want = (target + Bp - 1) / Bp;            // workgroups per sample
   if (want < 1) want = 1;
   int m = nsub / want;
   if (m < 1) m = 1;
