@@ -55,31 +55,14 @@ struct GnArgs {
   const float* resid;   // backward apply: added to gx (skip-branch cotangent), may alias gx
 };
 
-// V double partials per thread (channels V*cv .. V*cv+V-1 of pixel lane pl; per-thread fp32 sums over one sub-chunk
-// are widened and from there on everything is added in double): LDS image [pl][C], then one thread per group sums its
-// channels over the pixel lanes and STORES the chunk's value in its slot.
-template <int V>
-__device__ __forceinline__ void gn_group_store_d(double* red, const double (&v)[V], bool live, int cv, int pl, int C, int PL,
-                                                 int G, int cpg, double* dst, int stride) {
-  if (live) {
-#pragma unroll
-    for (int k = 0; k < V; ++k) red[pl * C + V * cv + k] = v[k];
-  }
-  __syncthreads();
-  const int tid = threadIdx.x;
-  if (tid < G) {
-    double s = 0.0;
-    for (int p = 0; p < PL; ++p)
-      for (int cc = 0; cc < cpg; ++cc) s += red[p * C + tid * cpg + cc];
-    dst[(size_t)tid * stride] = s;
-  }
-  __syncthreads();
-}
-
+// Reduction tail of the reduce kernels: every thread holds V double partials per moment (channels V*cv .. V*cv+V-1 of pixel
+// lane pl; per-thread fp32 sums over one sub-chunk are widened and from there on everything is added in double).  ALL moments
+// go to LDS images [moment][pl][C] at once; after ONE barrier one thread per (moment, group) sums its channels over the pixel
+// lanes in a fixed order and STORES the chunk's value in its slot.
 template <bool VEC>
 __global__ void __launch_bounds__(256) k_gn_fwd_reduce(GnArgs A) {
   constexpr int V = VEC ? 4 : 1;
-  __shared__ double red[1024];
+  __shared__ double red[4 * 1024];       // all moments at once: ONE barrier in the tail instead of two per moment
   const int tid = threadIdx.x, b = blockIdx.x;
   const int C = A.C, P = A.P, G = A.G, cpg = C / G;
   const int CV = C / V, PL = 256 / CV;
@@ -126,11 +109,24 @@ __global__ void __launch_bounds__(256) k_gn_fwd_reduce(GnArgs A) {
     for (int k = 0; k < V; ++k) { d0[k] += (double)s0[k]; d1[k] += (double)s1[k]; d2[k] += (double)s2[k]; d3[k] += (double)s3[k]; }
    }
   double* dst = A.acc + ((size_t)b * GN_SLOTS + blockIdx.y) * G * 8;
-  gn_group_store_d<V>(red, d0, live, cv, pl, C, PL, G, cpg, dst + 0, 8);
-  gn_group_store_d<V>(red, d1, live, cv, pl, C, PL, G, cpg, dst + 1, 8);
-  if (A.dual) {
-    gn_group_store_d<V>(red, d2, live, cv, pl, C, PL, G, cpg, dst + 2, 8);
-    gn_group_store_d<V>(red, d3, live, cv, pl, C, PL, G, cpg, dst + 3, 8);
+  const int nm = A.dual ? 4 : 2;
+  if (live) {
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      const int e = pl * C + V * cv + k;
+      red[e] = d0[k]; red[1024 + e] = d1[k];
+      if (A.dual) { red[2048 + e] = d2[k]; red[3072 + e] = d3[k]; }
+    }
+  }
+  __syncthreads();
+  // one thread per (moment, group): the pixel lanes in order, the group's channels inside
+  for (int i = tid; i < nm * G; i += 256) {
+    const int m = i / G, g = i - m * G;
+    const double* r = red + m * 1024 + g * cpg;
+    double t = 0.0;
+    for (int p = 0; p < PL; ++p)
+      for (int cc = 0; cc < cpg; ++cc) t += r[p * C + cc];
+    dst[(size_t)g * 8 + m] = t;
   }
 }
 
@@ -266,8 +262,8 @@ __global__ void __launch_bounds__(256) k_gn_fwd_apply(GnArgs A, const float* __r
 template <bool VEC>
 __global__ void __launch_bounds__(256) k_gn_bwd_reduce(GnArgs A) {
   constexpr int V = VEC ? 4 : 1;
-  __shared__ double redd[1024];
-  float* red = reinterpret_cast<float*>(redd);
+  __shared__ double redd[5 * 1024];      // the five moments and (below) both parameter partials: ONE barrier in the tail
+  __shared__ float red[2 * 1024];
   const int tid = threadIdx.x, b = blockIdx.x;
   const int C = A.C, P = A.P, G = A.G, cpg = C / G;
   const int CV = C / V, PL = 256 / CV;
@@ -330,26 +326,32 @@ __global__ void __launch_bounds__(256) k_gn_bwd_reduce(GnArgs A) {
     }
    }
   double* dst = A.acc + ((size_t)b * GN_SLOTS + blockIdx.y) * G * 8;
-  gn_group_store_d<V>(redd, dX, live, cv, pl, C, PL, G, cpg, dst + 0, 8);
-  gn_group_store_d<V>(redd, dXx, live, cv, pl, C, PL, G, cpg, dst + 1, 8);
-  gn_group_store_d<V>(redd, dW, live, cv, pl, C, PL, G, cpg, dst + 2, 8);
-  gn_group_store_d<V>(redd, dWx, live, cv, pl, C, PL, G, cpg, dst + 3, 8);
-  gn_group_store_d<V>(redd, dWw, live, cv, pl, C, PL, G, cpg, dst + 4, 8);
-  // per-channel parameter gradients: sum the pixel lanes, one value per channel into this (sample, chunk)'s slot
   const size_t slot = (size_t)b * gridDim.y + blockIdx.y, nslots = (size_t)gridDim.x * gridDim.y;
   if (live) {
 #pragma unroll
-    for (int k = 0; k < V; ++k) red[pl * C + V * cv + k] = dga[k];
+    for (int k = 0; k < V; ++k) {
+      const int e = pl * C + V * cv + k;
+      redd[e] = dX[k]; redd[1024 + e] = dXx[k]; redd[2048 + e] = dW[k]; redd[3072 + e] = dWx[k]; redd[4096 + e] = dWw[k];
+      red[e] = dga[k]; red[1024 + e] = dbe[k];
+    }
   }
   __syncthreads();
-  if (tid < C) { float t = 0.f; for (int p = 0; p < PL; ++p) t += red[p * C + tid]; A.pslots[slot * C + tid] = t; }
-  __syncthreads();
-  if (live) {
-#pragma unroll
-    for (int k = 0; k < V; ++k) red[pl * C + V * cv + k] = dbe[k];
+  // one thread per (moment, group): the pixel lanes in order, the group's channels inside
+  for (int i = tid; i < 5 * G; i += 256) {
+    const int m = i / G, g = i - m * G;
+    const double* r = redd + m * 1024 + g * cpg;
+    double t = 0.0;
+    for (int p = 0; p < PL; ++p)
+      for (int cc = 0; cc < cpg; ++cc) t += r[p * C + cc];
+    dst[(size_t)g * 8 + m] = t;
   }
-  __syncthreads();
-  if (tid < C) { float t = 0.f; for (int p = 0; p < PL; ++p) t += red[p * C + tid]; A.pslots[(nslots + slot) * C + tid] = t; }
+  // per-channel parameter gradients: the pixel lanes in order, one value per channel into this (sample, chunk)'s slot
+  for (int i = tid; i < 2 * C; i += 256) {
+    const int which = i / C, c = i - which * C;
+    float t = 0.f;
+    for (int p = 0; p < PL; ++p) t += red[which * 1024 + p * C + c];
+    A.pslots[((size_t)which * nslots + slot) * C + c] = t;
+  }
 }
 
 // dgamma[c] += sum over the (sample, chunk) slots, dbeta alike (blockIdx.y = 0 / 1): 32 channels x 32 slot slices per
