@@ -370,6 +370,24 @@ int msgm_conv_wgrad_det(const msgm_conv_geom_t* geom, const float* gy, const flo
                         const uint16_t* tapmask_c32, const uint16_t* tapmask_co32, void* workspace, size_t workspace_bytes,
                         msgm_stream_t stream);
 
+/* Deferred form of msgm_conv_wgrad_det: launches the producing kernel(s) only and describes the slot reduction(s) it would
+ * have launched in jobs_out[0 .. *n_jobs_out) (host memory, room for 2) — the workspace must stay untouched until the
+ * caller has run them, all jobs of a backward pass in ONE launch, with msgm_slot_reduce_batched (the weight / bias
+ * gradients of a U-Net step are ~140 reductions of a few microseconds each).  The caller uploads the job table after
+ * filling block_begin with the running sum of ceil(n_elem / 32) + ceil(n_elem2 / 32); total_blocks = that sum. */
+typedef struct {
+  const float* part;      /* [nslots][stride] partials */
+  float* out;             /* weight image (Ktot > 0: element e = (row)*C + c goes to row*Ktot + koff + c) or plain vector */
+  float* out2;            /* optional second range [n_elem, n_elem + n_elem2) of the same slots, identity-mapped (bias) */
+  int64_t stride, n_elem, n_elem2, block_begin;
+  int32_t nslots, C, Ktot, koff, rowsP, rows, accumulate, reserved;
+} msgm_reduce_job_t;
+int msgm_conv_wgrad_slabs(const msgm_conv_geom_t* geom, const float* gy, const float* src, int32_t C, int32_t koff,
+                          float* dWp, int32_t Cout, int32_t CoutP, int32_t Ktot, float* dbias, int32_t n_bias,
+                          const uint16_t* tapmask_c32, const uint16_t* tapmask_co32, void* workspace, size_t workspace_bytes,
+                          msgm_reduce_job_t* jobs_out, int32_t* n_jobs_out, msgm_stream_t stream);
+int msgm_slot_reduce_batched(const msgm_reduce_job_t* jobs_dev, int32_t n_jobs, int64_t total_blocks, msgm_stream_t stream);
+
 /* Wp[t][r][kp_off + c] = W[r*sr + (col_off + c)*sc + t*st] for r < rows, c < ncols
  * (strides in elements: any of the PyTorch layouts (Cout,Cin,k), (Cin,Cout,k) and
  * their transposes for dgrad); msgm_unpack_weight is the inverse for gradients. */

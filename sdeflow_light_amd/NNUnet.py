@@ -542,7 +542,8 @@ class VorticityUNet(nn.Module, FlatParamMixin):
         a_flat = ops.image_to_flat(out, N, Cc, S_, S_, forder, float(scale_image))      # [2B][d]: a | adot
         per, g = ops.ssm_loss(a_flat.view(-1), u, cst, inv_batch)
         gimg = ops.flat_to_image(g.view(N, d), N, Cc, S_, S_, forder, float(scale_image))   # adjoint of (x5, unflatten)
-        self._backward(tape, gimg, N, B)
+        with ops.DeferredReduces.on(y.device):           # the ~140 slot reductions of the weight / bias gradients: one launch
+            self._backward(tape, gimg, N, B)
         x["set"].unpack_grads()
         if x["set2t"] is not None and any(rec[0] == "res2" for rec in tape):
             x["set2t"].unpack_grads()            # after "set": the twins' images replace the (unused, zero) single-source ones

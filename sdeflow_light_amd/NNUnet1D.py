@@ -201,7 +201,8 @@ class UNet1D(nn.Module, FlatParamMixin):
         h0 = torch.cat([y.contiguous().float(), v.contiguous().float()], 0).reshape(-1)
         out = self._run(h0, t.reshape(-1).contiguous().float(), N, B, L, True, tape)
         per, g = ops.ssm_loss(out, u, cst, inv_batch)
-        self._backward(tape, g, N, B)
+        with ops.DeferredReduces.on(y.device):           # all slot reductions of the weight / bias gradients in one launch
+            self._backward(tape, g, N, B)
         self._opset.unpack_grads()
         return per
 

@@ -37,6 +37,13 @@ class ConvFuseT(C.Structure):
                 ("chanstats", C.c_void_p)]
 
 
+class ReduceJobT(C.Structure):
+    """msgm_reduce_job_t (include/msgm_hip.h)."""
+    _fields_ = [("part", C.c_void_p), ("out", C.c_void_p), ("out2", C.c_void_p), ("stride", C.c_int64), ("n_elem", C.c_int64),
+                ("n_elem2", C.c_int64), ("block_begin", C.c_int64), ("nslots", C.c_int32), ("C", C.c_int32), ("Ktot", C.c_int32),
+                ("koff", C.c_int32), ("rowsP", C.c_int32), ("rows", C.c_int32), ("accumulate", C.c_int32), ("reserved", C.c_int32)]
+
+
 class PackJobT(C.Structure):
     """msgm_pack_job_t (include/msgm_hip.h)."""
     _fields_ = [("W", C.c_void_p), ("Wp", C.c_void_p), ("sr", C.c_int64), ("sc", C.c_int64), ("st", C.c_int64),
@@ -88,6 +95,9 @@ SIGNATURES = {
     "msgm_conv_input_transform_supported": (C.c_int, [C.POINTER(ConvGeomT), _I32, _I32, _I32]),
     "msgm_groupnorm_affine": (C.c_int, [_P, _I32, _P, _I32, _P, _P, _P, _P, _I32, _I32, _I32, _F, _P, C.c_size_t, _P]),
     "msgm_conv_chanstats_slots": (C.c_int32, [C.POINTER(ConvGeomT), _I32, _I32, _I32, _I32]),
+    "msgm_conv_wgrad_slabs": (C.c_int, [C.POINTER(ConvGeomT), _P, _P, _I32, _I32, _P, _I32, _I32, _I32, _P, _I32, _P, _P, _P, _SZ,
+                                        C.POINTER(ReduceJobT), C.POINTER(C.c_int32), _P]),
+    "msgm_slot_reduce_batched": (C.c_int, [_P, _I32, _I64, _P]),
     "msgm_conv_small_cout_supported": (C.c_int, [C.POINTER(ConvGeomT), _I32, _I32, _I32]),
     "msgm_groupnorm_affine_chanstats": (C.c_int, [_P, _I32, _I32, _P, _I32, _I32, _P, _P, _P, _P, _I32, _I32, _I32, _F, _P]),
     "msgm_conv_wgrad": (C.c_int, [C.POINTER(ConvGeomT), _P, _P, _I32, _I32, _P, _I32, _I32, _I32, _P, _I32,

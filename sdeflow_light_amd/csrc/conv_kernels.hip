@@ -1567,14 +1567,14 @@ __global__ void k_act_dual_bwd(const float* __restrict__ z, float* __restrict__ 
 // dWp[(tap*CoutP + co)*Ktot + koff + c] when Ktot > 0, identity otherwise.
 // A second, identity-mapped element range [n_elem, n_elem + n_elem2) of the same slots (the bias gradient that the tiled
 // wgrad leaves behind its weight image) is reduced into out2 by the trailing workgroups of the SAME launch.
-__global__ void __launch_bounds__(256) k_slot_reduce(const float* __restrict__ part, int nslots, long stride, long n_elem,
-                                                      float* __restrict__ out, int C, int Ktot, int koff, int accumulate,
-                                                      int rowsP, int rows, long n_elem2, float* __restrict__ out2) {
+__device__ __forceinline__ void slot_reduce_block(long blk, const float* __restrict__ part, int nslots, long stride, long n_elem,
+                                                  float* __restrict__ out, int C, int Ktot, int koff, int accumulate,
+                                                  int rowsP, int rows, long n_elem2, float* __restrict__ out2) {
   __shared__ float red[8][32];
   const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const long nb1 = (n_elem + 31) / 32;
-  if ((long)blockIdx.x >= nb1) {                       // workgroup-uniform
-    const long e2 = ((long)blockIdx.x - nb1) * 32 + el;
+  if (blk >= nb1) {                                    // workgroup-uniform
+    const long e2 = (blk - nb1) * 32 + el;
     const bool ok2 = e2 < n_elem2;
     float t2 = 0.f;
     if (ok2)
@@ -1589,7 +1589,7 @@ __global__ void __launch_bounds__(256) k_slot_reduce(const float* __restrict__ p
     }
     return;
   }
-  const long e = (long)blockIdx.x * 32 + el;
+  const long e = blk * 32 + el;
   // padding rows (co >= Cout of a [taps][CoutP][C] image) are never written by the producers
   const bool ok = e < n_elem && (rowsP == 0 || (int)((e / C) % rowsP) < rows);
   float t = 0.f;
@@ -1604,6 +1604,25 @@ __global__ void __launch_bounds__(256) k_slot_reduce(const float* __restrict__ p
     const long o = Ktot > 0 ? (e / C) * Ktot + koff + (e % C) : e;
     out[o] = accumulate ? out[o] + r : r;
   }
+}
+__global__ void __launch_bounds__(256) k_slot_reduce(const float* __restrict__ part, int nslots, long stride, long n_elem,
+                                                      float* __restrict__ out, int C, int Ktot, int koff, int accumulate,
+                                                      int rowsP, int rows, long n_elem2, float* __restrict__ out2) {
+  slot_reduce_block((long)blockIdx.x, part, nslots, stride, n_elem, out, C, Ktot, koff, accumulate, rowsP, rows, n_elem2, out2);
+}
+// Many slot reductions in ONE launch (the weight / bias gradients of a whole backward pass: ~140 launches of a few
+// microseconds each otherwise): the jobs sit in a device table with the first workgroup of each; a workgroup finds its
+// job by bisection.  Same arithmetic, same order as k_slot_reduce.
+__global__ void __launch_bounds__(256) k_slot_reduce_batched(const msgm_reduce_job_t* __restrict__ jobs, int n_jobs) {
+  int lo = 0, hi = n_jobs - 1;
+  const long blk = blockIdx.x;
+  while (lo < hi) {                                    // last job whose block_begin <= blk
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].block_begin <= blk) lo = mid; else hi = mid - 1;
+  }
+  const msgm_reduce_job_t J = jobs[lo];
+  slot_reduce_block(blk - J.block_begin, J.part, J.nslots, (long)J.stride, (long)J.n_elem, J.out, J.C, J.Ktot, J.koff, J.accumulate,
+                    J.rowsP, J.rows, (long)J.n_elem2, J.out2);
 }
 
 __global__ void __launch_bounds__(256) k_colsum(const float* __restrict__ x, float* __restrict__ S, int P, int C, int chunk, int acc) {
@@ -2020,7 +2039,7 @@ static WgradPlan wgrad_plan(const msgm_conv_geom_t* geom, int C, int Cout, int n
 static int wgrad_impl(const msgm_conv_geom_t* geom, const float* gy, const float* src, int32_t C, int32_t koff,
                       float* dWp, int32_t Cout, int32_t CoutP, int32_t Ktot, float* dbias, int32_t n_bias,
                       const uint16_t* tapmask_c32, const uint16_t* tapmask_co32, float* ws, size_t ws_bytes, bool det,
-                      msgm_stream_t stream);
+                      msgm_stream_t stream, msgm_reduce_job_t* jobs_out = nullptr, int32_t* n_jobs_out = nullptr);
 
 size_t msgm_conv_wgrad_workspace(const msgm_conv_geom_t* geom, int32_t C, int32_t Cout, int32_t CoutP, int32_t n_bias) {
   if (check_geom(geom) || C <= 0 || Cout <= 0 || CoutP < Cout) return 0;
@@ -2046,10 +2065,26 @@ int msgm_conv_wgrad_det(const msgm_conv_geom_t* geom, const float* gy, const flo
                     static_cast<float*>(workspace), workspace_bytes, true, stream);
 }
 
+int msgm_conv_wgrad_slabs(const msgm_conv_geom_t* geom, const float* gy, const float* src, int32_t C, int32_t koff,
+                          float* dWp, int32_t Cout, int32_t CoutP, int32_t Ktot, float* dbias, int32_t n_bias,
+                          const uint16_t* tapmask_c32, const uint16_t* tapmask_co32, void* workspace, size_t workspace_bytes,
+                          msgm_reduce_job_t* jobs_out, int32_t* n_jobs_out, msgm_stream_t stream) {
+  if (!workspace || !jobs_out || !n_jobs_out) return MSGM_E_BADARG;
+  *n_jobs_out = 0;
+  return wgrad_impl(geom, gy, src, C, koff, dWp, Cout, CoutP, Ktot, dbias, n_bias, tapmask_c32, tapmask_co32,
+                    static_cast<float*>(workspace), workspace_bytes, true, stream, jobs_out, n_jobs_out);
+}
+
+int msgm_slot_reduce_batched(const msgm_reduce_job_t* jobs_dev, int32_t n_jobs, int64_t total_blocks, msgm_stream_t stream) {
+  if (!jobs_dev || n_jobs <= 0 || total_blocks <= 0 || total_blocks > 0x7fffffffLL) return MSGM_E_BADARG;
+  hipLaunchKernelGGL(k_slot_reduce_batched, dim3((unsigned)total_blocks), dim3(256), 0, S(stream), jobs_dev, n_jobs);
+  return msgm_check_launch();
+}
+
 static int wgrad_impl(const msgm_conv_geom_t* geom, const float* gy, const float* src, int32_t C, int32_t koff,
                       float* dWp, int32_t Cout, int32_t CoutP, int32_t Ktot, float* dbias, int32_t n_bias,
                       const uint16_t* tapmask_c32, const uint16_t* tapmask_co32, float* ws, size_t ws_bytes, bool det,
-                      msgm_stream_t stream) {
+                      msgm_stream_t stream, msgm_reduce_job_t* jobs_out, int32_t* n_jobs_out) {
   int rc = check_geom(geom);
   if (rc) return rc;
   if (!gy || !src || !dWp || C <= 0 || Cout <= 0 || koff < 0 || koff + C > Ktot || (dbias && n_bias <= 0)) return MSGM_E_BADARG;
@@ -2064,6 +2099,12 @@ static int wgrad_impl(const msgm_conv_geom_t* geom, const float* gy, const float
   }
   const int taps = geom->KH * geom->KW;
   auto reduce_slabs = [&](int nslots, bool with_bias) {     // deterministic mode: slabs -> dWp (+ dbias), slot order
+    if (jobs_out) {                                          // deferred: the caller batches the reductions of a whole pass
+      msgm_reduce_job_t& J = jobs_out[(*n_jobs_out)++];
+      J = msgm_reduce_job_t{ws, dWp, with_bias ? dbias : nullptr, (int64_t)A.slab_stride, (int64_t)img, with_bias ? (int64_t)Cout : 0, 0,
+                            nslots, C, Ktot, koff, CoutP, Cout, 1, 0};
+      return;
+    }
     const long nb = (img + 31) / 32 + (with_bias ? (Cout + 31) / 32 : 0);
     hipLaunchKernelGGL(k_slot_reduce, dim3((unsigned)nb), dim3(256), 0, S(stream), (const float*)ws, nslots, A.slab_stride, img,
                        dWp, C, Ktot, koff, 1, CoutP, Cout, with_bias ? (long)Cout : 0L, dbias);
@@ -2110,6 +2151,10 @@ static int wgrad_impl(const msgm_conv_geom_t* geom, const float* gy, const float
     if (det) {
       float* part = ws + (size_t)nchunks * A.slab_stride;   // [bias_slots][Cout] partials, then slot-ordered sum
       hipLaunchKernelGGL(k_colsum, dim3(1, (unsigned)pl.bias_slots), dim3(256), 0, S(stream), gy, part, (int)Pb, Cout, (int)pl.bias_chunk, 2);
+      if (jobs_out) {
+        msgm_reduce_job_t& J = jobs_out[(*n_jobs_out)++];
+        J = msgm_reduce_job_t{part, dbias, nullptr, (int64_t)Cout, (int64_t)Cout, 0, 0, (int32_t)pl.bias_slots, 1, 0, 0, 0, 0, 1, 0};
+      } else
       hipLaunchKernelGGL(k_slot_reduce, dim3((unsigned)((Cout + 31) / 32)), dim3(256), 0, S(stream), (const float*)part,
                          (int)pl.bias_slots, (long)Cout, (long)Cout, dbias, 1, 0, 0, 1, 0, 0, 0L, (float*)nullptr);
     } else {

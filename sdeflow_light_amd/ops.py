@@ -6,6 +6,7 @@ GPU for everyone), passes raw device pointers through ctypes, and raises
 """
 from __future__ import annotations
 
+import ctypes as C_
 import math
 from typing import Optional
 
@@ -418,9 +419,101 @@ def conv_wgrad(geom: L.ConvGeomT, gy: torch.Tensor, src: torch.Tensor, C: int, k
         return
     # default: deterministic — per-workgroup slabs added in slot order (no float atomics; same bits every run)
     need = int(lib().msgm_conv_wgrad_workspace(geom, C, Cout, CoutP, int(n_bias) if dbias is not None else 0))
+    d = DeferredReduces.active
+    if d is not None and d.device == gy.device:
+        # inside a backward pass that batches its slot reductions: slabs go to the pass's arena, the reduction is described
+        # to the pass and runs with all the others in one launch (DeferredReduces.flush)
+        ws, nbytes = d.take(need)
+        jobs, nj = (L.ReduceJobT * 2)(), C_.c_int32(0)
+        check(lib().msgm_conv_wgrad_slabs(geom, ptr(f32(gy)), ptr(f32(src)), C, koff, ptr(f32(dWp)), Cout, CoutP, Ktot,
+                                          ptr(dbias), int(n_bias), mc, mo, ws, nbytes, jobs, C_.byref(nj), stream()),
+              "msgm_conv_wgrad_slabs")
+        d.add(jobs, nj.value, (dWp, dbias))
+        return
     ws = scratch(gy.device, need, "wgrad")
     check(lib().msgm_conv_wgrad_det(geom, ptr(f32(gy)), ptr(f32(src)), C, koff, ptr(f32(dWp)), Cout, CoutP, Ktot,
                                     ptr(dbias), int(n_bias), mc, mo, ptr(ws), ws.numel() * 4, stream()), "msgm_conv_wgrad_det")
+
+
+class DeferredReduces:
+    """One backward pass's slot reductions (deterministic weight / bias gradients) batched into ONE launch.
+    ``with DeferredReduces.on(device): ... backward ...`` makes every conv_wgrad inside write its per-workgroup slabs into a
+    bump arena that lives until the end of the pass and register its reduction; leaving the block uploads the job table
+    (only when it differs from the cached one: the arena hands out the same addresses every step, so under a captured
+    hipGraph nothing is uploaded) and runs msgm_slot_reduce_batched.  Same arithmetic and order as the per-call form."""
+    active = None
+    _cache = {}                      # device -> DeferredReduces (arena chunks and the device job table persist)
+    CHUNK = 256 << 20
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.chunks, self.jobs, self.keep = [], [], []
+        self.table = None            # (bytes, device tensor)
+        self.reset()
+
+    @classmethod
+    def on(cls, device):
+        device = torch.device(device)
+        if device.index is None and device.type == "cuda":
+            device = torch.device("cuda", torch.cuda.current_device())
+        d = cls._cache.get(device)
+        if d is None:
+            d = cls._cache[device] = cls(device)
+        return d
+
+    def reset(self):
+        self.ci, self.off, self.jobs, self.keep = 0, 0, [], []
+
+    def take(self, nbytes: int):
+        nbytes = (int(nbytes) + 255) & ~255
+        while True:
+            if self.ci < len(self.chunks) and self.off + nbytes <= self.chunks[self.ci].numel() * 4:
+                p = self.chunks[self.ci].data_ptr() + self.off
+                self.off += nbytes
+                return p, nbytes
+            if self.ci < len(self.chunks):
+                self.ci, self.off = self.ci + 1, 0
+                continue
+            if torch.cuda.is_current_stream_capturing():
+                raise MsgmError("the slab arena must reach its size in an eager step before graph capture")
+            self.chunks.append(torch.empty(max(self.CHUNK, nbytes) // 4, dtype=torch.float32, device=self.device))
+
+    def add(self, jobs, n, keep):
+        for i in range(n):
+            self.jobs.append(L.ReduceJobT.from_buffer_copy(jobs[i]))
+        self.keep.append(keep)
+
+    def __enter__(self):
+        if DeferredReduces.active is not None:
+            raise MsgmError("DeferredReduces does not nest")
+        self.reset()
+        DeferredReduces.active = self
+        return self
+
+    def __exit__(self, et, ev, tb):
+        DeferredReduces.active = None
+        if et is None:
+            self.flush()
+        self.jobs, self.keep = [], []
+        return False
+
+    def flush(self):
+        n = len(self.jobs)
+        if n == 0:
+            return
+        arr = (L.ReduceJobT * n)()
+        blk = 0
+        for i, j in enumerate(self.jobs):
+            arr[i] = j
+            arr[i].block_begin = blk
+            blk += (j.n_elem + 31) // 32 + (j.n_elem2 + 31) // 32
+        raw = bytes(arr)
+        if self.table is None or self.table[0] != raw:
+            if torch.cuda.is_current_stream_capturing():
+                raise MsgmError("the reduction job table changed inside a graph capture (run one eager step first)")
+            host = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+            self.table = (raw, host.to(self.device))
+        check(lib().msgm_slot_reduce_batched(ptr(self.table[1]), n, blk, stream()), "msgm_slot_reduce_batched")
 
 
 def pack_weight(W: torch.Tensor, w_off: int, Wp: torch.Tensor, rows, ncols, col_off, taps, sr, sc, st, rowsP, Ktot, kp_off):
