@@ -2006,7 +2006,8 @@ static WgradPlan wgrad_plan(const msgm_conv_geom_t* geom, int C, int Cout, int n
     p.tiles_x = (geom->Wo + TW - 1) / TW; p.tiles_y = (geom->Ho + TH - 1) / TH;
     p.n_tiles = p.tiles_x * p.tiles_y * geom->N;
     p.yblocks = ((Cout + 31) / 32) * ((C + 31) / 32);
-    int wgs = 1024 / p.yblocks;                            // ~4 workgroups per CU overall
+    static const int wg_target = getenv("MSGM_WGRAD_WGS") ? atoi(getenv("MSGM_WGRAD_WGS")) : 1024;   // measured 512 / 768 / 1536: 127.2 / 131.3 / 128.7 vs 127.6 ms per C4 step
+    int wgs = wg_target / p.yblocks;                       // ~4 workgroups per CU overall
     if (wgs < 1) wgs = 1;
     int per = (p.n_tiles + wgs - 1) / wgs;
     static const int min_per = getenv("MSGM_WGRAD_PER") ? atoi(getenv("MSGM_WGRAD_PER")) : 8;   // >= 8 tiles per workgroup amortise the cross-wave sum + atomics
