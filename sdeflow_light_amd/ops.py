@@ -448,7 +448,7 @@ class DeferredReduces:
     def __init__(self, device):
         self.device = torch.device(device)
         self.chunks, self.jobs, self.keep = [], [], []
-        self.table = None            # (bytes, device tensor)
+        self.tables = {}             # job table bytes -> device copy
         self.reset()
 
     @classmethod
@@ -508,12 +508,13 @@ class DeferredReduces:
             arr[i].block_begin = blk
             blk += (j.n_elem + 31) // 32 + (j.n_elem2 + 31) // 32
         raw = bytes(arr)
-        if self.table is None or self.table[0] != raw:
+        tab = self.tables.get(raw)
+        if tab is None:
+            # every table ever uploaded stays alive: a captured hipGraph keeps the address of the one it was captured with
             if torch.cuda.is_current_stream_capturing():
                 raise MsgmError("the reduction job table changed inside a graph capture (run one eager step first)")
-            host = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
-            self.table = (raw, host.to(self.device))
-        check(lib().msgm_slot_reduce_batched(ptr(self.table[1]), n, blk, stream()), "msgm_slot_reduce_batched")
+            tab = self.tables[raw] = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+        check(lib().msgm_slot_reduce_batched(ptr(tab), n, blk, stream()), "msgm_slot_reduce_batched")
 
 
 def pack_weight(W: torch.Tensor, w_off: int, Wp: torch.Tensor, rows, ncols, col_off, taps, sr, sc, st, rowsP, Ktot, kp_off):
