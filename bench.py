@@ -118,6 +118,9 @@ def time_kernel_events(fn, iters, dev):
 def free_gpu():
     import gc
     import torch
+    from sdeflow_light_amd import ops
+    gc.collect()                       # drops the finished leg's trainers / graphs (they hold the arena's addresses)
+    ops.DeferredReduces.release()      # then the slab arena of the deterministic weight gradients
     gc.collect()
     torch.cuda.empty_cache()
 

@@ -223,8 +223,12 @@ class PhiloxState:
         return self.state.data_ptr()
 
     def set_shard(self, row_base: int, n: int) -> None:
-        if (row_base * n) % 4:
-            raise MsgmError("shard base: row_base * n must be a multiple of 4 (Philox draws are addressed by quads)")
+        # k_fill / the prep kernels address draws by QUADS of the global index: row-indexed streams (t, the latent rows)
+        # by row quads, element-indexed ones by element quads.  A base that is not a multiple of 4 would be truncated
+        # and this shard would re-draw the previous rank's numbers.
+        if row_base % 4 or (row_base * n) % 4:
+            raise MsgmError("shard base: row_base (and row_base * n) must be multiples of 4 — Philox draws are addressed "
+                            "by quads of the GLOBAL row / element index")
         self.state[2:].copy_(torch.tensor([row_base, row_base * n], dtype=torch.int64))
 
     def advance(self, n: int = 1) -> None:
@@ -235,5 +239,7 @@ class PhiloxState:
         return {"seed": seed, "offset": offset, "row_base": row_base, "elem_base": elem_base}
 
     def load_state_dict(self, sd: dict) -> None:
-        self.state.copy_(torch.tensor([sd["seed"], sd["offset"], sd.get("row_base", 0), sd.get("elem_base", 0)],
-                                      dtype=torch.int64))
+        """Restores the STREAM position (seed, offset) only.  The shard base {row_base, elem_base} belongs to the rank
+        that loads, not to the rank that wrote the file: in a data-parallel resume every rank loads rank 0's checkpoint
+        and must keep drawing the numbers of ITS rows (set_shard), otherwise all ranks would replay rank 0's noise."""
+        self.state[:2].copy_(torch.tensor([sd["seed"], sd["offset"]], dtype=torch.int64))

@@ -2006,12 +2006,13 @@ static WgradPlan wgrad_plan(const msgm_conv_geom_t* geom, int C, int Cout, int n
     p.tiles_x = (geom->Wo + TW - 1) / TW; p.tiles_y = (geom->Ho + TH - 1) / TH;
     p.n_tiles = p.tiles_x * p.tiles_y * geom->N;
     p.yblocks = ((Cout + 31) / 32) * ((C + 31) / 32);
-    static const int wg_target = getenv("MSGM_WGRAD_WGS") ? atoi(getenv("MSGM_WGRAD_WGS")) : 1024;   // measured 512 / 768 / 1536: 127.2 / 131.3 / 128.7 vs 127.6 ms per C4 step
+    static const int wg_target = getenv("MSGM_WGRAD_WGS") ? (atoi(getenv("MSGM_WGRAD_WGS")) > 0 ? atoi(getenv("MSGM_WGRAD_WGS")) : 1) : 1024;   // measured 512 / 768 / 1536: 127.2 / 131.3 / 128.7 vs 127.6 ms per C4 step
     int wgs = wg_target / p.yblocks;                       // ~4 workgroups per CU overall
     if (wgs < 1) wgs = 1;
     int per = (p.n_tiles + wgs - 1) / wgs;
-    static const int min_per = getenv("MSGM_WGRAD_PER") ? atoi(getenv("MSGM_WGRAD_PER")) : 8;   // >= 8 tiles per workgroup amortise the cross-wave sum + atomics
+    static const int min_per = getenv("MSGM_WGRAD_PER") ? (atoi(getenv("MSGM_WGRAD_PER")) > 0 ? atoi(getenv("MSGM_WGRAD_PER")) : 1) : 8;   // >= 8 tiles per workgroup amortise the cross-wave sum + atomics
     if (per < min_per) per = p.n_tiles < min_per ? p.n_tiles : min_per;
+    if (per < 1) per = 1;
     p.per = per;
     p.wgs = (p.n_tiles + per - 1) / per;
     return p;

@@ -443,7 +443,7 @@ class DeferredReduces:
     hipGraph nothing is uploaded) and runs msgm_slot_reduce_batched.  Same arithmetic and order as the per-call form."""
     active = None
     _cache = {}                      # device -> DeferredReduces (arena chunks and the device job table persist)
-    CHUNK = 256 << 20
+    CHUNK = 16 << 20                 # arena granule: chunks are sized from what the pass asks for, rounded up to this
 
     def __init__(self, device):
         self.device = torch.device(device)
@@ -476,7 +476,26 @@ class DeferredReduces:
                 continue
             if torch.cuda.is_current_stream_capturing():
                 raise MsgmError("the slab arena must reach its size in an eager step before graph capture")
-            self.chunks.append(torch.empty(max(self.CHUNK, nbytes) // 4, dtype=torch.float32, device=self.device))
+            # grow geometrically from the measured need (a tiny UNet1D / smoke run keeps 16 MB, the C4 backward ends
+            # near its real footprint) instead of pinning 256 MB per device for every pass
+            have = sum(c.numel() * 4 for c in self.chunks)
+            want = max(nbytes, have // 2, self.CHUNK)
+            want = (want + self.CHUNK - 1) // self.CHUNK * self.CHUNK
+            self.chunks.append(torch.empty(want // 4, dtype=torch.float32, device=self.device))
+
+    @classmethod
+    def release(cls, device=None):
+        """Drop the arena(s) and job tables (bench legs / tests that want the memory back).  Any hipGraph captured with
+        the old arena must be dropped first: it holds the addresses."""
+        if cls.active is not None:
+            raise MsgmError("DeferredReduces.release inside a pass")
+        if device is None:
+            cls._cache.clear()
+        else:
+            device = torch.device(device)
+            if device.index is None and device.type == "cuda":
+                device = torch.device("cuda", torch.cuda.current_device())
+            cls._cache.pop(device, None)
 
     def add(self, jobs, n, keep):
         for i in range(n):

@@ -23,32 +23,58 @@ from ._lib import MsgmError
 
 
 class _TrainerState:
-    """Checkpoint surface shared by the trainers (Adam layout of torch.optim.Adam + the device Philox state)."""
+    """Checkpoint surface shared by the trainers (Adam layout of torch.optim.Adam + the device Philox state).
+
+    The reference builds its optimizer over ``gen_sde.parameters()`` (MSGM_higherDim.py:792,899-900): index 0 of that
+    list is the non-trainable horizon ``T`` (an nn.Parameter(requires_grad=False), MSGM_higherDim.py:728), the score
+    net's tensors follow.  The trainers write / read their Adam state under THOSE indices (``T`` gets a slot in
+    ``param_groups[0]['params']`` and no state, exactly as torch.optim.Adam leaves it), so a trainer checkpoint loads
+    into ``torch.optim.Adam(gen_sde.parameters())`` / ``FusedAdam`` and vice versa."""
+
+    def _param_index(self):
+        """(all parameters of gen_sde in optimizer order, [(index, flat offset, parameter)] of the net's tensors)."""
+        offs, off = {}, 0
+        for p in self.net.parameters():
+            offs[id(p)] = off
+            off += p.numel()
+        allp = list(self.gen_sde.parameters())
+        mine = [(i, offs[id(p)], p) for i, p in enumerate(allp) if id(p) in offs]
+        if len(mine) != len(offs):
+            raise MsgmError("the score net's parameters are not all reachable from gen_sde.parameters()")
+        return allp, mine
 
     def state_dict(self) -> dict:
         step = float(self.step_dev.item())
-        st, off = {}, 0
-        for i, p in enumerate(self.net.parameters()):
-            k = p.numel()
-            st[i] = {"step": torch.tensor(step), "exp_avg": self.m[off:off + k].view(p.shape).clone(),
-                     "exp_avg_sq": self.v[off:off + k].view(p.shape).clone()}
-            off += k
+        allp, mine = self._param_index()
+        st = {}
+        if step > 0:                              # a never-stepped torch.optim.Adam has an empty state too
+            for i, off, p in mine:
+                k = p.numel()
+                st[i] = {"step": torch.tensor(step), "exp_avg": self.m[off:off + k].view(p.shape).clone(),
+                         "exp_avg_sq": self.v[off:off + k].view(p.shape).clone()}
         group = {"lr": self.lr, "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0, "amsgrad": False,
                  "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
-                 "params": list(range(len(st)))}
+                 "decoupled_weight_decay": False, "params": list(range(len(allp)))}
         return {"state": st, "param_groups": [group], "philox": self.rng.state_dict()}
 
     def load_state_dict(self, sd: dict) -> None:
-        off, step = 0, 0
-        for i, p in enumerate(self.net.parameters()):
+        allp, mine = self._param_index()
+        saved = sd["param_groups"][0]["params"] if sd.get("param_groups") else list(range(len(allp)))
+        if len(saved) == len(allp):
+            shift = 0
+        elif len(saved) == len(mine):             # written by a round-2 trainer: net tensors only, indexed from 0
+            shift = mine[0][0]
+        else:
+            raise MsgmError(f"optimizer state has {len(saved)} parameters; gen_sde.parameters() has {len(allp)}")
+        step = 0
+        for i, off, p in mine:
             k = p.numel()
-            e = sd["state"].get(i)
+            e = sd["state"].get(i - shift)
             if e is None:                       # never-stepped checkpoint: empty Adam state
                 self.m[off:off + k].zero_(); self.v[off:off + k].zero_()
             else:
                 self.m[off:off + k].copy_(e["exp_avg"].reshape(-1)); self.v[off:off + k].copy_(e["exp_avg_sq"].reshape(-1))
                 step = int(float(e["step"]))
-            off += k
         self.step_dev.fill_(step)
         if sd.get("param_groups"):
             lr = float(sd["param_groups"][0]["lr"])
@@ -56,7 +82,7 @@ class _TrainerState:
                 raise MsgmError("the captured step has the learning rate baked in; build a new trainer for another lr")
             self.lr = lr
         if "philox" in sd:                      # absent in checkpoints written by torch.optim.Adam: keep the stream
-            self.rng.load_state_dict(sd["philox"])
+            self.rng.load_state_dict(sd["philox"])      # stream position only; the shard base stays this rank's
 
 
 class MLPScoreTrainer(_TrainerState):
@@ -220,12 +246,14 @@ class UNetScoreTrainer(_TrainerState):
         torch.cuda.current_stream(self.dev).wait_stream(side)
         self._collective_update()
         torch.cuda.synchronize(self.dev)
-        self.graph = ops.new_graph()
+        self._eager_step_done = True
+        graph = ops.new_graph()
         mode = "global" if not parallel.multi(self.world) else "thread_local"      # a collective backend's watchdog thread must not
-        with torch.cuda.graph(self.graph, capture_error_mode=mode):  # invalidate the capture
+        with torch.cuda.graph(graph, capture_error_mode=mode):       # invalidate the capture
             self._fwd_bwd()
             if not parallel.multi(self.world):
                 self._update()
+        self.graph = graph
 
     def step(self):
         if not self.use_graph:
@@ -233,7 +261,18 @@ class UNetScoreTrainer(_TrainerState):
             self._collective_update()
             return self.loss
         if self.graph is None:
-            self.capture()                           # performs this call's step eagerly
+            try:
+                self.capture()                       # performs this call's step eagerly
+            except Exception as e:                   # noqa: BLE001
+                # capture() runs the eager step FIRST, so this call's update is already done when the capture itself
+                # fails.  With N ranks a failed capture next to a live RCCL communicator must not take the job down:
+                # log it and stay on the eager path in the same process (N > 1 RCCL capture is unverified on hardware).
+                if not parallel.multi(self.world) or not getattr(self, "_eager_step_done", False):
+                    raise
+                import sys
+                print(f"[msgm] hipGraph capture of the train step failed with {self.world} ranks ({type(e).__name__}: {e}); "
+                      "continuing eagerly", file=sys.stderr)
+                self.graph, self.use_graph = None, False
             return self.loss
         self.graph.replay()
         if parallel.multi(self.world):

@@ -209,3 +209,69 @@ def test_multi_rank_code_path_on_a_real_rccl_communicator():
     # the forced run's graph ends before the collective: it lacks the Adam / Philox-advance nodes of the one-rank graph
     assert set(k0) == set(k1) == {"kernel"} and k1["kernel"] < k0["kernel"]
     print(f"one rank through RCCL == plain run bit for bit; graph nodes {k0['kernel']} (whole step) vs {k1['kernel']} (up to the collective)")
+
+
+def _resume_worker(rank, world, port, path, q):
+    """a data-parallel resume.  Both ranks train 2 steps with shard placement, rank 0 writes ONE
+    checkpoint, BOTH ranks load it into fresh trainers (each with its own row_base) and train 2 more steps.  The result
+    must equal the uninterrupted 4-step run bit for bit — which it cannot if the loader takes rank 0's shard base."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), MSGM_DIST_BACKEND="gloo")
+    import torch.distributed as dist
+    from sdeflow_light_amd import parallel
+    from sdeflow_light_amd.NN import MLP, save_checkpoint, load_checkpoint
+    from sdeflow_light_amd.SDEs import SGMsde, PluginReverseSDE
+    from sdeflow_light_amd.train import MLPScoreTrainer
+    r, local, w = parallel.init_distributed()
+    dev = parallel.local_device(local)
+    torch.cuda.set_device(dev)
+    rows, d = 512, 2
+    b, e = parallel.shard_rows(rows, r, w)
+    torch.manual_seed(5)
+    data = torch.randn(rows, d, device=dev)
+
+    def fresh():
+        torch.manual_seed(0)
+        T = torch.nn.Parameter(torch.FloatTensor([1.0]), requires_grad=False)
+        gen = PluginReverseSDE(SGMsde(T=T, num_steps_forward=16, device=dev), MLP(2).to(dev), T, deviceReverseSDE=dev).to(dev)
+        tr = MLPScoreTrainer(gen, e - b, lr=1e-3, world=w, seed=9, row_base=b, use_graph=False)
+        tr.set_data(data[b:e])
+        return gen, tr
+    gen, tr = fresh()                                     # uninterrupted: 4 steps
+    for _ in range(4):
+        tr.step()
+    want = gen.a.flat_parameters()[0].detach().cpu().numpy().tobytes()
+    gen, tr = fresh()                                     # interrupted after 2
+    for _ in range(2):
+        tr.step()
+    if r == 0:
+        save_checkpoint(path, gen, tr, 2)
+    parallel.barrier()
+    gen2, tr2 = fresh()
+    it = load_checkpoint(path, gen2, tr2, dev)
+    base = [int(v) for v in tr2.rng.state.tolist()]
+    for _ in range(2):
+        tr2.step()
+    got = gen2.a.flat_parameters()[0].detach().cpu().numpy().tobytes()
+    q.put((r, it, base, got == want, b))
+    parallel.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_resume_from_rank0_checkpoint_equals_the_uninterrupted_run(tmp_path):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    path = str(tmp_path / "dp_resume.pt")
+    ps = [ctx.Process(target=_resume_worker, args=(r, world, port, path, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted([q.get(timeout=500) for _ in range(world)], key=lambda t: t[0])
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    for r, it, base, same, b in res:
+        assert it == 2
+        assert base[2] == b and base[3] == b * 2, (r, base)          # the loader kept ITS shard base, not rank 0's
+        assert same, f"rank {r}: resumed run differs from the uninterrupted one"

