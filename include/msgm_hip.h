@@ -463,6 +463,18 @@ int msgm_groupnorm_dual_backward2(const float* x0, int32_t C0, const float* x1, 
                                   const float* beta, const float* stats, const float* gout, float* gx0, float* gx1,
                                   float* dgamma, float* dbeta, int32_t Bp, int32_t P, int32_t G, int32_t silu, float eps,
                                   void* workspace, size_t workspace_bytes, msgm_stream_t stream);
+/* The backward of either form (x1 == NULL, C1 == 0: one source) with the PARAMETER gradients left as slots: the
+ * per-(sample, chunk) partial sums of dgamma | dbeta are written to `pslots` (msgm_groupnorm_param_slots_bytes() bytes, caller
+ * owned, must stay valid until the reduction ran) and their slot-ordered sums into dgamma / dbeta (accumulating) are described
+ * in jobs_out[0..1] for msgm_slot_reduce_batched — a backward pass runs ONE reduction launch for all its GroupNorms and
+ * convolutions instead of one per layer (model/nn_utils.py:107-114 under autograd: two reductions per layer). */
+size_t msgm_groupnorm_param_slots_bytes(int32_t Bp, int32_t P, int32_t C);
+int msgm_groupnorm_dual_backward_slots(const float* x0, int32_t C0, const float* x1, int32_t C1, const float* gamma,
+                                       const float* beta, const float* stats, const float* gout, float* gx0, float* gx1,
+                                       float* dgamma, float* dbeta, int32_t Bp, int32_t P, int32_t G, int32_t silu, float eps,
+                                       const float* residual, void* workspace, size_t workspace_bytes, float* pslots,
+                                       size_t pslots_bytes, msgm_reduce_job_t* jobs_out, int32_t* n_jobs_out,
+                                       msgm_stream_t stream);
 
 /* GroupNorm statistics only, returned as the per-(sample, channel) affine map y = scale x + shift
  * (scale = gamma/sigma, shift = beta - mean scale; [Bp][C0+C1] each) for a consumer that applies it while reading

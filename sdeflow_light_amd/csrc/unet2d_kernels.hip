@@ -10,6 +10,7 @@
 // half of the batch (rows n >= Bp).
 #include "common.h"
 #include <stdlib.h>
+typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f32x4 mfma16u(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -130,13 +131,29 @@ __global__ void __launch_bounds__(256) k_gn_fwd_reduce(GnArgs A) {
   }
 }
 
-// moments of (sample b, group g): the chunk slots added in chunk order
+// moments of (sample b, group g): the chunk slots added in chunk order.  The loads of up to 4 slots are issued before the
+// first add (the slots are independent addresses; a plain loop waited for every slot's round trip in turn).
 __device__ __forceinline__ void gn_sum_slots(const GnArgs& A, int b, int g, int nm, double (&a8)[8]) {
 #pragma unroll
   for (int m = 0; m < 8; ++m) a8[m] = 0.0;
-  for (int ch = 0; ch < A.nch; ++ch) {
-    const double* p = A.acc + (((size_t)b * GN_SLOTS + ch) * A.G + g) * 8;
-    for (int m = 0; m < nm; ++m) a8[m] += p[m];
+  const double* base = A.acc + ((size_t)b * GN_SLOTS * A.G + g) * 8;
+  const size_t sstride = (size_t)A.G * 8;
+  for (int ch0 = 0; ch0 < A.nch; ch0 += 4) {
+    double v[4][5];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ch = min(ch0 + j, A.nch - 1);                // clamped: every load unconditional
+      const double* p = base + (size_t)ch * sstride;
+      const f64x2 q0 = *reinterpret_cast<const f64x2*>(p), q1 = *reinterpret_cast<const f64x2*>(p + 2);
+      v[j][0] = q0[0]; v[j][1] = q0[1]; v[j][2] = q1[0]; v[j][3] = q1[1];
+      v[j][4] = nm > 4 ? p[4] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (ch0 + j < A.nch) {
+#pragma unroll
+        for (int m = 0; m < 5; ++m) if (m < nm) a8[m] += v[j][m];
+      }
   }
 }
 
@@ -148,20 +165,6 @@ __device__ __forceinline__ void gn_stats(const double* a8, double cnt, float eps
   const double d = a8[2] / cnt;
   mu = (float)m; inv = (float)iv; md = (float)d;
   a = (float)(iv * (a8[3] / cnt - m * d));
-}
-
-// {mean, inv_std, mean(xdot), a} per (sample, group), once — not per element (the double-precision divide and
-// square root used to sit in the elementwise pass).  Written to the workspace tail and, if asked, to `stats`.
-__global__ void __launch_bounds__(256) k_gn_finalize(GnArgs A, float* __restrict__ wstats) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= A.Bp * A.G) return;
-  const double cnt = (double)A.P * (A.C / A.G);
-  float mu, inv, md, a;
-  double a8[8];
-  gn_sum_slots(A, i / A.G, i % A.G, A.dual ? 4 : 2, a8);
-  gn_stats(a8, cnt, A.eps, mu, inv, md, a);
-  *reinterpret_cast<f32x4*>(wstats + (size_t)i * 4) = f32x4{mu, inv, md, a};
-  if (A.stats) *reinterpret_cast<f32x4*>(A.stats + (size_t)i * 4) = f32x4{mu, inv, md, a};
 }
 
 // GroupNorm as a per-(sample, channel) affine map y = a x + b (a = gamma/sigma, b = beta - mean a) for a consumer that
@@ -195,11 +198,25 @@ __device__ __forceinline__ GnSrc gn_src(const GnArgs& A, int c) {
 }
 
 template <bool VEC>
-__global__ void __launch_bounds__(256) k_gn_fwd_apply(GnArgs A, const float* __restrict__ wstats) {
+__global__ void __launch_bounds__(256) k_gn_fwd_apply(GnArgs A) {
   constexpr int V = VEC ? 4 : 1;
+  __shared__ f32x4 sst[64];
   const int C = A.C, P = A.P, G = A.G, cpg = C / G;
   const int CV = C / V, PL = 256 / CV;
   const int tid = threadIdx.x, b = blockIdx.y;
+  // {mean, inv_std, mean(xdot), a} of this sample's groups, rebuilt by every workgroup from the chunk slots the reduce
+  // kernel left (thread g: the slots of group g in chunk order, in double — the arithmetic of the former one-thread-per-
+  // (sample, group) finalise launch, which cost 5-10 us per GroupNorm at the 32-row shard for a few KB of work).
+  // The sample's first workgroup keeps them for the backward.
+  if (tid < G) {
+    float mu, inv, md, a;
+    double a8[8];
+    gn_sum_slots(A, b, tid, A.dual ? 4 : 2, a8);
+    gn_stats(a8, (double)P * cpg, A.eps, mu, inv, md, a);
+    sst[tid] = f32x4{mu, inv, md, a};
+    if (A.stats && blockIdx.x == 0) *reinterpret_cast<f32x4*>(A.stats + ((size_t)b * G + tid) * 4) = f32x4{mu, inv, md, a};
+  }
+  __syncthreads();
   if (tid >= CV * PL) return;
   const int cv = tid % CV, pl = tid / CV;
   const long tot = (long)A.Bp * P * C;
@@ -207,7 +224,7 @@ __global__ void __launch_bounds__(256) k_gn_fwd_apply(GnArgs A, const float* __r
 #pragma unroll
   for (int k = 0; k < V; ++k) {
     const int c = V * cv + k;
-    const f32x4 st = *reinterpret_cast<const f32x4*>(wstats + ((size_t)b * G + c / cpg) * 4);
+    const f32x4 st = sst[c / cpg];
     mu[k] = st[0]; inv[k] = st[1]; md[k] = st[2]; a[k] = st[3];
     ga[k] = A.gamma[c]; be[k] = A.beta[c];
   }
@@ -357,24 +374,10 @@ __global__ void __launch_bounds__(256) k_gn_bwd_reduce(GnArgs A) {
 // dgamma[c] += sum over the (sample, chunk) slots, dbeta alike (blockIdx.y = 0 / 1): 32 channels x 32 slot slices per
 // workgroup (1024 threads: the grid is only C/32 x 2 workgroups, so the parallelism has to come from inside), every
 // slice walks its slots in order and the 32 slices are added in order — no atomics, same bits every run.
-// The first nb_fin workgroups of the SAME launch do k_gn_bwd_finalize's job (one launch less per GroupNorm backward: at
-// the 32-row shard of C4 these few-microsecond launches add up to a tenth of the step).
 __global__ void __launch_bounds__(1024) k_gn_param_reduce(const float* __restrict__ pslots, size_t nslots, int C,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, GnArgs A,
-                                                           int nb_fin, int nbc) {
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int nbc) {
   __shared__ float red[32][32];
-  if ((int)blockIdx.x < nb_fin) {                      // workgroup-uniform
-    const int i = blockIdx.x * 1024 + threadIdx.x;
-    if (i < A.Bp * A.G) {
-      double a8[8];
-      gn_sum_slots(A, i / A.G, i % A.G, 5, a8);
-      double* o = A.accf + (size_t)i * 8;
-#pragma unroll
-      for (int m = 0; m < 5; ++m) o[m] = a8[m];
-    }
-    return;
-  }
-  const int bid = blockIdx.x - nb_fin, bx = bid % nbc, by = bid / nbc;
+  const int bid = blockIdx.x, bx = bid % nbc, by = bid / nbc;
   const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int c = bx * 32 + cl;
   const float* p = pslots + (size_t)by * nslots * C;
@@ -398,6 +401,16 @@ __global__ void __launch_bounds__(256) k_gn_bwd_apply(GnArgs A) {
   const int C = A.C, P = A.P, G = A.G, cpg = C / G;
   const int CV = C / V, PL = 256 / CV;
   const int tid = threadIdx.x, b = blockIdx.y;
+  // the five backward moments of this sample's groups: every workgroup adds the reduce kernel's chunk slots itself (thread
+  // g, chunk order, double) instead of a finalise launch in between
+  __shared__ float sm5[64][5];
+  if (tid < G) {
+    double a8[8];
+    gn_sum_slots(A, b, tid, 5, a8);
+#pragma unroll
+    for (int m = 0; m < 5; ++m) sm5[tid][m] = (float)a8[m];
+  }
+  __syncthreads();
   if (tid >= CV * PL) return;
   const int cv = tid % CV, pl = tid / CV;
   const long tot = (long)A.Bp * P * C;
@@ -408,9 +421,8 @@ __global__ void __launch_bounds__(256) k_gn_bwd_apply(GnArgs A) {
     const int c = V * cv + k, g = c / cpg;
     const f32x4 st = *reinterpret_cast<const f32x4*>(A.stats + ((size_t)b * G + g) * 4);
     mu[k] = st[0]; inv[k] = st[1]; md[k] = st[2]; a[k] = st[3];
-    const double* a8 = A.accf + ((size_t)b * G + g) * 8;
-    mX[k] = (float)a8[0] * rc; mXx[k] = (float)a8[1] * rc; mW[k] = (float)a8[2] * rc; pp[k] = (float)a8[3] * rc;
-    cc[k] = (float)a8[4] * rc;
+    mX[k] = sm5[g][0] * rc; mXx[k] = sm5[g][1] * rc; mW[k] = sm5[g][2] * rc; pp[k] = sm5[g][3] * rc;
+    cc[k] = sm5[g][4] * rc;
     ga[k] = A.gamma[c]; be[k] = A.beta[c];
   }
   const int p0 = blockIdx.x * A.chunk, p1 = min(p0 + A.chunk, P);
@@ -969,16 +981,15 @@ static int gn_forward_impl(const float* x, int32_t C0, const float* x1, int32_t 
   if (workspace_bytes < msgm_groupnorm_workspace(Bp, G)) return MSGM_E_WORKSPACE;
   GnArgs A{x, gamma, beta, out, reinterpret_cast<double*>(workspace), stats, P, C, G, Bp, dual, silu, 0, eps,
            nullptr, nullptr, nullptr, nullptr, x1, C0};
-  float* wstats = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + gn_acc_bytes(Bp, G) + gn_accf_bytes(Bp, G));
   const int nch = gn_chunks(Bp, P, &A.chunk, &A.sub);
   if (nch > GN_SLOTS) return MSGM_E_UNSUPPORTED;
   A.nch = nch;
+  // two launches: chunk moments -> slots, then the apply pass (every workgroup finalises its sample's statistics itself)
   if (C % 4 == 0) hipLaunchKernelGGL(k_gn_fwd_reduce<true>, dim3(Bp, nch), dim3(256), 0, S(stream), A);
   else hipLaunchKernelGGL(k_gn_fwd_reduce<false>, dim3(Bp, nch), dim3(256), 0, S(stream), A);
-  hipLaunchKernelGGL(k_gn_finalize, dim3((Bp * G + 255) / 256), dim3(256), 0, S(stream), A, wstats);
   const int nap = gn_chunks_apply(Bp, P, &A.chunk);
-  if (C % 4 == 0) hipLaunchKernelGGL(k_gn_fwd_apply<true>, dim3(nap, Bp), dim3(256), 0, S(stream), A, (const float*)wstats);
-  else hipLaunchKernelGGL(k_gn_fwd_apply<false>, dim3(nap, Bp), dim3(256), 0, S(stream), A, (const float*)wstats);
+  if (C % 4 == 0) hipLaunchKernelGGL(k_gn_fwd_apply<true>, dim3(nap, Bp), dim3(256), 0, S(stream), A);
+  else hipLaunchKernelGGL(k_gn_fwd_apply<false>, dim3(nap, Bp), dim3(256), 0, S(stream), A);
   return msgm_check_launch();
 }
 
@@ -1057,10 +1068,14 @@ int msgm_groupnorm_affine_chanstats(const float* cs0, int32_t S0, int32_t C0, co
   return msgm_check_launch();
 }
 
+// pslots_ext != nullptr: the per-(sample, chunk) dgamma | dbeta partials go to the CALLER's buffer and their slot-ordered
+// sums are described in jobs_out[0..1] instead of being launched — a backward pass batches the parameter reductions of all
+// its GroupNorms (and its convolutions' weight gradients) into ONE msgm_slot_reduce_batched launch.
 static int gn_backward_impl(const float* x, int32_t C0, const float* x1, int32_t C, const float* gamma, const float* beta,
                             const float* stats, const float* gout, float* gx, float* gx1, float* dgamma, float* dbeta, int32_t Bp,
                             int32_t P, int32_t G, int32_t silu, float eps, const float* residual, void* workspace,
-                            size_t workspace_bytes, msgm_stream_t stream) {
+                            size_t workspace_bytes, msgm_stream_t stream, float* pslots_ext = nullptr, size_t pslots_bytes = 0,
+                            msgm_reduce_job_t* jobs_out = nullptr, int32_t* n_jobs_out = nullptr) {
   if (!x || !gamma || !beta || !stats || !gout || !gx || !dgamma || !dbeta || !workspace || Bp <= 0 || P <= 0 || C <= 0 || G <= 0)
     return MSGM_E_BADARG;
   if (C % G || C > 256 || G > 64) return MSGM_E_UNSUPPORTED;
@@ -1072,18 +1087,49 @@ static int gn_backward_impl(const float* x, int32_t C0, const float* x1, int32_t
   if (nch > GN_SLOTS) return MSGM_E_UNSUPPORTED;
   A.nch = nch;
   char* wsb = reinterpret_cast<char*>(workspace);
-  A.accf = reinterpret_cast<double*>(wsb + gn_acc_bytes(Bp, G));
+  A.accf = nullptr;
   A.pslots = reinterpret_cast<float*>(wsb + gn_acc_bytes(Bp, G) + gn_accf_bytes(Bp, G) + gn_stats_bytes(Bp, G));
+  const size_t nslots = (size_t)Bp * nch;
+  if (pslots_ext) {
+    if (!jobs_out || !n_jobs_out || pslots_bytes < 2 * nslots * C * sizeof(float)) return MSGM_E_WORKSPACE;
+    A.pslots = pslots_ext;
+  }
   A.resid = residual;
   if (C % 4 == 0) hipLaunchKernelGGL(k_gn_bwd_reduce<true>, dim3(Bp, nch), dim3(256), 0, S(stream), A);
   else hipLaunchKernelGGL(k_gn_bwd_reduce<false>, dim3(Bp, nch), dim3(256), 0, S(stream), A);
-  const int nb_fin = (Bp * G + 1023) / 1024, nbc = (C + 31) / 32;
-  hipLaunchKernelGGL(k_gn_param_reduce, dim3(nb_fin + 2 * nbc), dim3(1024), 0, S(stream), (const float*)A.pslots,
-                     (size_t)Bp * nch, C, dgamma, dbeta, A, nb_fin, nbc);
+  if (pslots_ext) {
+    for (int w = 0; w < 2; ++w)
+      jobs_out[w] = msgm_reduce_job_t{A.pslots + (size_t)w * nslots * C, w == 0 ? dgamma : dbeta, nullptr, (int64_t)C, (int64_t)C, 0, 0,
+                                      (int32_t)nslots, 1, 0, 0, 0, 0, 1, 0};
+    *n_jobs_out = 2;
+  } else {
+    const int nbc = (C + 31) / 32;
+    hipLaunchKernelGGL(k_gn_param_reduce, dim3(2 * nbc), dim3(1024), 0, S(stream), (const float*)A.pslots, nslots, C, dgamma, dbeta,
+                       nbc);
+  }
   const int nap = gn_chunks_apply(Bp, P, &A.chunk);
   if (C % 4 == 0) hipLaunchKernelGGL(k_gn_bwd_apply<true>, dim3(nap, Bp), dim3(256), 0, S(stream), A);
   else hipLaunchKernelGGL(k_gn_bwd_apply<false>, dim3(nap, Bp), dim3(256), 0, S(stream), A);
   return msgm_check_launch();
+}
+
+size_t msgm_groupnorm_param_slots_bytes(int32_t Bp, int32_t P, int32_t C) {
+  if (Bp <= 0 || P <= 0 || C <= 0) return 0;
+  int chunk, sub;
+  const int nch = gn_chunks(Bp, P, &chunk, &sub);
+  return (size_t)2 * Bp * nch * C * sizeof(float);
+}
+
+int msgm_groupnorm_dual_backward_slots(const float* x0, int32_t C0, const float* x1, int32_t C1, const float* gamma,
+                                       const float* beta, const float* stats, const float* gout, float* gx0, float* gx1,
+                                       float* dgamma, float* dbeta, int32_t Bp, int32_t P, int32_t G, int32_t silu, float eps,
+                                       const float* residual, void* workspace, size_t workspace_bytes, float* pslots,
+                                       size_t pslots_bytes, msgm_reduce_job_t* jobs_out, int32_t* n_jobs_out,
+                                       msgm_stream_t stream) {
+  if (!pslots || !jobs_out || !n_jobs_out || (x1 ? C1 <= 0 : C1 != 0)) return MSGM_E_BADARG;
+  *n_jobs_out = 0;
+  return gn_backward_impl(x0, C0, x1, C0 + C1, gamma, beta, stats, gout, gx0, gx1, dgamma, dbeta, Bp, P, G, silu, eps, residual,
+                          workspace, workspace_bytes, stream, pslots, pslots_bytes, jobs_out, n_jobs_out);
 }
 
 int msgm_groupnorm_dual_backward(const float* x, const float* gamma, const float* beta, const float* stats, const float* gout,

@@ -655,6 +655,22 @@ def groupnorm_dual_forward(x, gamma, beta, Bp, P, C, G, dual, silu, stats=None, 
     return out
 
 
+def _gn_backward_slots(x0, C0, x1, C1, gamma, beta, stats, gout, gx0, gx1, dgamma, dbeta, Bp, P, G, silu, eps, residual, d):
+    """GroupNorm backward inside a DeferredReduces pass: the dgamma / dbeta partials go to the pass's arena and their
+    slot-ordered sums join the pass's ONE batched reduction launch."""
+    import ctypes as C_
+    C = C0 + C1
+    need = int(lib().msgm_groupnorm_param_slots_bytes(Bp, P, C))
+    ps, nbytes = d.take(need)
+    ws = _gn_ws(Bp, G, x0.device)
+    jobs, nj = (L.ReduceJobT * 2)(), C_.c_int32(0)
+    check(lib().msgm_groupnorm_dual_backward_slots(ptr(f32(x0)), C0, ptr(x1), C1, ptr(f32(gamma)), ptr(f32(beta)), ptr(f32(stats)),
+                                                   ptr(f32(gout)), ptr(gx0), ptr(gx1), ptr(dgamma), ptr(dbeta), Bp, P, G,
+                                                   int(bool(silu)), float(eps), ptr(residual), ptr(ws), ws.numel() * 8, ps, nbytes,
+                                                   jobs, C_.byref(nj), stream()), "msgm_groupnorm_dual_backward_slots")
+    d.add(jobs, nj.value, (dgamma, dbeta))
+
+
 def groupnorm_dual_backward(x, gamma, beta, stats, gout, dgamma, dbeta, Bp, P, C, G, silu, gx=None, eps=1e-5, residual=None):
     """``residual`` (same shape as x) is added to the returned cotangent in the apply pass (skip branch, no extra axpy)."""
     if x.numel() != 2 * Bp * P * C or gout.numel() != x.numel() or stats.numel() != Bp * G * 4:
@@ -664,6 +680,10 @@ def groupnorm_dual_backward(x, gamma, beta, stats, gout, dgamma, dbeta, Bp, P, C
     gx = gout if gx is None else gx
     if residual is not None and residual.numel() != x.numel():
         raise MsgmError("groupnorm backward: residual size")
+    d = DeferredReduces.active
+    if d is not None and d.device == x.device:
+        _gn_backward_slots(x, C, None, 0, gamma, beta, stats, gout, gx, None, dgamma, dbeta, Bp, P, G, silu, eps, residual, d)
+        return gx
     ws = _gn_ws(Bp, G, x.device)
     check(lib().msgm_groupnorm_dual_backward(ptr(f32(x)), ptr(f32(gamma)), ptr(f32(beta)), ptr(f32(stats)), ptr(f32(gout)),
                                              ptr(gx), ptr(dgamma), ptr(dbeta), Bp, P, C, G, int(bool(silu)), float(eps),
@@ -689,6 +709,10 @@ def groupnorm_dual_backward2(x0, C0, x1, C1, gamma, beta, stats, gout, dgamma, d
     if gout.numel() != 2 * Bp * P * (C0 + C1) or x0.numel() != 2 * Bp * P * C0 or x1.numel() != 2 * Bp * P * C1:
         raise MsgmError("groupnorm2 backward: size mismatch")
     gx0, gx1 = torch.empty_like(x0), torch.empty_like(x1)
+    d = DeferredReduces.active
+    if d is not None and d.device == x0.device:
+        _gn_backward_slots(x0, C0, x1, C1, gamma, beta, stats, gout, gx0, gx1, dgamma, dbeta, Bp, P, G, silu, eps, None, d)
+        return gx0, gx1
     ws = _gn_ws(Bp, G, x0.device)
     check(lib().msgm_groupnorm_dual_backward2(ptr(f32(x0)), C0, ptr(f32(x1)), C1, ptr(f32(gamma)), ptr(f32(beta)), ptr(f32(stats)),
                                               ptr(f32(gout)), ptr(gx0), ptr(gx1), ptr(dgamma), ptr(dbeta), Bp, P, G, int(bool(silu)),
