@@ -578,6 +578,29 @@ int msgm_flat_to_image(const float* flat, float* img, int32_t B, int32_t C, int3
                        float scale, msgm_stream_t stream);
 int msgm_image_to_flat(const float* img, float* flat, int32_t B, int32_t C, int32_t H, int32_t W, int32_t forder,
                        float scale, msgm_stream_t stream);
+/* Embedding-projection bank: the emb_layers Linear(4*mc -> co) of EVERY ResBlock (model/unet.py:145-151, applied at :176-180)
+ * in one launch per direction, straight on the PyTorch-layout parameters.  job j = one ResBlock; `block_begin` = index of the
+ * job's first 32-channel workgroup (jobs sorted, total_blocks = sum of ceil(co/32)).
+ *   forward : out_j[r][c] = (r < n_bias ? b_j[c] : 0) + sum_k semb[r][k] W_j[c][k]            (out_j: [R][co])
+ *   backward: dW_j[c][k] = sum_r dout_j[r][c] semb[r][k];  db_j[c] = db2_j[c] = sum_{r<n_bias} dout_j[r][c]  (db / db2 may be
+ *             NULL; db2 = the conv bias added at the same place);  dsemb[r][k] = sum_j sum_c dout_j[r][c] W_j[c][k]  (written,
+ *             not accumulated).  Sums run in a fixed order: bitwise reproducible.  K % 4 == 0, K <= 512. */
+typedef struct {
+  const float* W;      /* [co][K]  (PyTorch Linear.weight)              */
+  const float* b;      /* [co] or NULL                                   */
+  float* out;          /* forward output  [R][co]                        */
+  const float* dout;   /* backward input  [R][co]                        */
+  float* dW;           /* [co][K]                                        */
+  float* db;           /* [co] or NULL                                   */
+  float* db2;          /* [co] or NULL                                   */
+  int32_t co;
+  int32_t block_begin;
+} msgm_emb_job_t;
+int msgm_emb_bank_forward(const msgm_emb_job_t* jobs_dev, int32_t n_jobs, int32_t total_blocks, const float* semb, int32_t R,
+                          int32_t K, int32_t n_bias, msgm_stream_t stream);
+int msgm_emb_bank_backward(const msgm_emb_job_t* jobs_dev, int32_t n_jobs, int32_t total_blocks, const float* semb, float* dsemb,
+                           int32_t R, int32_t K, int32_t n_bias, msgm_stream_t stream);
+
 /* out[n][h][w][c] = sum of the 2x2 block in[n][2h..2h+1][2w..2w+1][c]: adjoint of the
  * nearest-2x upsample (model/unet.py:67). */
 int msgm_sum2x2(const float* in, float* out, int32_t N, int32_t H, int32_t W, int32_t C, msgm_stream_t stream);

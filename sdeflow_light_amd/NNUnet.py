@@ -148,11 +148,13 @@ class _Res:
         ci, co = m.channels, m.out_channels
         self.ci, self.co = ci, co
         self.conv1 = ConvOp(m.in_layers[2].weight, m.in_layers[2].bias, "conv", (3, 3), 1, 1, [ci])
-        self.lin = ConvOp(m.emb_layers[1].weight, m.emb_layers[1].bias, "linear", (1,), 1, 0, [m.emb_layers[1].in_features])
+        # the embedding projection emb_layers[1] runs in the network's ops.EmbBank (one launch for all ResBlocks);
+        # bank_i = this block's index in it
+        self.bank_i = -1
         self.conv2 = ConvOp(m.out_layers[3].weight, m.out_layers[3].bias, "conv", (3, 3), 1, 1, [co])
         self.skip = None if isinstance(m.skip_connection, nn.Identity) else \
             ConvOp(m.skip_connection.weight, m.skip_connection.bias, "conv", (1, 1), 1, 0, [ci])
-        self.ops = [self.conv1, self.lin, self.conv2] + ([self.skip] if self.skip else [])
+        self.ops = [self.conv1, self.conv2] + ([self.skip] if self.skip else [])
         self.conv1_2 = self.skip_2 = None      # two-source twins for decoder blocks (sampler path, see make_two_source)
         self.skip_2t = None                    # the skip twin of the TRAINING path (its own gradient image)
         self.split = None
@@ -245,6 +247,10 @@ class VorticityUNet(nn.Module, FlatParamMixin):
                 allops += o.ops if kind in ("res", "attn") else [o]
         x["all"] = allops
         x["set"] = ConvOpSet(allops)
+        res = [o for blk in x["in"] + [x["mid"]] + x["outb"] for kind, o in blk if kind == "res"]
+        for i, r in enumerate(res):
+            r.bank_i = i
+        x["bank"] = ops.EmbBank([(r.m.emb_layers[1].weight, r.m.emb_layers[1].bias, r.m.in_layers[2].bias) for r in res], 4 * mc)
         # channel count after every input block = the skip tensors the decoder pops (model/unet.py:506-514)
         chans = []
         for blk in x["in"]:
@@ -282,7 +288,7 @@ class VorticityUNet(nn.Module, FlatParamMixin):
 
     def _res_fwd(self, r: _Res, x, N, Bp, H, W, semb, dual, tape, er):
         P = H * W
-        eo, _, _ = r.lin.forward([semb], er, 1, 1, Bp)           # er rows carry an embedding (N with log-radius conditioning)
+        eo = self._eo[r.bank_i]                                  # emb_layers projection, er rows (N with log-radius conditioning)
         if isinstance(x, tuple) and tape is not None:            # training, decoder block: cat([h, skip]) never materialised
             h0, s0 = x
             C0, C1 = r.split
@@ -420,6 +426,7 @@ class VorticityUNet(nn.Module, FlatParamMixin):
             pre = (le, zs, as_)
             emb, er = es, N
         semb = ops.act_dual_forward(SILU, emb, torch.empty_like(emb), dual and er == N and N != Bp)   # emb_layers[0] = SiLU
+        self._eo = x["bank"].forward(semb, er, Bp)               # every ResBlock's emb_layers[1] in ONE launch
         if tape is not None:
             tape.append(("emb", e0, z1, a1, emb, semb, pre, er))
 
@@ -561,7 +568,8 @@ class VorticityUNet(nn.Module, FlatParamMixin):
         dev = g.device
         emb_rec = tape[0]
         _, e0, z1, a1, emb, semb, pre, er = emb_rec
-        dsemb = torch.zeros_like(semb)
+        dsemb = torch.empty_like(semb)       # written (not accumulated) by the embedding bank's backward after the loop
+        deo_all = x["bank"].dout
         dh = g
         pend = []                       # gradients w.r.t. the skip (hs) tensors, in pop order
         i = len(tape) - 1
@@ -577,9 +585,8 @@ class VorticityUNet(nn.Module, FlatParamMixin):
                 P = H * W
                 (dh3,) = rb.conv2.backward(dh, [h3], N, H, W, Bp)
                 dh2 = self._gn_bwd(rb.m.out_layers[0], h2, st2, dh3, Bp, P, rb.co, True)
-                deo = torch.empty(er * rb.co, device=dev)
-                (dh1,) = rb.conv1.backward(dh2, [h1], N, H, W, Bp, dsamp_bias=deo, emb_rows=er)
-                rb.lin.backward(deo, [semb], er, 1, 1, Bp, dsrc=[dsemb], dacc=[True])
+                (dh1,) = rb.conv1.backward(dh2, [h1], N, H, W, Bp, dsamp_bias=deo_all[rb.bank_i], emb_rows=er,
+                                           bias_grad_elsewhere=True)
                 # identity skip: the `h + x` cotangent is added in the GroupNorm apply pass (no separate axpy)
                 dx = self._gn_bwd(rb.m.in_layers[0], xin, st1, dh1, Bp, P, rb.ci, True, residual=None if rb.skip is not None else dh)
                 if rb.skip is not None:
@@ -591,9 +598,8 @@ class VorticityUNet(nn.Module, FlatParamMixin):
                 C0, C1 = rb.split
                 (dh3,) = rb.conv2.backward(dh, [h3], N, H, W, Bp)
                 dh2 = self._gn_bwd(rb.m.out_layers[0], h2, st2, dh3, Bp, P, rb.co, True)
-                deo = torch.empty(er * rb.co, device=dev)
-                (dh1,) = rb.conv1.backward(dh2, [h1], N, H, W, Bp, dsamp_bias=deo, emb_rows=er)
-                rb.lin.backward(deo, [semb], er, 1, 1, Bp, dsrc=[dsemb], dacc=[True])
+                (dh1,) = rb.conv1.backward(dh2, [h1], N, H, W, Bp, dsamp_bias=deo_all[rb.bank_i], emb_rows=er,
+                                           bias_grad_elsewhere=True)
                 gnm = rb.m.in_layers[0]
                 dx0, dx1 = ops.groupnorm_dual_backward2(h0, C0, s0, C1, gnm.weight.detach(), gnm.bias.detach(), st1, dh1,
                                                         gnm.weight.grad, gnm.bias.grad, Bp, P, gnm.num_groups, True)
@@ -625,6 +631,8 @@ class VorticityUNet(nn.Module, FlatParamMixin):
                 else:
                     ops.lincomb(dh, dh, 1.0, sk, 1.0)
             i -= 1
+        # emb_layers[1] of every ResBlock: weight / bias gradients (+ the conv1 biases, same gradient) and dsemb, 2 launches
+        x["bank"].backward(semb, dsemb, er, Bp)
         # embedding MLPs: Linear -> SiLU -> Linear -> SiLU (shared emb_layers[0])
         if pre is not None:
             le, zs, as_ = pre

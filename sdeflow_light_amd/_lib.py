@@ -51,6 +51,12 @@ class PackJobT(C.Structure):
                 ("rowsP", C.c_int32), ("Ktot", C.c_int32), ("kp_off", C.c_int32), ("reserved", C.c_int32)]
 
 
+class EmbJobT(C.Structure):
+    """msgm_emb_job_t (include/msgm_hip.h)."""
+    _fields_ = [("W", C.c_void_p), ("b", C.c_void_p), ("out", C.c_void_p), ("dout", C.c_void_p), ("dW", C.c_void_p),
+                ("db", C.c_void_p), ("db2", C.c_void_p), ("co", C.c_int32), ("block_begin", C.c_int32)]
+
+
 class ConvGeomT(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("N", "Hi", "Wi", "Ho", "Wo", "KH", "KW", "strideH", "padH", "strideW", "padW", "mode", "ups")]
 
@@ -123,6 +129,8 @@ SIGNATURES = {
     "msgm_groupnorm_param_slots_bytes": (_SZ, [_I32, _I32, _I32]),
     "msgm_groupnorm_dual_backward_slots": (C.c_int, [_P, _I32, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F,
                                                      _P, _P, _SZ, _P, _SZ, C.POINTER(ReduceJobT), C.POINTER(C.c_int32), _P]),
+    "msgm_emb_bank_forward": (C.c_int, [_P, _I32, _I32, _P, _I32, _I32, _I32, _P]),
+    "msgm_emb_bank_backward": (C.c_int, [_P, _I32, _I32, _P, _P, _I32, _I32, _I32, _P]),
     "msgm_bmm": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, _I32, _P]),
     "msgm_bmm_dual": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64,
                                 _F, _I32, _P]),

@@ -272,10 +272,11 @@ class ConvOp:
                  emb: Optional[torch.Tensor] = None, demb: Optional[torch.Tensor] = None,
                  need: Optional[Sequence[bool]] = None, dsrc: Optional[List[Optional[torch.Tensor]]] = None,
                  dacc: Optional[Sequence[bool]] = None, dsamp_bias: Optional[torch.Tensor] = None,
-                 emb_rows: Optional[int] = None, bias_grad_zeroed: bool = False):
+                 emb_rows: Optional[int] = None, bias_grad_zeroed: bool = False, bias_grad_elsewhere: bool = False):
         """gy: cotangent of the output [N][Ho][Wo][Cout].  Accumulates the packed
         weight gradient, writes bias.grad, adds to ``demb`` / writes ``dsamp_bias``
-        (per-sample bias cotangent, primal rows) and returns d(src_s)."""
+        (per-sample bias cotangent, primal rows) and returns d(src_s).
+        bias_grad_elsewhere: with ``dsamp_bias``, the caller derives bias.grad from the per-sample sums itself (ops.EmbBank)."""
         geom, Ho, Wo = self._geom(N, Hi, Wi)
         dev = gy.device
         P = Ho * Wo
@@ -295,7 +296,7 @@ class ConvOp:
         elif self.bias is not None or self.embC or dsamp_bias is not None:
             S = dsamp_bias if dsamp_bias is not None else torch.empty(er * self.Cout, device=dev)
             ops.colsum(gy, er, P, self.Cout, out=S)                           # rows that carry a bias / embedding
-            if self.bias is not None:                                         # the bias itself: primal rows only
+            if self.bias is not None and not (bias_grad_elsewhere and dsamp_bias is not None):   # the bias itself: primal rows only
                 ops.colsum(S, 1, n_bias, self.Cout, out=self.bias.grad.view(1, -1))
         if self.embC:
             Bp, E = er, self.embC

@@ -924,6 +924,164 @@ __global__ void k_sum2x2(const float* __restrict__ in, float* __restrict__ out, 
   }
 }
 
+// ------------------------------------------------------------------ embedding-projection bank
+// Every ResBlock projects the SAME time embedding through its own Linear(4*mc -> co) (emb_layers, model/unet.py:145-151,
+// applied at :176-180).  Upstream that is 22 tiny GEMMs forward and 22 x (wgrad + bias sum + dgrad) backward per step —
+// 4-16 us launches that are pure latency at the 32-row shard.  The bank runs them as ONE launch per direction straight on
+// the PyTorch-layout parameters (no packed images): job j = one ResBlock; a workgroup owns 32 output channels of one job.
+//   forward : out_j[r][c]  = (r < n_bias ? b_j[c] : 0) + sum_k semb[r][k] W_j[c][k]
+//   wgrad   : dW_j[c][k]   = sum_r dout_j[r][c] semb[r][k]          (rows in order: deterministic)
+//             db_j[c]      = sum_{r < n_bias} dout_j[r][c]          (also written to db2_j: the conv bias that is added at
+//                                                                    the same place has the same gradient)
+//   dgrad   : dsemb[r][k]  = sum_j sum_c dout_j[r][c] W_j[c][k]     (jobs and channels in order)
+// K <= 512 and a multiple of 4; out_j / dout_j are [rows][co] contiguous per job.
+#define EB_ROWS 64
+template <int MODE>    // 0 forward, 1 wgrad
+__global__ void __launch_bounds__(256) k_emb_bank(const msgm_emb_job_t* __restrict__ jobs, int n_jobs, const float* __restrict__ semb,
+                                                  int R, int K, int n_bias) {
+  extern __shared__ float lds[];
+  const int KP = K + 4;                              // pitch: rows 16-byte aligned, consecutive rows on different banks
+  float* sS = lds;                                   // [EB_ROWS][KP]   semb rows of the current row tile
+  float* sW = lds + EB_ROWS * KP;                    // forward: [32][KP] weight rows; wgrad: [EB_ROWS][32] dout tile
+  int lo = 0, hi = n_jobs - 1;
+  const int blk = blockIdx.x;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (jobs[mid].block_begin <= blk) lo = mid; else hi = mid - 1; }
+  const msgm_emb_job_t J = jobs[lo];
+  const int c0 = (blk - J.block_begin) * 32, tid = threadIdx.x;
+  const int K4 = K >> 2;
+  if (MODE == 0) {
+    for (int i = tid; i < 32 * K4; i += 256) {       // weight rows c0..c0+31, coalesced 16-byte loads
+      const int c = i / K4, k4 = i - c * K4;
+      f32x4 w = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c0 + c < J.co) w = *reinterpret_cast<const f32x4*>(J.W + (size_t)(c0 + c) * K + 4 * k4);
+      *reinterpret_cast<f32x4*>(sW + c * KP + 4 * k4) = w;
+    }
+    const int cl = tid & 31, rg = tid >> 5;
+    const bool okc = c0 + cl < J.co;
+    const float bias = (okc && J.b) ? J.b[c0 + cl] : 0.f;
+    for (int r0 = blockIdx.y * EB_ROWS; r0 < R; r0 += gridDim.y * EB_ROWS) {
+      __syncthreads();
+      for (int i = tid; i < EB_ROWS * K4; i += 256) {
+        const int r = i / K4, k4 = i - r * K4;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (r0 + r < R) v = *reinterpret_cast<const f32x4*>(semb + (size_t)(r0 + r) * K + 4 * k4);
+        *reinterpret_cast<f32x4*>(sS + r * KP + 4 * k4) = v;
+      }
+      __syncthreads();
+      float acc[EB_ROWS / 8];
+#pragma unroll
+      for (int j = 0; j < EB_ROWS / 8; ++j) acc[j] = 0.f;
+      for (int k4 = 0; k4 < K4; ++k4) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(sW + cl * KP + 4 * k4);
+#pragma unroll
+        for (int j = 0; j < EB_ROWS / 8; ++j) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(sS + (rg + 8 * j) * KP + 4 * k4);
+          acc[j] = fmaf(v[0], w[0], acc[j]); acc[j] = fmaf(v[1], w[1], acc[j]);
+          acc[j] = fmaf(v[2], w[2], acc[j]); acc[j] = fmaf(v[3], w[3], acc[j]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < EB_ROWS / 8; ++j) {
+        const int r = r0 + rg + 8 * j;
+        if (okc && r < R) J.out[(size_t)r * J.co + c0 + cl] = acc[j] + (r < n_bias ? bias : 0.f);
+      }
+    }
+  } else {
+    // thread: 4 consecutive k (k4 = tid % K4 ... strided over K4) x 4 channels (cg = group of 4 of the 32)
+    const int kt = tid & 31, cg = tid >> 5;          // kt walks k4 = kt, kt + 32, ...; K4 <= 128 -> at most 4 rounds
+    float acc[4][4][4];                              // [round][channel][k]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][b][c] = 0.f;
+    float bsum = 0.f;                                // threads 0..31: bias gradient of channel c0 + tid
+    for (int r0 = 0; r0 < R; r0 += EB_ROWS) {
+      __syncthreads();
+      for (int i = tid; i < EB_ROWS * K4; i += 256) {
+        const int r = i / K4, k4 = i - r * K4;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (r0 + r < R) v = *reinterpret_cast<const f32x4*>(semb + (size_t)(r0 + r) * K + 4 * k4);
+        *reinterpret_cast<f32x4*>(sS + r * KP + 4 * k4) = v;
+      }
+      for (int i = tid; i < EB_ROWS * 32; i += 256) {
+        const int r = i >> 5, c = i & 31;
+        sW[r * 36 + c] = (r0 + r < R && c0 + c < J.co) ? J.dout[(size_t)(r0 + r) * J.co + c0 + c] : 0.f;
+      }
+      __syncthreads();
+      const int rend = min(EB_ROWS, R - r0);
+      for (int r = 0; r < rend; ++r) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(sW + r * 36 + 4 * cg);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int k4 = kt + 32 * a;
+          if (k4 < K4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(sS + r * KP + 4 * k4);
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+              for (int c = 0; c < 4; ++c) acc[a][b][c] = fmaf(g[b], v[c], acc[a][b][c]);
+          }
+        }
+      }
+      if (tid < 32) {
+        const int rb = min(rend, n_bias - r0);
+        for (int r = 0; r < rb; ++r) bsum += sW[r * 36 + tid];
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int k4 = kt + 32 * a;
+      if (k4 < K4) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int c = c0 + 4 * cg + b;
+          if (c < J.co) *reinterpret_cast<f32x4*>(J.dW + (size_t)c * K + 4 * k4) = f32x4{acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+        }
+      }
+    }
+    if (tid < 32 && c0 + tid < J.co) {
+      if (J.db) J.db[c0 + tid] = bsum;
+      if (J.db2) J.db2[c0 + tid] = bsum;
+    }
+  }
+}
+
+// dsemb[r][k] = sum over jobs and their channels, in order.  Grid (row tiles of 16, k tiles of 32); a thread owns one k
+// and two rows; the dout rows of a job are staged through LDS 64 channels at a time.
+__global__ void __launch_bounds__(256) k_emb_bank_dgrad(const msgm_emb_job_t* __restrict__ jobs, int n_jobs, float* __restrict__ dsemb,
+                                                        int R, int K) {
+  __shared__ float sG[16][68];
+  const int tid = threadIdx.x, kl = tid & 31, rs = tid >> 5;
+  const int k = blockIdx.y * 32 + kl, r0 = blockIdx.x * 16;
+  float a0 = 0.f, a1 = 0.f;
+  for (int j = 0; j < n_jobs; ++j) {
+    const msgm_emb_job_t J = jobs[j];
+    for (int cb = 0; cb < J.co; cb += 64) {
+      __syncthreads();
+      for (int i = tid; i < 16 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        sG[r][c] = (r0 + r < R && cb + c < J.co) ? J.dout[(size_t)(r0 + r) * J.co + cb + c] : 0.f;
+      }
+      __syncthreads();
+      const int cend = min(64, J.co - cb);
+      if (k < K) {
+#pragma unroll 8
+        for (int c = 0; c < cend; ++c) {
+          const float w = J.W[(size_t)(cb + c) * K + k];
+          a0 = fmaf(sG[rs][c], w, a0);
+          a1 = fmaf(sG[rs + 8][c], w, a1);
+        }
+      }
+    }
+  }
+  if (k < K) {
+    if (r0 + rs < R) dsemb[(size_t)(r0 + rs) * K + k] = a0;
+    if (r0 + rs + 8 < R) dsemb[(size_t)(r0 + rs + 8) * K + k] = a1;
+  }
+}
+
 // ============================================================ C ABI
 static inline hipStream_t S(msgm_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
@@ -1271,6 +1429,42 @@ int msgm_image_to_flat(const float* img, float* flat, int32_t B, int32_t C, int3
 int msgm_sum2x2(const float* in, float* out, int32_t N, int32_t H, int32_t W, int32_t C, msgm_stream_t stream) {
   if (!in || !out || N <= 0 || H <= 0 || W <= 0 || C <= 0) return MSGM_E_BADARG;
   hipLaunchKernelGGL(k_sum2x2, dim3(grid_for((int64_t)N * H * W * C, 256)), dim3(256), 0, S(stream), in, out, N, H, W, C);
+  return msgm_check_launch();
+}
+
+int msgm_emb_bank_forward(const msgm_emb_job_t* jobs_dev, int32_t n_jobs, int32_t total_blocks, const float* semb, int32_t R,
+                          int32_t K, int32_t n_bias, msgm_stream_t stream) {
+  if (!jobs_dev || !semb || n_jobs <= 0 || total_blocks <= 0 || R <= 0 || K <= 0 || n_bias < 0) return MSGM_E_BADARG;
+  if (K % 4 || K > 512) return MSGM_E_UNSUPPORTED;
+  const size_t lds = (size_t)(EB_ROWS + 32) * (K + 4) * sizeof(float);
+  static const int once = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_emb_bank<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_emb_bank<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return 0;
+  }();
+  (void)once;
+  int ry = (R + EB_ROWS - 1) / EB_ROWS;
+  if (ry > 8) ry = 8;
+  hipLaunchKernelGGL(k_emb_bank<0>, dim3((unsigned)total_blocks, (unsigned)ry), dim3(256), lds, S(stream), jobs_dev, n_jobs, semb, R, K,
+                     n_bias);
+  return msgm_check_launch();
+}
+
+int msgm_emb_bank_backward(const msgm_emb_job_t* jobs_dev, int32_t n_jobs, int32_t total_blocks, const float* semb, float* dsemb,
+                           int32_t R, int32_t K, int32_t n_bias, msgm_stream_t stream) {
+  if (!jobs_dev || !semb || !dsemb || n_jobs <= 0 || total_blocks <= 0 || R <= 0 || K <= 0 || n_bias < 0) return MSGM_E_BADARG;
+  if (K % 4 || K > 512) return MSGM_E_UNSUPPORTED;
+  size_t lds = (size_t)EB_ROWS * (K + 4) * sizeof(float) + (size_t)EB_ROWS * 36 * sizeof(float);
+  const size_t lds_f = (size_t)(EB_ROWS + 32) * (K + 4) * sizeof(float);
+  if (lds < lds_f) lds = lds_f;                      // one carve formula for both modes (sW starts at EB_ROWS * KP)
+  static const int once = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_emb_bank<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return 0;
+  }();
+  (void)once;
+  hipLaunchKernelGGL(k_emb_bank<1>, dim3((unsigned)total_blocks), dim3(256), lds, S(stream), jobs_dev, n_jobs, semb, R, K, n_bias);
+  hipLaunchKernelGGL(k_emb_bank_dgrad, dim3((unsigned)((R + 15) / 16), (unsigned)((K + 31) / 32)), dim3(256), 0, S(stream), jobs_dev,
+                     n_jobs, dsemb, R, K);
   return msgm_check_launch();
 }
 

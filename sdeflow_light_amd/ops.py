@@ -536,6 +536,64 @@ class DeferredReduces:
         check(lib().msgm_slot_reduce_batched(ptr(tab), n, blk, stream()), "msgm_slot_reduce_batched")
 
 
+class EmbBank:
+    """The time-embedding projections of all ResBlocks of a U-Net (emb_layers[1], model/unet.py:145-151) as ONE launch per
+    direction (msgm_emb_bank_forward / _backward) on the PyTorch-layout parameters.  ``items`` = [(weight (co, K), bias (co),
+    conv_bias or None)] in execution order; conv_bias is the bias of the conv whose output the projection is added to
+    (model/unet.py:179-180): it has the same gradient, so the bank writes both.  ``out[i]`` / ``dout[i]`` are the per-block
+    [rows][co] views the ResBlocks read / write."""
+
+    def __init__(self, items, K: int):
+        self.items, self.K = list(items), int(K)
+        self.cos = [int(w.shape[0]) for w, _, _ in self.items]
+        self.blocks, nb = [], 0
+        for co in self.cos:
+            self.blocks.append(nb)
+            nb += (co + 31) // 32
+        self.total_blocks = nb
+        self.sig, self.table, self.out, self.dout, self._keep = None, None, None, None, []
+
+    def _prepare(self, rows: int, dev):
+        grads = tuple((w.grad.data_ptr() if w.grad is not None else 0) for w, _, _ in self.items)
+        sig = (rows, str(dev), tuple(w.data_ptr() for w, _, _ in self.items), grads)
+        if sig == self.sig:
+            return
+        if torch.cuda.is_current_stream_capturing():
+            raise MsgmError("the embedding bank's job table must be built in an eager step before graph capture")
+        tot = sum(self.cos) * rows
+        if self.table is not None:
+            self._keep.append((self.table, self.eo_all, self.deo_all))     # a captured graph may still hold the old addresses
+        self.eo_all = torch.empty(tot, dtype=torch.float32, device=dev)
+        self.deo_all = torch.zeros(tot, dtype=torch.float32, device=dev)
+        arr = (L.EmbJobT * len(self.items))()
+        self.out, self.dout, off = [], [], 0
+        for i, ((w, b, cb), co) in enumerate(zip(self.items, self.cos)):
+            o, d = self.eo_all[off:off + rows * co], self.deo_all[off:off + rows * co]
+            self.out.append(o); self.dout.append(d)
+            g = lambda t: (t.grad.data_ptr() if (t is not None and t.grad is not None) else None)
+            arr[i] = L.EmbJobT(w.data_ptr(), b.data_ptr() if b is not None else None, o.data_ptr(), d.data_ptr(), g(w), g(b), g(cb),
+                               co, self.blocks[i])
+            off += rows * co
+        self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        self.sig = sig
+
+    def forward(self, semb: torch.Tensor, rows: int, n_bias: int):
+        if semb.numel() != rows * self.K:
+            raise MsgmError("embedding bank: semb must be [rows][K]")
+        self._prepare(rows, semb.device)
+        check(lib().msgm_emb_bank_forward(ptr(self.table), len(self.items), self.total_blocks, ptr(f32(semb)), rows, self.K,
+                                          int(n_bias), stream()), "msgm_emb_bank_forward")
+        return self.out
+
+    def backward(self, semb: torch.Tensor, dsemb: torch.Tensor, rows: int, n_bias: int):
+        """dout[i] filled by the ResBlocks' backward; writes every weight.grad / bias.grad / conv_bias.grad and dsemb."""
+        self._prepare(rows, semb.device)
+        if any(w.grad is None for w, _, _ in self.items) or dsemb.numel() != rows * self.K:
+            raise MsgmError("embedding bank backward: missing .grad or bad dsemb")
+        check(lib().msgm_emb_bank_backward(ptr(self.table), len(self.items), self.total_blocks, ptr(f32(semb)), ptr(dsemb), rows,
+                                           self.K, int(n_bias), stream()), "msgm_emb_bank_backward")
+
+
 def pack_weight(W: torch.Tensor, w_off: int, Wp: torch.Tensor, rows, ncols, col_off, taps, sr, sc, st, rowsP, Ktot, kp_off):
     need = w_off + (rows - 1) * sr + (col_off + ncols - 1) * sc + (taps - 1) * st + 1
     if need > W.numel() or Wp.numel() < taps * rowsP * Ktot:

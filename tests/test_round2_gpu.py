@@ -70,7 +70,7 @@ def test_mlp_em_256_steps_vs_reference():
 
 
 # ------------------------------------------------------------------------------------------ (b) BASELINE shapes
-def ssm_parity_vs_fp64(gen, score, p, x, u, eps, uv, what, grad_key=lambda k: k):
+def ssm_parity_vs_fp64(gen, score, p, x, u, eps, uv, what, grad_key=lambda k: k, **kw):
     """SGM + (u, eps, u_v) injected: HIP ``ssm`` against the float32 / float64 CPU oracle (conftest.parity_vs_fp64)."""
     from oracle import sde_ref as S, ssm_ref as LR
     from conftest import parity_vs_fp64
@@ -90,7 +90,7 @@ def ssm_parity_vs_fp64(gen, score, p, x, u, eps, uv, what, grad_key=lambda k: k)
         v = S.rademacher_from_uniform(uv)
         _, per, g = LR.ssm_mean_and_grads(sp, score, {k: w.to(dt) for k, w in p.items()}, t.to(dt), y.to(dt), v.to(dt))
         return per, g
-    return parity_vs_fp64(hip, oracle, what)
+    return parity_vs_fp64(hip, oracle, what, **kw)
 
 
 def test_c4_shape_ssm_loss_and_all_gradients_vs_oracle():
@@ -287,4 +287,6 @@ def test_unet2d_long_reverse_sde_run_vs_oracle():
         ref = S.euler_maruyama(proc, x0, steps, z, keep_all=True, include_t0=True)
     e = [rel_l2(xs[i], ref[i]) for i in (1, 16, 32, 64, 96, 128)]
     print("HIP vs oracle, 128-step U-Net EM, rel-L2 at steps 1,16,32,64,96,128: " + " ".join(f"{v:.1e}" for v in e))
-    assert max(e) <= 6e-6          # measured 3.5e-06 with the Winograd sampler, 1.5e-06 with the direct kernels (north_star bound: 1e-4)
+    # measured (r3, embedding bank): 4.5e-06 run alone, 6.6e-06 after the other tests of this file (r2: 1.4e-06 / 3.5e-06 —
+    # the det_params net amplifies a one-ulp difference in the embedding projection ~10x per evaluation); north_star bound 1e-4
+    assert max(e) <= 1.5e-5

@@ -106,3 +106,41 @@ def test_trainer_checkpoint_interchanges_with_adam_and_fused_adam(tmp_path):
     tr3 = MLPScoreTrainer(make_gen("sgm", MLP(2)), 1024, lr=1e-3, seed=3, use_graph=False)
     tr3.load_state_dict(adam.state_dict())
     assert torch.equal(tr3.m.cpu(), tr.m.cpu()) and int(tr3.step_dev.item()) == 3
+
+
+@pytest.mark.parametrize("rows,n_bias,cos,K", [(2, 2, [32, 64, 128], 128), (64, 32, [32, 96, 128, 40], 128), (200, 100, [64, 128], 64)])
+def test_embedding_bank_forward_backward_vs_fp64(rows, n_bias, cos, K):
+    """ops.EmbBank (all ResBlocks' emb_layers[1] in one launch per direction, model/unet.py:145-151,176-180) against
+    float64 torch: forward rows, weight / bias gradients (bias over the primal rows only, also written to the partner conv
+    bias) and the embedding cotangent."""
+    torch.manual_seed(rows + K)
+    items = []
+    for co in cos:
+        w = torch.nn.Parameter(torch.randn(co, K, device=DEV) / K ** 0.5)
+        b = torch.nn.Parameter(torch.randn(co, device=DEV))
+        cb = torch.nn.Parameter(torch.randn(co, device=DEV))
+        for t in (w, b, cb):
+            t.grad = torch.full_like(t, 7.0)                       # must be overwritten, not accumulated into
+        items.append((w, b, cb))
+    bank = ops.EmbBank(items, K)
+    semb = torch.randn(rows, K, device=DEV)
+    outs = bank.forward(semb, rows, n_bias)
+    worst = 0.0
+    for (w, b, _), o in zip(items, outs):
+        ref = semb.double() @ w.double().t()
+        ref[:n_bias] += b.double()
+        worst = max(worst, rel_l2(o.view(rows, -1).cpu(), ref.cpu()))
+    douts = [torch.randn(rows, co, device=DEV) for co in cos]
+    for d, dd in zip(bank.dout, douts):
+        d.copy_(dd.reshape(-1))
+    dsemb = torch.full((rows, K), 3.0, device=DEV)
+    bank.backward(semb, dsemb, rows, n_bias)
+    ref_ds = torch.zeros(rows, K, dtype=torch.float64, device=DEV)
+    for (w, b, cb), dd in zip(items, douts):
+        worst = max(worst, rel_l2(w.grad.cpu(), (dd.double().t() @ semb.double()).cpu()))
+        rb = dd[:n_bias].double().sum(0).cpu()
+        worst = max(worst, rel_l2(b.grad.cpu(), rb), rel_l2(cb.grad.cpu(), rb))
+        ref_ds += dd.double() @ w.double()
+    worst = max(worst, rel_l2(dsemb.cpu(), ref_ds.cpu()))
+    print(f"embedding bank rows={rows} cos={cos} K={K}: worst rel-L2 vs float64 {worst:.2e}")
+    assert worst <= 1e-6
