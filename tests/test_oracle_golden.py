@@ -221,6 +221,24 @@ def test_g10_ssm_unet2d():
     _check_digest(g, "u2d", grads, "a.", 2e-4)
 
 
+@pytest.mark.parametrize("tag,S_", [("w32", 32), ("w64", 64)])
+def test_g17_ssm_unet2d_wellconditioned(tag, S_):
+    """The oracle against the reference on the WELL-CONDITIONED parameter set (oracle.det_params.init_like_*): forward,
+    per-sample SSM loss and the gradient digest at 32x32 and 64x64 (attention at T = 1024 / 256 — the C4 shapes)."""
+    from oracle.det_params import init_like_state_dict
+    g = load_golden("g17_ssm_wellconditioned")
+    sp = spec()
+    cfg = N.UNet2DConfig(in_space=S_)
+    p = init_like_state_dict(unet2d_shapes(cfg, "core."))
+    score = lambda prm, yy, tt: N.vorticity_unet_forward(prm, yy, tt, cfg, None, "F")
+    with torch.no_grad():
+        close(score(p, g[tag + "_x"], g[tag + "_fwd_t"]), g[tag + "_fwd"], 5e-6)
+    t, y, v = _ssm_inputs(g, tag, sp)
+    loss, per, grads = L.ssm_mean_and_grads(sp, score, p, t, y, v, form="jvp")
+    close(per, g[tag + "_per"], 1e-5)
+    _check_digest(g, tag, grads, "a.", 1e-4)
+
+
 def test_g11_three_train_steps_adam():
     g = load_golden("g11_train3")
     sp = spec()

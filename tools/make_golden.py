@@ -53,7 +53,7 @@ from SDEs import SGMsde, MSGMsde, PluginReverseSDE, forward_SDE, sample_rademach
 from sde_scheme import EMstep, euler_maruyama_sampler, heun_sampler, rk4_stratonovich_sampler  # noqa: E402
 from model.nn_utils import timestep_embedding  # noqa: E402
 
-from oracle.det_params import load_det_  # noqa: E402
+from oracle.det_params import load_det_, load_init_like_  # noqa: E402
 
 
 class Recorder:
@@ -549,6 +549,30 @@ def g16_round2():
         y = s0.sample(t, x0)
     out.update(smallt_x0=x0, smallt_t=t, smallt_eps=r.draws[0][1], smallt_y=y)
     save("g16_round2", **out)
+
+
+def g17_ssm_wellconditioned():
+    """VERDICT r2 #5a: SSM per-sample loss + gradient digests of the reference's VorticityUNet at 32x32 and at 64x64
+    (attention at T = 1024 / 256, i.e. the C4 network's attention shapes) on a WELL-CONDITIONED parameter set
+    (oracle.det_params.load_init_like_: the statistics of the reference's default init, zero-init layers re-randomised
+    small) — the fixture the HIP path is held to with an ABSOLUTE tolerance."""
+    torch.manual_seed(17)
+    out = {}
+    for tag, S_, B in (("w32", 32, 2), ("w64", 64, 2)):
+        net = VorticityUNet(base_channels=32, channel_mults=(1, 2, 4), num_res_blocks=2, premodule=None, in_space=S_,
+                            attention_resolutions=(2, 4), flatten_order="F")
+        load_init_like_(net)
+        rev = PluginReverseSDE(sgm(), net, Tparam())
+        d = S_ * S_
+        x, u_t, eps, u_v = torch.randn(B, d) * 3, torch.rand(B, 1), torch.randn(B, d), torch.rand(B, d)
+        res = _ssm_case(rev, x, u_t, eps, u_v, full_grads=False)
+        out.update({f"{tag}_x": x, f"{tag}_u_t": u_t, f"{tag}_eps": eps, f"{tag}_u_v": u_v})
+        out.update({f"{tag}_{k}": v for k, v in res.items()})
+        with torch.no_grad():
+            t = torch.full((B,), 0.37)
+            out[f"{tag}_fwd_t"], out[f"{tag}_fwd"] = t, net(x, t)
+        print(tag, "loss", float(res["loss"]), "per", res["per"].tolist())
+    save("g17_ssm_wellconditioned", **out)
 
 
 if __name__ == "__main__":
