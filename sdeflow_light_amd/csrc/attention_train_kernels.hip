@@ -37,13 +37,13 @@ static inline hipStream_t S(msgm_stream_t s) { return reinterpret_cast<hipStream
 // Transposed formulation (as the sampler kernel): S^T[key][query] = K Q^T, O^T[c][query] += V^T P^T, so a lane owns ONE
 // query (lane&15): running max / sums are per-lane scalars, and e^{S-m} in the C/D layout IS the B operand of the
 // second product (MFMA step r of key tile kt contracts key 16kt + 4(lane>>4) + r on both operands).
-template <int CT, int QT, int KB>   // C = 16*CT channels; QT tiles of 16 queries per wave; KB keys per LDS block
-__global__ void __launch_bounds__(256) k_attn_dual_fwd(const float* __restrict__ qkv, float* __restrict__ att,
+template <int CT, int QT, int KB, int NW = 4>   // C = 16*CT channels; QT tiles of 16 queries per wave; KB keys per LDS block;
+__global__ void __launch_bounds__(64 * NW) k_attn_dual_fwd(const float* __restrict__ qkv, float* __restrict__ att,   // NW waves
                                                         float* __restrict__ lse, float* __restrict__ rbar, int T, int nqb,
                                                         int64_t Bp, float scale) {
-  constexpr int C = 16 * CT, KP = C + 4, LD = 3 * C, KT = KB / 16;
-  constexpr int NV = (KB * C / 4) / 256;                  // float4 per thread per matrix and key block
-  static_assert(NV >= 1, "key block too small for 256 threads");
+  constexpr int C = 16 * CT, KP = C + 4, LD = 3 * C, KT = KB / 16, NT = 64 * NW;
+  constexpr int NV = (KB * C / 4) / NT;                   // float4 per thread per matrix and key block
+  static_assert(NV >= 1 && (KB * C / 4) % NT == 0, "key block does not divide over the workgroup's threads");
   extern __shared__ __attribute__((aligned(16))) float atd_lds[];
   float* Ks = atd_lds;
   float* Kd = Ks + KB * KP;
@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(256) k_attn_dual_fwd(const float* __restrict__
   }
   const float* bp = qkv + (size_t)smp * T * LD;            // primal rows of this sample
   const float* bt = bp + (size_t)Bp * T * LD;              // tangent rows
-  const int q0 = (qb * 4 + w) * 16 * QT;                   // first query of this wave
+  const int q0 = (qb * NW + w) * 16 * QT;                  // first query of this wave
 
   f32x4 qf[QT][CT], qd[QT][CT], o[QT][CT], od[QT][CT];
   float m[QT], l[QT], rr[QT];
@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(256) k_attn_dual_fwd(const float* __restrict__
   auto gload = [&](int kb) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int idx = tid + 256 * i, key = idx / (C / 4), c4 = idx - key * (C / 4);
+      const int idx = tid + NT * i, key = idx / (C / 4), c4 = idx - key * (C / 4);
       const size_t off = (size_t)(kb * KB + key) * LD + 4 * c4;
       pk[i] = *reinterpret_cast<const f32x4*>(bp + off + C);
       pv[i] = *reinterpret_cast<const f32x4*>(bp + off + 2 * C);
@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(256) k_attn_dual_fwd(const float* __restrict__
     __syncthreads();                                       // the previous block's readers are done
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int idx = tid + 256 * i, key = idx / (C / 4), c4 = idx - key * (C / 4);
+      const int idx = tid + NT * i, key = idx / (C / 4), c4 = idx - key * (C / 4);
       *reinterpret_cast<f32x4*>(Ks + key * KP + 4 * c4) = pk[i];
       *reinterpret_cast<f32x4*>(Kd + key * KP + 4 * c4) = pkd[i];
       *reinterpret_cast<f32x4*>(Vs + key * KP + 4 * c4) = pv[i];
@@ -220,28 +220,31 @@ __global__ void __launch_bounds__(256) k_attn_dual_delta(const float* __restrict
 }
 
 // =============================================================================================== backward: main kernel
-// Workgroup = 8 waves = 64 keys of one sample; wave (qs = w&1, kg = w>>1) works on the 16-query sub-tile qs of the
+// Workgroup = 2*KG waves = KB = 16*KG keys of one sample; wave (qs = w&1, kg = w>>1) works on the 16-query sub-tile qs of the
 // current 32-query block and on keys [16kg, 16kg+16).  Per 32-query block:
-//   phase 1  tiles S, Sd, Pbar, D (96 MFMA), the elementwise adjoints, the key-side products (96 MFMA; the tile registers
-//            are their B operand), Sbar / Sdbar parked in LDS;
-//   phase 2  query-side products from the parked tiles (48 MFMA per wave: wave (qs, ct) owns 16 queries x 16 channels)
-//            -> one slab row per (key block, query).
-template <int CT>
-__global__ void __launch_bounds__(512) k_attn_dual_bwd(const float* __restrict__ qkv, const float* __restrict__ datt,
+//   phase 1  tiles S, Sd, Pbar, D (24 MFMA per 16 channels), the elementwise adjoints, the key-side products (24 per 16
+//            channels; the tile registers are their B operand), Sbar / Sdbar parked in LDS;
+//   phase 2  query-side products from the parked tiles: the 2*CT (query sub-tile, 16-channel tile) pairs are dealt to the
+//            waves (wave (qs, kg) takes channel tiles kg, kg + KG, ...) -> one slab row per (key block, query).
+// KG = 4 (64 keys, 8 waves) for C <= 64; KG = 2 (32 keys, 4 waves) for C = 128, where the four resident key-side tiles of
+// 64 keys alone would be 135 KB of LDS (the T = 256 blocks of the C4 network, model/unet.py:236-250 at (ch, T) = (128, 256)).
+template <int CT, int KG>
+__global__ void __launch_bounds__(128 * KG) k_attn_dual_bwd(const float* __restrict__ qkv, const float* __restrict__ datt,
                                                         const float* __restrict__ stats /* [2][Bp*T]: lse | rbar */,
                                                         const float* __restrict__ ccde /* [2][Bp*T]: c | delta */,
                                                         float* __restrict__ dqkv, float* __restrict__ slab, int T, int nkb,
                                                         int64_t Bp, float scale) {
-  constexpr int C = 16 * CT, KP = C + 4, LD = 3 * C, DP = 64 + 4, QB = 32;
-  constexpr int NK = (64 * C / 4) / 512;                  // float4 per thread per resident matrix
-  constexpr int NQ = (QB * C / 4 + 511) / 512;            // float4 per thread per streamed matrix and query block
-  constexpr bool QFULL = (QB * C / 4) % 512 == 0;         // C = 32: only half of the threads stage a float4
+  constexpr int C = 16 * CT, KP = C + 4, LD = 3 * C, KB = 16 * KG, DP = KB + 4, QB = 32, NT = 128 * KG;
+  constexpr int NK = (KB * C / 4) / NT;                   // float4 per thread per resident matrix
+  constexpr int NQ = (QB * C / 4 + NT - 1) / NT;          // float4 per thread per streamed matrix and query block
+  constexpr bool QFULL = (QB * C / 4) % NT == 0;          // C = 32: only half of the threads stage a float4
+  static_assert(NK >= 1 && (KB * C / 4) % NT == 0, "resident tiles do not divide over the workgroup");
   extern __shared__ __attribute__((aligned(16))) float atb_lds[];
-  float* Ks = atb_lds;                                    // [64][KP] x4, resident
-  float* Kd = Ks + 64 * KP;
-  float* Vs = Kd + 64 * KP;
-  float* Vd = Vs + 64 * KP;
-  float* Qs = Vd + 64 * KP;                               // [32][KP] x4, per query block
+  float* Ks = atb_lds;                                    // [KB][KP] x4, resident
+  float* Kd = Ks + KB * KP;
+  float* Vs = Kd + KB * KP;
+  float* Vd = Vs + KB * KP;
+  float* Qs = Vd + KB * KP;                               // [32][KP] x4, per query block
   float* Qd = Qs + QB * KP;
   float* Gs = Qd + QB * KP;
   float* Gd = Gs + QB * KP;
@@ -264,8 +267,8 @@ __global__ void __launch_bounds__(512) k_attn_dual_bwd(const float* __restrict__
   // ---- resident K, Kd, V, Vd tiles of this key block
 #pragma unroll
   for (int i = 0; i < NK; ++i) {
-    const int idx = tid + 512 * i, key = idx / (C / 4), c4 = idx - key * (C / 4);
-    const size_t off = (size_t)(kb * 64 + key) * LD + 4 * c4;
+    const int idx = tid + NT * i, key = idx / (C / 4), c4 = idx - key * (C / 4);
+    const size_t off = (size_t)(kb * KB + key) * LD + 4 * c4;
     *reinterpret_cast<f32x4*>(Ks + key * KP + 4 * c4) = *reinterpret_cast<const f32x4*>(bp + off + C);
     *reinterpret_cast<f32x4*>(Vs + key * KP + 4 * c4) = *reinterpret_cast<const f32x4*>(bp + off + 2 * C);
     *reinterpret_cast<f32x4*>(Kd + key * KP + 4 * c4) = *reinterpret_cast<const f32x4*>(bp + half_qkv + off + C);
@@ -281,7 +284,7 @@ __global__ void __launch_bounds__(512) k_attn_dual_bwd(const float* __restrict__
   auto gload = [&](int qb) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
-      const int idx = tid + 512 * i, qr = idx / (C / 4), c4 = idx - qr * (C / 4);
+      const int idx = tid + NT * i, qr = idx / (C / 4), c4 = idx - qr * (C / 4);
       if (!QFULL && idx >= QB * C / 4) break;
       const size_t row = (size_t)(qb * QB + qr);
       pq[i] = *reinterpret_cast<const f32x4*>(bp + row * LD + 4 * c4);
@@ -304,7 +307,7 @@ __global__ void __launch_bounds__(512) k_attn_dual_bwd(const float* __restrict__
     // scalars; phase 2 of the previous block only reads its own dS buffer and the resident K tiles
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
-      const int idx = tid + 512 * i, qr = idx / (C / 4), c4 = idx - qr * (C / 4);
+      const int idx = tid + NT * i, qr = idx / (C / 4), c4 = idx - qr * (C / 4);
       if (!QFULL && idx >= QB * C / 4) break;
       *reinterpret_cast<f32x4*>(Qs + qr * KP + 4 * c4) = pq[i];
       *reinterpret_cast<f32x4*>(Qd + qr * KP + 4 * c4) = pqd[i];
@@ -372,19 +375,20 @@ __global__ void __launch_bounds__(512) k_attn_dual_bwd(const float* __restrict__
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();                                       // [C] Sbar / Sdbar of the whole 32 x 64 block are parked
-    // ---- phase 2: qbar^T[c][query] += K^T Sbar^T + Kd^T Sdbar^T ; qdbar^T += K^T Sdbar^T   (wave = (qs, ct = kg))
-    if (kg < CT) {
+    __syncthreads();                                       // [C] Sbar / Sdbar of the whole 32 x KB block are parked
+    // ---- phase 2: qbar^T[c][query] += K^T Sbar^T + Kd^T Sdbar^T ; qdbar^T += K^T Sdbar^T   (wave (qs, kg): tiles ct = kg, kg+KG, ..)
+#pragma unroll
+    for (int ct = kg; ct < CT; ct += KG) {
       f32x4 dq = {0, 0, 0, 0}, dqd = {0, 0, 0, 0};
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {
+      for (int kt = 0; kt < KG; ++kt) {
         const f32x4 b1 = *reinterpret_cast<const f32x4*>(dS + (16 * qs + il) * DP + 16 * kt + 4 * q);
         const f32x4 b2 = *reinterpret_cast<const f32x4*>(dSd + (16 * qs + il) * DP + 16 * kt + 4 * q);
         float a1[4], a2[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          a1[r] = Ks[(16 * kt + 4 * q + r) * KP + 16 * kg + il];
-          a2[r] = Kd[(16 * kt + 4 * q + r) * KP + 16 * kg + il];
+          a1[r] = Ks[(16 * kt + 4 * q + r) * KP + 16 * ct + il];
+          a2[r] = Kd[(16 * kt + 4 * q + r) * KP + 16 * ct + il];
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -394,8 +398,8 @@ __global__ void __launch_bounds__(512) k_attn_dual_bwd(const float* __restrict__
         }
       }
       const size_t row = (size_t)qb * QB + 16 * qs + il;
-      float* sp = slab + (((size_t)smp * nkb + kb) * T + row) * C + 16 * kg + 4 * q;
-      float* sdp = slab + (((size_t)(Bp + smp) * nkb + kb) * T + row) * C + 16 * kg + 4 * q;
+      float* sp = slab + (((size_t)smp * nkb + kb) * T + row) * C + 16 * ct + 4 * q;
+      float* sdp = slab + (((size_t)(Bp + smp) * nkb + kb) * T + row) * C + 16 * ct + 4 * q;
 #ifdef ATT_EXP_NODQ           // diagnostic (WRONG results): what the query-gradient slab stores cost inside the loop
       if (dq[0] == 12345.678f) { *reinterpret_cast<f32x4*>(sp) = dq; *reinterpret_cast<f32x4*>(sdp) = dqd; }
 #else
@@ -416,7 +420,7 @@ __global__ void __launch_bounds__(512) k_attn_dual_bwd(const float* __restrict__
   }
   __syncthreads();
   if (qs == 0) {
-    const size_t row = (size_t)smp * T + kb * 64 + 16 * kg + il;     // key of this lane
+    const size_t row = (size_t)smp * T + kb * KB + 16 * kg + il;     // key of this lane
     float* kp_ = dqkv + row * LD;
     float* kt_ = dqkv + half_qkv + row * LD;
 #pragma unroll
@@ -446,42 +450,48 @@ __global__ void __launch_bounds__(256) k_attn_dq_reduce(const float* __restrict_
 }
 
 // =============================================================================================== launchers
-template <int CT, int QT, int KB>
+template <int CT, int QT, int KB, int NW>
 static int launch_fwd(const float* qkv, float* att, float* stats, int64_t Bp, int T, float scale, hipStream_t st) {
   constexpr int C = 16 * CT;
   constexpr size_t lds = (size_t)4 * KB * (C + 4) * sizeof(float);
   static const int once = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_dual_fwd<CT, QT, KB>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_dual_fwd<CT, QT, KB, NW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     return 0;
   }();
   (void)once;
-  const int nqb = T / (64 * QT);
-  hipLaunchKernelGGL((k_attn_dual_fwd<CT, QT, KB>), dim3((unsigned)(Bp * nqb)), dim3(256), lds, st, qkv, att, stats,
+  const int nqb = T / (16 * NW * QT);
+  hipLaunchKernelGGL((k_attn_dual_fwd<CT, QT, KB, NW>), dim3((unsigned)(Bp * nqb)), dim3(64 * NW), lds, st, qkv, att, stats,
                      stats + Bp * T, T, nqb, Bp, scale);
   return msgm_check_launch();
 }
 
-template <int CT>
+// keys per backward workgroup
+static inline int attn_bwd_keys(int C) { return C == 128 ? 32 : 64; }
+
+template <int CT, int KG>
 static int launch_bwd(const float* qkv, const float* att, const float* datt, const float* stats, float* dqkv, int64_t Bp, int T,
                       float scale, float* ws, hipStream_t st) {
-  constexpr int C = 16 * CT, KP = C + 4;
-  constexpr size_t lds = ((size_t)4 * 64 * KP + 4 * 32 * KP + 4 * 32 + 4 * 32 * 68) * sizeof(float);
+  constexpr int C = 16 * CT, KP = C + 4, KB = 16 * KG;
+  constexpr size_t lds_main = ((size_t)4 * KB * KP + 4 * 32 * KP + 4 * 32 + 4 * 32 * (KB + 4)) * sizeof(float);
+  constexpr size_t lds_epi = (size_t)KG * 4 * CT * 64 * 4 * sizeof(float);        // the cross-wave sum of the key-side gradients
+  constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+  static_assert(lds <= 160 * 1024, "backward tiles exceed the CU's LDS");
   static const int once = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_dual_bwd<CT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_dual_bwd<CT, KG>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
     return 0;
   }();
   (void)once;
   const int64_t rows = Bp * T;
-  const int nkb = T / 64;
+  const int nkb = T / KB;
   float* cc = ws;
   float* de = ws + rows;
   float* slab = ws + 2 * rows;
   hipLaunchKernelGGL(k_attn_dual_delta, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, att, datt, stats + rows, cc, de,
                      rows, C);
-  hipLaunchKernelGGL((k_attn_dual_bwd<CT>), dim3((unsigned)(Bp * nkb)), dim3(512), lds, st, qkv, datt, stats, cc, dqkv, slab, T, nkb, Bp,
-                     scale);
+  hipLaunchKernelGGL((k_attn_dual_bwd<CT, KG>), dim3((unsigned)(Bp * nkb)), dim3(128 * KG), lds, st, qkv, datt, stats, cc, dqkv, slab, T,
+                     nkb, Bp, scale);
   const int64_t work = 2 * Bp * T * (C / 4);
   hipLaunchKernelGGL(k_attn_dq_reduce, dim3((unsigned)grid_for(work, 256, 16384)), dim3(256), 0, st, slab, dqkv, 2 * Bp, T, C,
                      nkb, scale);
@@ -490,34 +500,43 @@ static int launch_bwd(const float* qkv, const float* att, const float* datt, con
 
 extern "C" {
 
+// C in {32, 64}: T a multiple of 64; C = 128 (the 16x16 / 8x8 attention of the 2-D U-Net): T a multiple of 32
 int msgm_attention_dual_supported(int32_t T, int32_t C) {
+  if (C == 128) return T >= 32 && T % 32 == 0;
   return (C == 32 || C == 64) && T >= 64 && T % 64 == 0;
 }
 
 size_t msgm_attention_dual_workspace(int64_t Bp, int32_t T, int32_t C) {
   if (!msgm_attention_dual_supported(T, C) || Bp <= 0) return 0;
-  return ((size_t)2 * Bp * T + (size_t)2 * Bp * (T / 64) * T * C) * sizeof(float);
+  return ((size_t)2 * Bp * T + (size_t)2 * Bp * (T / attn_bwd_keys(C)) * T * C) * sizeof(float);
 }
 
 int msgm_attention_dual_forward(const float* qkv, float* att, float* stats, int64_t Bp, int32_t T, int32_t C, float scale,
                                 msgm_stream_t stream) {
   if (!qkv || !att || !stats || Bp <= 0 || T <= 0 || C <= 0) return MSGM_E_BADARG;
-  if (!msgm_attention_dual_supported(T, C) || Bp * (int64_t)(T / 64) > 0x7fffffffLL) return MSGM_E_UNSUPPORTED;
+  if (!msgm_attention_dual_supported(T, C) || Bp * (int64_t)(T / 32) > 0x7fffffffLL) return MSGM_E_UNSUPPORTED;
+  if (C == 128) {
+    // 64-query workgroups (4 waves) while they fill the chip twice over, else 32-query workgroups (2 waves): at the 32-row
+    // shard the T = 256 blocks are only 128 workgroups of 64 queries
+    if (T % 64 == 0 && Bp * (int64_t)(T / 64) >= 512) return launch_fwd<8, 1, 16, 4>(qkv, att, stats, Bp, T, scale, S(stream));
+    return launch_fwd<8, 1, 16, 2>(qkv, att, stats, Bp, T, scale, S(stream));
+  }
   static const bool qt2 = getenv("MSGM_ATTN_DUAL_QT2") != nullptr;   // diagnostic A/B
   const bool two = qt2 && T % 128 == 0;
-  if (C == 32) return launch_fwd<2, 1, 64>(qkv, att, stats, Bp, T, scale, S(stream));
-  return two ? launch_fwd<4, 2, 32>(qkv, att, stats, Bp, T, scale, S(stream)) : launch_fwd<4, 1, 32>(qkv, att, stats, Bp, T, scale, S(stream));
+  if (C == 32) return launch_fwd<2, 1, 64, 4>(qkv, att, stats, Bp, T, scale, S(stream));
+  return two ? launch_fwd<4, 2, 32, 4>(qkv, att, stats, Bp, T, scale, S(stream)) : launch_fwd<4, 1, 32, 4>(qkv, att, stats, Bp, T, scale, S(stream));
 }
 
 int msgm_attention_dual_backward(const float* qkv, const float* att, const float* datt, const float* stats, float* dqkv,
                                  int64_t Bp, int32_t T, int32_t C, float scale, void* workspace, size_t workspace_bytes,
                                  msgm_stream_t stream) {
   if (!qkv || !att || !datt || !stats || !dqkv || !workspace || Bp <= 0 || T <= 0 || C <= 0) return MSGM_E_BADARG;
-  if (!msgm_attention_dual_supported(T, C) || Bp * (int64_t)(T / 64) > 0x7fffffffLL) return MSGM_E_UNSUPPORTED;
+  if (!msgm_attention_dual_supported(T, C) || Bp * (int64_t)(T / 32) > 0x7fffffffLL) return MSGM_E_UNSUPPORTED;
   if (workspace_bytes < msgm_attention_dual_workspace(Bp, T, C)) return MSGM_E_WORKSPACE;
   float* ws = static_cast<float*>(workspace);
-  if (C == 32) return launch_bwd<2>(qkv, att, datt, stats, dqkv, Bp, T, scale, ws, S(stream));
-  return launch_bwd<4>(qkv, att, datt, stats, dqkv, Bp, T, scale, ws, S(stream));
+  if (C == 128) return launch_bwd<8, 2>(qkv, att, datt, stats, dqkv, Bp, T, scale, ws, S(stream));
+  if (C == 32) return launch_bwd<2, 4>(qkv, att, datt, stats, dqkv, Bp, T, scale, ws, S(stream));
+  return launch_bwd<4, 4>(qkv, att, datt, stats, dqkv, Bp, T, scale, ws, S(stream));
 }
 
 }  // extern "C"

@@ -517,7 +517,8 @@ def test_flat_img_helpers_match_reference_semantics(order):
     assert back.shape == (B, H * W) and rel_l2(back.cpu(), x) <= 1e-6
 
 
-@pytest.mark.parametrize("Bp,T,C", [(3, 64, 32), (2, 128, 64), (2, 320, 64), (1, 1024, 64), (5, 192, 32)])
+@pytest.mark.parametrize("Bp,T,C", [(3, 64, 32), (2, 128, 64), (2, 320, 64), (1, 1024, 64), (5, 192, 32),
+                                    (2, 256, 128), (3, 64, 128), (1, 32, 128), (9, 96, 128), (40, 256, 128)])   # C = 128: the 16x16 / 8x8 blocks (r3)
 def test_fused_dual_attention_forward_backward(Bp, T, C):
     """K8 (training path): attention on dual numbers, forward and backward, without the (T,T) tensors — vs plain PyTorch
     fp32 (torch.func.jvp of QKVAttention.forward's arithmetic, model/unet.py:236-250, then autograd of the pair)."""
