@@ -74,7 +74,7 @@ class SDE(nn.Module):
         return new
 
     def T_float(self) -> float:
-        return float(self.T.item()) if torch.is_tensor(self.T) else float(self.T)
+        return L.host_scalar(self.T)          # cached: no device synchronisation per call (graph-capturable)
 
     def struct(self) -> L.SdeT:
         """msgm_sde_t for the kernels."""

@@ -210,6 +210,28 @@ def f32(t: torch.Tensor, name: str = "tensor") -> torch.Tensor:
     return t
 
 
+_HOST_SCALARS = {}
+
+
+def host_scalar(t) -> float:
+    """Value of a one-element tensor (the horizon T: an nn.Parameter(requires_grad=False) on the device upstream,
+    MSGM_higherDim.py:728) WITHOUT a device synchronisation per call: read once, cached per (storage address, version
+    counter) — an in-place update (load_state_dict) bumps the version and is read again.  Needed because the reference's
+    ``sde.T.item()`` (sde_scheme.py:54-57) sits inside code that the trainers capture into a hipGraph."""
+    if not torch.is_tensor(t):
+        return float(t)
+    if t.device.type == "cpu":
+        return float(t.item())
+    key = (t.device.index, t.data_ptr(), t._version)
+    v = _HOST_SCALARS.get(key)
+    if v is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise MsgmError("a device scalar (the horizon T) is read for the first time inside a graph capture; "
+                            "run one eager step first")
+        v = _HOST_SCALARS[key] = float(t.item())
+    return v
+
+
 def stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 

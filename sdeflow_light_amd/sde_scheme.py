@@ -54,7 +54,7 @@ class _Run:
         if x_0.dim() != 2:
             raise MsgmError("state must be 2-D (B,n)")
         self.B, self.n = x_0.shape
-        self.T_ = sde.T.item() if (not torch.is_tensor(T_) and T_ == -1) else T_.item()
+        self.T_ = L.host_scalar(sde.T) if (not torch.is_tensor(T_) and T_ == -1) else L.host_scalar(T_)   # sde_scheme.py:54-57
         self.N = num_steps
         self.delta = self.T_ / num_steps
         self.ts = torch.linspace(0, 1, num_steps + 1) * self.T_               # fp32, host (sde_scheme.py:59)
@@ -64,7 +64,11 @@ class _Run:
             raise MsgmError("sde must be a PluginReverseSDE or a forward_SDE")
         self.proc = L.PROC_REVERSE if self.reverse else L.PROC_FORWARD
         self.struct = self.base.struct()
-        self.x = x_0.detach().clone().to(self.device).float().contiguous()
+        if x_0.is_cuda and x_0.dtype == torch.float32 and x_0.is_contiguous() and x_0.device == self.device:
+            # device-to-device copy as a KERNEL (captured steps hold kernel nodes only: see msgm_zero_async in csrc/common.h)
+            self.x = ops.lincomb(torch.empty_like(x_0), x_0.detach(), 1.0)
+        else:
+            self.x = x_0.detach().clone().to(self.device).float().contiguous()
         self.norm0 = ops.row_norm(self.x) if norm_correction else None
         self.include_t0 = bool(include_t0)
         self.keep_all = keep_all_samples

@@ -85,16 +85,45 @@ class _TrainerState:
             self.rng.load_state_dict(sd["philox"])      # stream position only; the shard base stays this rank's
 
 
+def _msgm_draws(tr):
+    """(y, t, v, u, cst) of one training step under the MULTIPLICATIVE SDE, drawn in the order and from the stream
+    positions ``PluginReverseSDE.ssm`` uses (SDEs.py:684-693 sample_t, :78-122 sample_scheme, :514-515 probe): uniform t
+    clamped at t_epsilon, the device-resident masked RK4 forward perturbation over the nsf-step grid
+    (sde_scheme.msgm_forward_perturb), the Rademacher probe, then u = G(y)^T v, cst of the general loss form
+    (msgm_ssm_terms).  Every launch is a kernel on the current stream, no host synchronisation: capturable.
+    The base SDE draws from the TRAINER's Philox stream (shard placement included)."""
+    from .sde_scheme import msgm_forward_perturb
+    base, rng = tr.base, tr.rng
+    ops.fill_uniform(tr.u, rng, L.RNG_STREAM_T)
+    torch.mul(tr.u, tr.T_host, out=tr.t)
+    tr.t.clamp_(min=base.t_epsilon)                  # == m*t_eps + (1-m)*t of SDEs.py:690-692, bit for bit
+    y = msgm_forward_perturb(base, tr.t.view(-1, 1), tr.x)          # advances the stream by 2 nsf + 2
+    v = ops.rademacher((tr.B, tr.d), tr.dev, rng=rng)
+    rng.advance(1)
+    uu, cst = ops.ssm_terms(y, v, tr.t, tr.st)
+    return y, tr.t, v, uu, cst
+
+
+def _adopt_stream(tr):
+    """The multiplicative SDE's forward perturbation draws through ``base.philox()``: hand it the trainer's stream."""
+    tr.msgm = tr.base.kind != L.SDE_SGM
+    if tr.msgm:
+        tr.base.rng = tr.rng
+        tr.T_host = tr.base.T_float()
+        tr.u = torch.empty(tr.B, dtype=torch.float32, device=tr.dev)
+
+
 class MLPScoreTrainer(_TrainerState):
-    """SGM + MLP (configs C1/C2).  ``x`` is this rank's shard (B_local, d) and
-    stays resident; each ``step()`` draws fresh (t, eps, v) on the device."""
+    """MLP score net (configs C1/C2) under the additive (SGMsde) or the multiplicative SDE (MSGMsde, dense or sparse
+    tensor: MSGM_higherDim.py:733-746).  ``x`` is this rank's shard (B_local, d) and stays resident; each ``step()`` draws
+    fresh (t, eps | forward-SDE noise, v) on the device."""
 
     def __init__(self, gen_sde, batch_local: int, lr: float = 1e-3, world: int = 1, use_graph: bool = True,
                  seed: int = 0, row_base: int = 0):
         from .NN import MLP
         net, base = gen_sde.a, gen_sde.base_sde
-        if not (isinstance(net, MLP) and base.kind == L.SDE_SGM):
-            raise MsgmError("MLPScoreTrainer is built for MLP + SGMsde")
+        if not isinstance(net, MLP):
+            raise MsgmError("MLPScoreTrainer is built for the MLP score net (SGMsde or MSGMsde)")
         self.gen_sde, self.net, self.base = gen_sde, net, base
         self.dev = next(net.parameters()).device
         self.B, self.d, self.world = batch_local, net.input_dim, world
@@ -119,6 +148,7 @@ class MLPScoreTrainer(_TrainerState):
         self.inv_batch = 1.0 / (batch_local * world)        # mean over the GLOBAL batch
         self.graph = None
         self.use_graph = use_graph and not parallel.multi(world)
+        _adopt_stream(self)
 
     def _body(self):
         """3 launches on one GPU: prep (K1 + probe + step tick) -> fused SSM kernel ->
@@ -126,10 +156,18 @@ class MLPScoreTrainer(_TrainerState):
         reduction and Adam are split around the RCCL all-reduce of the flat bucket."""
         import ctypes as C
         lib, s = ops.lib(), ops.stream()
-        ops.check(lib.msgm_ssm_prep(self.x.data_ptr(), self.y.data_ptr(), self.t.data_ptr(), self.vp.data_ptr(), self.B,
-                                    self.d, self.st, self.rng.ptr(), self.step_dev.data_ptr(), s), "msgm_ssm_prep")
+        if self.msgm:
+            # multiplicative SDE: no closed-form perturbation — masked RK4 on the device, then the general loss form
+            y, t, vp, uu, cst = _msgm_draws(self)
+            ops.counter_inc(self.step_dev)
+            pu, pc, adv = uu.data_ptr(), cst.data_ptr(), None       # the draws advanced the stream themselves
+            self._live = (y, vp, uu, cst)
+        else:
+            ops.check(lib.msgm_ssm_prep(self.x.data_ptr(), self.y.data_ptr(), self.t.data_ptr(), self.vp.data_ptr(), self.B,
+                                        self.d, self.st, self.rng.ptr(), self.step_dev.data_ptr(), s), "msgm_ssm_prep")
+            y, t, vp, pu, pc, adv = self.y, self.t, self.vp, None, None, self.rng.ptr()
         nsl = C.c_int32(0)
-        ops.check(lib.msgm_mlp_ssm_partial(self.P, self.y.data_ptr(), self.t.data_ptr(), self.vp.data_ptr(), None, None, self.B,
+        ops.check(lib.msgm_mlp_ssm_partial(self.P, y.data_ptr(), t.data_ptr(), vp.data_ptr(), pu, pc, self.B,
                                            self.st, self.inv_batch, None, self.ws.data_ptr(), self.ws.numel() * 4,
                                            C.byref(nsl), s), "msgm_mlp_ssm_partial")
         pre = int(self.net.pre is not None)
@@ -137,13 +175,14 @@ class MLPScoreTrainer(_TrainerState):
             ops.check(lib.msgm_mlp_ssm_reduce_adam(self.d, pre, self.ws.data_ptr(), nsl.value, self.inv_batch,
                                                    self.gflat.data_ptr(), self.loss.data_ptr(), self.flat.data_ptr(),
                                                    self.m.data_ptr(), self.v.data_ptr(), self.lr, 0.9, 0.999, 1e-8,
-                                                   self.step_dev.data_ptr(), self.rng.ptr(), s), "msgm_mlp_ssm_reduce_adam")
+                                                   self.step_dev.data_ptr(), adv, s), "msgm_mlp_ssm_reduce_adam")
         else:
             ops.check(lib.msgm_mlp_ssm_reduce(self.d, pre, self.ws.data_ptr(), nsl.value, self.inv_batch,
                                               self.gflat.data_ptr(), self.loss.data_ptr(), s), "msgm_mlp_ssm_reduce")
             parallel.allreduce_sum_(self.gbuf)    # grads and loss already carry 1/global_batch
             ops.adam_step(self.flat, self.gflat, self.m, self.v, step=0, lr=self.lr, step_dev=self.step_dev)
-            self.rng.advance(1)
+            if not self.msgm:
+                self.rng.advance(1)
 
     def capture(self):
         """One ordinary step on a side stream (loads code objects; it is a REAL training step: parameters, Adam state,
@@ -173,7 +212,8 @@ class MLPScoreTrainer(_TrainerState):
 
 
 class UNetScoreTrainer(_TrainerState):
-    """SGM + a U-Net score net exposing ``ssm_grad`` (configs C3/C4): prep kernel
+    """A U-Net score net exposing ``ssm_grad`` (configs C3/C4) under the additive SDE or the multiplicative one (the
+    paper's model: MSGMsde, sparse tensor for d >= 256, nsf forward RK4 steps — MSGM_higherDim.py:733-746): prep kernel
     (K1 + probe) -> dual-number forward / hand-written backward -> [RCCL all-reduce
     of the flat gradient bucket] -> fused Adam on the flat parameter bucket.
 
@@ -185,8 +225,8 @@ class UNetScoreTrainer(_TrainerState):
     def __init__(self, gen_sde, batch_local: int, dim: int, lr: float = 1e-4, world: int = 1, seed: int = 0,
                  use_graph: Optional[bool] = None, row_base: int = 0):
         net, base = gen_sde.a, gen_sde.base_sde
-        if not hasattr(net, "ssm_grad") or base.kind != L.SDE_SGM:
-            raise MsgmError("UNetScoreTrainer needs a HIP U-Net score net and an SGMsde")
+        if not hasattr(net, "ssm_grad"):
+            raise MsgmError("UNetScoreTrainer needs a HIP U-Net score net (SGMsde or MSGMsde)")
         self.gen_sde, self.net, self.base = gen_sde, net, base
         self.dev = next(net.parameters()).device
         self.B, self.d, self.world, self.lr = batch_local, dim, world, lr
@@ -207,6 +247,7 @@ class UNetScoreTrainer(_TrainerState):
         # all-reduce and Adam follow eagerly on the same stream
         self.use_graph = True if use_graph is None else bool(use_graph)
         self.graph = None
+        _adopt_stream(self)
 
     def set_data(self, x):
         self.x.copy_(x)
@@ -214,10 +255,15 @@ class UNetScoreTrainer(_TrainerState):
     def _fwd_bwd(self):
         """Everything before the collective; leaves [grads | loss] (already x 1/global_batch) in ``gbuf``."""
         lib, s = ops.lib(), ops.stream()
-        ops.check(lib.msgm_ssm_prep(self.x.data_ptr(), self.y.data_ptr(), self.t.data_ptr(), self.vp.data_ptr(), self.B,
-                                    self.d, self.st, self.rng.ptr(), self.step_dev.data_ptr(), s), "msgm_ssm_prep")
-        u, cst = ops.ssm_terms(self.y, self.vp, self.t, self.st)
-        per = self.net.ssm_grad(self.y, self.t, self.vp, u, cst, self.inv_batch)
+        if self.msgm:
+            y, t, vp, u, cst = _msgm_draws(self)
+            ops.counter_inc(self.step_dev)
+        else:
+            ops.check(lib.msgm_ssm_prep(self.x.data_ptr(), self.y.data_ptr(), self.t.data_ptr(), self.vp.data_ptr(), self.B,
+                                        self.d, self.st, self.rng.ptr(), self.step_dev.data_ptr(), s), "msgm_ssm_prep")
+            y, t, vp = self.y, self.t, self.vp
+            u, cst = ops.ssm_terms(y, vp, t, self.st)
+        per = self.net.ssm_grad(y, t, vp, u, cst, self.inv_batch)
         flat, gflat = self.net.flat_parameters()
         if flat.data_ptr() != self.flat.data_ptr() or gflat.data_ptr() != self.gbuf.data_ptr():
             raise MsgmError("the flat parameter bucket moved; rebuild the trainer")
@@ -227,7 +273,8 @@ class UNetScoreTrainer(_TrainerState):
 
     def _update(self):
         ops.adam_step(self.flat, self.gbuf[: self.n], self.m, self.v, step=0, lr=self.lr, step_dev=self.step_dev)
-        self.rng.advance(1)
+        if not self.msgm:                        # the multiplicative SDE's draws advance the stream as they go
+            self.rng.advance(1)
 
     def _collective_update(self):
         if parallel.multi(self.world):

@@ -171,3 +171,55 @@ def test_unet2d_ssm_reference_init_fixture(tag, S_):
     per.mean().backward()
     grads = {k: p.grad.cpu() for k, p in gen.a.named_parameters()}
     check_digest(g, tag, grads, "a.", 3e-5)
+
+
+def _msgm_trainer(kind, use_graph, seed=11):
+    """(trainer, gen) for the multiplicative SDE: 'sparse' = UNet1D (d = 128, NormalizeLogRadius as the driver uses with
+    MSGM, MSGM_higherDim.py:704-725) on the sparse rotation tensor, 'dense' = MLP (d = 6) on the dense rank-3 tensor."""
+    from sdeflow_light_amd.train import MLPScoreTrainer, UNetScoreTrainer
+    torch.manual_seed(3)
+    if kind == "sparse":
+        from sdeflow_light_amd.NNUnet1D import UNet1D
+        net, B, d = UNet1D(input_dim=128, base_channels=16, channel_mults=(1, 2), emb_dim=32, premodule="NormalizeLogRadius"), 8, 128
+        gen = make_gen("sparse", net, n=d, nsf=4)
+        tr = UNetScoreTrainer(gen, B, d, lr=1e-3, seed=seed, use_graph=use_graph)
+    else:
+        from sdeflow_light_amd.NN import MLP
+        net, B, d = MLP(6, premodule="NormalizeLogRadius"), 256, 6
+        gen = make_gen("dense", net, n=d, nsf=4)
+        tr = MLPScoreTrainer(gen, B, lr=1e-3, seed=seed, use_graph=use_graph)
+    torch.manual_seed(5)
+    tr.set_data(torch.randn(B, d, device=DEV) * 1.5)
+    return tr, gen
+
+
+@pytest.mark.parametrize("kind", ["sparse", "dense"])
+def test_msgm_trainer_graph_equals_eager_and_matches_ssm(kind):
+    """the multiplicative SDE (SDEs.py:78-132,221-509; MSGM_higherDim.py:733-746) through the graph-captured
+    trainers.  (i) the captured step holds kernel nodes only and replays to the eager run's parameters BIT FOR BIT;
+    (ii) the trainer's first step computes the loss ``PluginReverseSDE.ssm`` (pinned against the reference by the g14 /
+    g08 fixtures) computes from the same stream state — same draws, same kernels."""
+    out = {}
+    for use_graph in (False, True):
+        tr, gen = _msgm_trainer(kind, use_graph)
+        st0 = tr.rng.state.clone()
+        x = tr.x.clone()
+        p0 = tr.flat.clone()
+        losses = [float(tr.step()) for _ in range(4)]
+        out[use_graph] = (losses, tr.flat.clone(), tr.rng.state.clone())
+        if use_graph:
+            assert set(ops.graph_node_kinds(tr.graph)) == {"kernel"}
+        else:
+            # (ii) replay the first step through the reference-surface entry point on a twin with the same start state
+            tr2, gen2 = _msgm_trainer(kind, False)
+            assert torch.equal(tr2.flat, p0) and torch.equal(tr2.rng.state, st0)
+            gen2.zero_grad()
+            per = gen2.ssm(x)
+            loss_ssm = float(per.mean())
+            print(f"MSGM {kind}: trainer step-1 loss {losses[0]:.6f} vs PluginReverseSDE.ssm {loss_ssm:.6f}")
+            assert abs(losses[0] - loss_ssm) <= 2e-6 * max(1.0, abs(loss_ssm))
+            nsf = gen2.base_sde.num_steps_forward
+            assert int(tr2.rng.state[1]) - int(st0[1]) == 2 * nsf + 3            # forward perturbation + the probe
+    (l0, f0, s0), (l1, f1, s1) = out[False], out[True]
+    assert l0 == l1 and torch.equal(f0, f1) and torch.equal(s0, s1)
+    assert all(v == v for v in l0) and float((f0 - p0).abs().max()) > 0
