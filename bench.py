@@ -13,10 +13,13 @@ over the ranks, fp32.
 On the same JSON line:
   sample_steps_per_s  C5: reverse-SDE Euler-Maruyama steps/s for 8192 samples of the same net (rows split over the
                       ranks, chunks of <= 4096 rows, ONE hipGraph-captured step replayed --sample-steps times per chunk);
-  roofline            the dominant kernel of the C4 step, timed live with per-launch HIP events on the launch stream
-                      (+ the other heavy kernels and the whole-step fraction);
-  cpu_baseline        the CPU oracle on this host's cores at a reduced batch (rank 0, N=1 only);
-  extra               C2 (MLP, B=65536) and C3 (UNet1D L=1024, B=4096) short legs (N=1 only).
+  roofline            the kernel family with the LARGEST MEASURED SHARE of the C4 step: one eager step of the same kernels
+                      with every launch bracketed by HIP events on the launch stream (StepProfiler), algorithmic FLOPs from
+                      each call's own geometry; step_profile lists every family (share, TFLOP/s or GB/s, fraction of peak);
+  roofline_hbm        the HBM-bound kernels (EM stage, perturbation, prep, Adam, GroupNorm) as GB/s of 8 TB/s and us/launch;
+  cpu_baseline        the CPU oracle on this host's cores at batch 8 incl. Adam, scaled to 256 (rank 0, N=1 only);
+  extra               C2 (MLP, B=65536), C3 (UNet1D L=1024, B=4096) and MSGM (multiplicative SDE: UNet1D d=1024 and the C4
+                      net at d=12288, sparse tensor, nsf=16) short legs (N=1 only).
 --workload c2|c3 selects those configs as the main line instead (c5 = sampling only).
 
 `--gpus N` with N > 1 and no torchrun environment: this process touches no GPU and starts N ranks itself
@@ -69,12 +72,38 @@ def launch_ranks(a) -> int:
 
 
 # ----------------------------------------------------------------------------------------------------- helpers
+_T0 = time.perf_counter()
+
+
+def log(msg: str) -> None:
+    """Progress on stderr (rank 0 prints the ONE JSON line on stdout at the end)."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.perf_counter() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def host_cores() -> int:
+    """CPU threads this process can actually use: the scheduler affinity, cut down to the cgroup CPU quota when there is one
+    (a GPU box hands each GPU a 16-CPU share of a much larger host through the quota, not the affinity mask: 200+ threads
+    on a 16-CPU quota thrash) and to 64 (more threads do not speed a batch-8 U-Net step up)."""
     try:
         avail = len(os.sched_getaffinity(0))
     except Exception:
         avail = os.cpu_count() or 1
-    return min(avail, 16)             # a 1-GPU box is given a 16-CPU share; more threads only oversubscribe
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(math.ceil(int(q) / int(per))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = max(1, int(math.ceil(q / per)))
+        except Exception:
+            quota = None
+    n = min(avail, quota) if quota else min(avail, 16)       # no quota visible: the documented 16-CPU share of a 1-GPU box
+    return max(1, min(n, 64))
 
 
 def timed_blocks(step_fn, steps, warmup, dev, min_seconds=1.0, max_blocks=50):
@@ -196,36 +225,43 @@ def cpu_baseline_mlp(budget_s=8.0):
             "sample": f"{n} full C2 train steps (B=65536, MLP d=2, double-backward SSM + Adam) on the CPU oracle in {dt:.1f} s"}
 
 
-def cpu_baseline_unet(workload, budget_s=15.0):
-    """CPU oracle at a reduced batch, scaled linearly to the config batch."""
+def cpu_baseline_unet(workload, budget_s=20.0):
+    """CPU oracle at the reduced batch SURVEY.md §8(d) / BASELINE.md §3 prescribe (C3: 64 rows -> here 8, C4: 8 samples),
+    the whole training step as upstream runs it — double-backward SSM loss + Adam (MSGM_higherDim.py:803-809) — timed on
+    this host's cores and scaled linearly to the config batch."""
     import torch
     from oracle import sde_ref as S, nets_ref as N, ssm_ref as LR
-    from oracle.det_params import det_state_dict
+    from oracle.det_params import init_like_state_dict
     from oracle.shapes import unet1d_shapes, unet2d_shapes
     torch.set_num_threads(host_cores())
     sp = S.SdeSpec()
     if workload == "c3":
         b, d, full = 8, 1024, 4096
-        p = det_state_dict(unet1d_shapes(1024, None))
+        p = init_like_state_dict(unet1d_shapes(1024, None))
         score = lambda prm, yy, tt: N.unet1d_forward(prm, yy, tt, None)
     else:
-        b, d, full = 1, 3 * 64 * 64, 256
+        b, d, full = 8, 3 * 64 * 64, 256
         cfg = N.UNet2DConfig(in_channels=3, out_channels=3, in_space=64)
-        p = det_state_dict(unet2d_shapes(cfg))
+        p = init_like_state_dict(unet2d_shapes(cfg))
         score = lambda prm, yy, tt: N.image_to_flat(N.unet2d_core_forward(prm, N.flat_to_image(yy, 64, 64, "F", 3), tt.reshape(-1), cfg), "F")
+    m = {k: torch.zeros_like(v) for k, v in p.items()}
+    vv = {k: torch.zeros_like(v) for k, v in p.items()}
     x = torch.randn(b, d)
 
-    def one():
+    def one(step):
         t = S.clamp_time(sp, torch.rand(b, 1)); y = S.vp_perturb(sp, t, x, torch.randn(b, d))
         v = S.rademacher_from_uniform(torch.rand(b, d))
-        LR.ssm_mean_and_grads(sp, score, p, t, y, v, form="double_backward")
-    one()
+        _, _, g = LR.ssm_mean_and_grads(sp, score, p, t, y, v, form="double_backward")
+        for k in p:
+            p[k], m[k], vv[k] = LR.adam_step(p[k], g[k], m[k], vv[k], step, lr=1e-4)
+    one(1)
     n, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < budget_s:
-        one(); n += 1
+        n += 1
+        one(n + 1)
     dt = (time.perf_counter() - t0) / n
     return {"value": 1.0 / (dt * full / b), "unit": f"train_steps/s (B={full})", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} oracle train steps at batch {b} ({dt:.2f} s each, double-backward SSM as upstream, no Adam), "
+            "sample": f"{n} oracle train steps at batch {b} ({dt:.2f} s each: double-backward SSM as upstream + Adam), "
                       f"scaled linearly to batch {full}"}
 
 
@@ -325,102 +361,253 @@ def leg_mlp(a, rank, world, dev, steps=200, sample_steps=200):
     return out
 
 
-# ----------------------------------------------------------------------------------------------------- kernel probes
-def kernel_probes(dev, Bp):
-    """The heavy kernels of the C4 step at their C4 shapes (dual batch N = 2*Bp), each launch bracketed by HIP events
-    on the launch stream.  FLOPs per launch are the algorithmic ones (2*MACs of the product(s) as written upstream)."""
+# ----------------------------------------------------------------------------------------------------- step profile
+PEAK_HBM_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E peak 8 TB/s (6.3 TB/s measured float4 copy)
+
+
+class StepProfiler:
+    """Per-launch timing of ONE eager training step, measured in this run: every C-ABI call of the step is bracketed by its
+    own pair of HIP events on the launch stream, and calls are grouped into kernel families with their ALGORITHMIC work —
+    FLOPs as written upstream (2*MACs from the call's own geometry arguments; attention: 6 / 12 products of 2 T^2 C per
+    sample forward / backward) or bytes (GroupNorm: one read + one write of the dual tensor forward, two reads + one write
+    backward).  `roofline` is the family with the largest measured share — nothing is typed in."""
+
+    def __init__(self):
+        self.recs = []
+
+    def _family(self, name, args):
+        from sdeflow_light_amd import _lib as L
+        g = args[0] if args and isinstance(args[0], L.ConvGeomT) else None
+        if name in ("msgm_conv_forward", "msgm_conv_forward_fused") and g is not None:
+            cin = int(args[2]) + (int(args[4]) if args[3] else 0)
+            flop = 2.0 * g.KH * g.KW * cin * int(args[6]) * g.N * g.Ho * g.Wo
+            k3 = g.KH * g.KW == 9 or (g.KH == 1 and g.KW == 3)
+            same = g.strideH == 1 and g.strideW == 1
+            if k3 and same and cin >= 16 and int(args[6]) >= 16:
+                return "3x3 stride-1 conv forward + dgrad (k_conv_tile; msgm_conv_forward_fused)", "mfma", flop
+            if g.KH * g.KW == 1:
+                return "1x1 conv / linear forward + dgrad (k_conv1x1)", "mfma", flop
+            return "other conv forward + dgrad (strided / 3-channel in-out)", "mfma", flop
+        if name in ("msgm_conv_wgrad_slabs", "msgm_conv_wgrad_det", "msgm_conv_wgrad") and g is not None:
+            flop = 2.0 * g.KH * g.KW * int(args[3]) * int(args[6]) * g.N * g.Ho * g.Wo
+            if g.KH * g.KW == 9 and g.strideH == 1:
+                return "3x3 stride-1 conv wgrad (k_wgrad_tile; msgm_conv_wgrad_slabs)", "mfma", flop
+            return "1x1 / strided conv wgrad", "mfma", flop
+        if name == "msgm_attention_dual_forward":
+            Bp, T, C = int(args[3]), int(args[4]), int(args[5])
+            return f"dual attention forward C={C} (k_attn_dual_fwd)", "mfma", 6 * 2.0 * T * T * C * Bp
+        if name == "msgm_attention_dual_backward":
+            Bp, T, C = int(args[5]), int(args[6]), int(args[7])
+            return f"dual attention backward C={C} (delta + k_attn_dual_bwd + slab reduce)", "mfma", 12 * 2.0 * T * T * C * Bp
+        if name in ("msgm_groupnorm_dual_forward", "msgm_groupnorm_dual_forward2"):
+            if name.endswith("2"):
+                Bp, P, C = int(args[8]), int(args[9]), int(args[1]) + int(args[3])
+            else:
+                Bp, P, C = int(args[5]), int(args[6]), int(args[7])
+            return "GroupNorm(+SiLU) dual forward (2 launches)", "hbm", 2 * 2.0 * Bp * P * C * 4
+        if name in ("msgm_groupnorm_dual_backward", "msgm_groupnorm_dual_backward2", "msgm_groupnorm_dual_backward_slots"):
+            if name.endswith("_slots"):
+                Bp, P, C = int(args[12]), int(args[13]), int(args[1]) + int(args[3])
+            elif name.endswith("2"):
+                Bp, P, C = int(args[12]), int(args[13]), int(args[1]) + int(args[3])
+            else:
+                Bp, P, C = int(args[8]), int(args[9]), int(args[10])
+            return "GroupNorm(+SiLU) dual backward (2 launches)", "hbm", 3 * 2.0 * Bp * P * C * 4
+        if name == "msgm_adam_step":
+            return "Adam (k_adam)", "hbm", 28.0 * int(args[4])
+        return "other (layout glue, embedding MLPs, reductions, loss)", None, 0.0
+
+    def install(self):
+        import torch
+        from sdeflow_light_amd import _lib as L
+        lib = L.lib()
+        self._orig = {}
+        for name in L.SIGNATURES:
+            fn = getattr(lib, name)
+            if fn.restype is not __import__("ctypes").c_int or name in ("msgm_version",):
+                continue
+            self._orig[name] = fn
+
+            def wrap(*args, _fn=fn, _name=name):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = _fn(*args)
+                e1.record()
+                self.recs.append((_name, self._family(_name, args), e0, e1))
+                return rc
+            setattr(lib, name, wrap)
+        self._lib = lib
+
+    def remove(self):
+        for name, fn in self._orig.items():
+            setattr(self._lib, name, fn)
+
+    def summary(self, dev):
+        import torch
+        torch.cuda.synchronize(dev)
+        fam = {}
+        total = 0.0
+        for name, (family, bound, work), e0, e1 in self.recs:
+            ms = e0.elapsed_time(e1)
+            total += ms
+            f = fam.setdefault(family, {"family": family, "bound": bound, "calls": 0, "ms": 0.0, "work": 0.0})
+            f["calls"] += 1; f["ms"] += ms; f["work"] += work
+        out = []
+        for f in sorted(fam.values(), key=lambda v: -v["ms"]):
+            r = {"family": f["family"], "calls": f["calls"], "ms": round(f["ms"], 3), "share_of_step": round(f["ms"] / total, 4)}
+            if f["bound"] == "mfma":
+                tf = f["work"] / (f["ms"] * 1e-3) / 1e12
+                r.update(bound="mfma", achieved=tf, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=tf / PEAK_F32_MFMA_TFLOPS,
+                         flop=f["work"])
+            elif f["bound"] == "hbm":
+                gbs = f["work"] / (f["ms"] * 1e-3) / 1e9
+                r.update(bound="hbm", achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s", frac=gbs / PEAK_HBM_GBS, bytes=f["work"])
+            out.append(r)
+        return out, total
+
+
+def leg_step_profile(dev, Bp):
+    """One EAGER C4 step (same kernels and shapes as the graph-replayed one) with every launch timed: the measured shares
+    and the as-written rate of each kernel family.  Small launches include the host's launch gap (eager), so the sum is a
+    few percent above the graph-replayed step; the MFMA families are >= 95 % of it and are not affected."""
     import torch
-    from sdeflow_light_amd import ops
-    N = 2 * Bp
-    probes = []
+    from sdeflow_light_amd.train import UNetScoreTrainer
+    from sdeflow_light_amd.data import random_images
+    gen, d = build_unet("c4", dev)
+    tr = UNetScoreTrainer(gen, Bp, d, lr=1e-4, world=1, seed=1, use_graph=False)
+    tr.set_data(random_images(Bp, seed=1234, device=dev))
+    for _ in range(2):
+        tr.step()
+    torch.cuda.synchronize(dev)
+    sp = StepProfiler()
+    sp.install()
+    try:
+        tr.step()
+        fams, total = sp.summary(dev)
+    finally:
+        sp.remove()
+    del tr, gen
+    return fams, total
 
-    def conv(H, Ci, Co):
-        x = torch.randn(N * H * H * Ci, device=dev)
-        Wp = torch.randn(9 * ops.pad16(Co) * ops.pad16(Ci), device=dev) * 0.05
-        out = torch.empty(N * H * H * Co, device=dev)
-        geom = ops.conv_geom(N, H, H, H, H, 3, 3, 1, 1)
-        return (f"k_conv_tile 3x3 {Ci}->{Co} @ {H}x{H}, dual batch {N} (msgm_conv_forward)", 2 * 9 * Ci * Co * N * H * H,
-                lambda: ops.conv_forward(geom, x, Ci, Wp, Co, out, n_bias=Bp), (x, Wp, out))
 
-    def wgrad(H, Ci, Co):
-        x = torch.randn(N * H * H * Ci, device=dev)
-        gy = torch.randn(N * H * H * Co, device=dev)
-        dWp = torch.zeros(9 * ops.pad16(Co) * ops.pad16(Ci), device=dev)
-        geom = ops.conv_geom(N, H, H, H, H, 3, 3, 1, 1)
-        return (f"k_wgrad_tile 3x3 {Ci}->{Co} @ {H}x{H}, dual batch {N} (msgm_conv_wgrad)", 2 * 9 * Ci * Co * N * H * H,
-                lambda: ops.conv_wgrad(geom, gy, x, Ci, 0, dWp, Co, ops.pad16(Co), ops.pad16(Ci)), (x, gy, dWp))
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of a kernel from the PMC passes committed under profiles/r03 (rocprofv3 --pmc FETCH_SIZE and
+    WRITE_SIZE in separate runs, 2 x FETCH + WRITE as MI355X_MICROARCH.md prescribes for gfx950); None if absent."""
+    pj = os.path.join(ROOT, "profiles", "r03", "pmc_c4_step.json")
+    try:
+        ks = json.load(open(pj))["kernels"]
+    except Exception:
+        return None, None
+    hits = [v for k, v in ks.items() if k.startswith(kernel_prefix) and v.get("hbm_bytes")]
+    if not hits:
+        return None, None
+    n = sum(v.get("launches", 1) for v in hits)
+    return sum(v["hbm_bytes"] * v.get("launches", 1) for v in hits) / n, "profiles/r03/pmc_c4_step.json (PMC passes of the C4 step, not measured in this run)"
 
-    def attn(T, C):
-        """Training attention at the C4 block shape.  Algorithmic products as written upstream (model/unet.py:236-250
-        under the dual-number step): forward 6 x 2T^2C (S, 2 for Sdot, P v, Pdot v, P vdot), backward 12 x 2T^2C; the
-        fused backward EXECUTES 15 (it recomputes S / Sdot instead of reading (B,T,T) tensors) — not counted."""
-        qkv = torch.randn(N * T * 3 * C, device=dev)
-        s2 = 1.0 / math.sqrt(C)
-        att, stats = ops.attention_dual_forward(qkv, Bp, T, C, s2)
-        datt = torch.randn(N * T * C, device=dev)
-        ops.attention_dual_backward(qkv, att, datt, stats, Bp, T, C, s2)         # allocates the slab workspace
-        prod = 2 * T * T * C * Bp
-        return [(f"k_attn_dual_bwd<{C // 16}> T={T} C={C}, batch {Bp} (msgm_attention_dual_backward: delta + main + slab reduce)",
-                 12 * prod, lambda: ops.attention_dual_backward(qkv, att, datt, stats, Bp, T, C, s2), (qkv, att, datt, stats)),
-                (f"k_attn_dual_fwd<{C // 16}> T={T} C={C}, batch {Bp} (msgm_attention_dual_forward)", 6 * prod,
-                 lambda: ops.attention_dual_forward(qkv, Bp, T, C, s2), (qkv,))]
 
-    # shares of the C4 step in the committed rocprofv3 kernel stats (profiles/r02/c4_b256_train_kernel_stats_v6.csv, training
-    # steps only): the fused attention backward CALL (main kernel 15.9 % + slab reduce 2.0 % + delta 0.2 %) and the 3x3
-    # halo-tile conv in its 64-channel form (19.3 % over all its shapes, forward and dgrad; + 7.8 % in the 32-channel form)
-    # are the two largest, then the tiled 3x3 wgrad (13.7 %) and the attention forward (6.6 %).  The attention backward is
-    # reported as THE roofline entry: it is one shape, so its live timing can be checked against the rocprofv3 average.
-    probes += attn(1024, 64)
-    probes.append(conv(32, 64, 64))
-    probes.append(wgrad(32, 64, 64))
-    share = {"k_attn_dual_bwd": 0.180, "k_attn_dual_fwd": 0.066, "k_conv_tile": 0.193, "k_wgrad_tile": 0.137}
-    pmc = {}
-    pj = os.path.join(ROOT, "profiles", "r02", "pmc_attention_bp256.json")
-    if os.path.exists(pj):
-        try:
-            pmc = json.load(open(pj))["kernels"]
-        except Exception:
-            pmc = {}
-    pmc2 = {}
-    pj2 = os.path.join(ROOT, "profiles", "r02", "pmc_conv_probes.json")     # the conv / wgrad probe shape (tools/probe_conv.py)
-    if os.path.exists(pj2):
-        try:
-            pmc2 = json.load(open(pj2))["kernels"]
-        except Exception:
-            pmc2 = {}
+def hbm_rooflines(dev):
+    """The HBM-bound kernels of the path timed live: algorithmic bytes / time against the 8 TB/s peak at the
+    C4 / C5 sizes, and microseconds per launch at the C2 size (512 KB tensors: latency-bound, report us)."""
+    import torch
+    from sdeflow_light_amd import ops, _lib as L
+    st = L.sde_struct(0, 0.1, 20.0, 1.0, 1e-3)
+    rng = L.PhiloxState(7, dev)
     res = []
-    for name, flop, fn, keep in probes:
-        tk = time_kernel_events(fn, 20, dev)
-        r = {"kernel": name, "bound": "mfma", "achieved": flop / tk / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
-             "unit": "TFLOP/s", "frac": flop / tk / 1e12 / PEAK_F32_MFMA_TFLOPS, "kernel_ms": tk * 1e3,
-             "flop_per_launch": flop, "traffic": None,
-             "share_of_c4_step": next((v for k, v in share.items() if name.startswith(k)), None)}
-        if name.startswith("k_attn_dual_bwd") and Bp == 256:
-            r["executed_tflops"] = flop * 15 / 12 / tk / 1e12     # 15 products run (S / Sdot recomputed), 12 are algorithmic
-            t = [v.get("hbm_bytes") for k, v in pmc.items() if k.startswith(("void k_attn_dual_bwd<4> grid=2097152", "k_attn_dq_reduce grid=4194304",
-                                                                              "k_attn_dual_delta grid=4194304"))]
-            if len(t) == 3 and all(t):
-                r["traffic"] = float(sum(t))
-                r["traffic_source"] = ("profiles/r02/pmc_attention_bp256.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                                       "tools/bench_attn.py, 2 x FETCH + WRITE, the three launches of the call; not measured in this run); "
-                                       "algorithmic bytes 0.81 GB (q, k, v, o, their tangents and cotangents once) — the rest is the 2.15 GB of "
-                                       "query-gradient slabs written and read back")
-        if name.startswith("k_attn_dual_fwd") and Bp == 256:
-            t = [v.get("hbm_bytes") for k, v in pmc.items() if k.startswith("void k_attn_dual_fwd<4, 1, 32> grid=1048576")]
-            if t and t[0]:
-                r["traffic"] = float(t[0])
-                r["traffic_source"] = "profiles/r02/pmc_attention_bp256.json (PMC pass, not measured in this run); algorithmic 0.54 GB"
-        if name.startswith(("k_conv_tile", "k_wgrad_tile")) and Bp == 256:
-            key = "void k_conv_tile<16, 16, 4, 3, 4, false> grid=524288" if name.startswith("k_conv_tile") else "void k_wgrad_tile<8, 16, 9, false> grid=262144"
-            t = pmc2.get(key, {}).get("hbm_bytes")
-            if t:
-                r["traffic"] = float(t)
-                r["traffic_source"] = ("profiles/r02/pmc_conv_probes.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/probe_conv.py, "
-                                       "2 x FETCH + WRITE; not measured in this run); algorithmic 0.27 GB (input + output / gradient once; the "
-                                       "wgrad reads each operand once per 32-channel block of the other: 2x at 64 channels)")
-        res.append(r)
-        del keep
+
+    def add(name, byts, fn, note):
+        t = time_kernel_events(fn, 30, dev)
+        res.append({"kernel": name, "bound": "hbm", "achieved": byts / t / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": byts / t / 1e9 / PEAK_HBM_GBS, "us_per_launch": t * 1e6, "algorithmic_bytes": byts, "size": note})
+    for B, d, tag in ((4096, 12288, "C5 chunk 4096 x 12288"), (65536, 2, "C2 65536 x 2 (latency-bound: read us_per_launch)")):
+        n = B * d
+        x, a = torch.randn(B, d, device=dev), torch.randn(B, d, device=dev)
+        y, v = torch.empty_like(x), torch.empty_like(x)
+        t = torch.empty(B, device=dev)
+        step = torch.zeros(1, dtype=torch.int64, device=dev)
+        add("k_stage_diag_flat (msgm_sde_stage, EM step)", 12 * n,
+            lambda: ops.sde_stage(x, x, 1.0, x, a, st, L.PROC_REVERSE, False, 0.5, 1e-3, 0.0, rng=rng, rng_step=1), tag)
+        add("k_perturb_vp (msgm_perturb_vp)", 8 * n, lambda: ops.perturb_vp(x, st, rng=rng), tag)
+        lib = ops.lib()
+        add("k_ssm_prep (msgm_ssm_prep: perturb + probe + tick)", 16 * n,
+            lambda: ops.check(lib.msgm_ssm_prep(x.data_ptr(), y.data_ptr(), t.data_ptr(), v.data_ptr(), B, d, st, rng.ptr(),
+                                                step.data_ptr(), ops.stream()), "msgm_ssm_prep"), tag)
+        del x, a, y, v
+    npar = 4023233 + 9 * 3 * 32 * 2          # the C4 net (3-channel in / out convs)
+    p, g, m, vv = (torch.randn(npar, device=dev) for _ in range(4)); vv.abs_()
+    add("k_adam (msgm_adam_step)", 28 * npar, lambda: ops.adam_step(p, g, m, vv, step=3, lr=1e-4), "C4 net, 4.02 M parameters")
+    del p, g, m, vv
+    Bp, P, C = 256, 64 * 64, 32               # the largest GroupNorm of the C4 step
+    xg = torch.randn(2 * Bp * P * C, device=dev)
+    ga, be = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    og = torch.empty_like(xg)
+    stats = torch.empty(Bp * 32 * 4, device=dev)
+    add("k_gn_fwd_reduce + k_gn_fwd_apply (msgm_groupnorm_dual_forward)", 2 * 4 * xg.numel(),
+        lambda: ops.groupnorm_dual_forward(xg, ga, be, Bp, P, C, 32, True, True, stats=stats, out=og), "C4 64x64x32, dual batch 512")
+    dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    gg = torch.randn_like(xg)
+    add("k_gn_bwd_reduce + param reduce + k_gn_bwd_apply (msgm_groupnorm_dual_backward)", 3 * 4 * xg.numel(),
+        lambda: ops.groupnorm_dual_backward(xg, ga, be, stats, gg, dg, db, Bp, P, C, 32, True, gx=og), "C4 64x64x32, dual batch 512")
     return res
+
+
+# ----------------------------------------------------------------------------------------------------- MSGM leg
+def leg_msgm(dev, steps=5, warmup=2):
+    """The paper's model — the MULTIPLICATIVE SDE (MSGMsde, sparse rotation tensor for d >= 256, nsf = 16 forward RK4 steps,
+    NormalizeLogRadius conditioning: MSGM_higherDim.py:704-746) — through the graph-captured trainers, reported separately
+    as SURVEY.md §8(d) asks: UNet1D d = 1024 (batch 4096) and the C4 net at d = 12288 (batch 256), plus the forward-SDE
+    stage kernel's algorithmic HBM rate (12 B / element / stage)."""
+    import torch
+    from sdeflow_light_amd import ops, _lib as L
+    from sdeflow_light_amd.SDEs import MSGMsde, PluginReverseSDE
+    from sdeflow_light_amd.train import UNetScoreTrainer
+    from sdeflow_light_amd.data import signals_1d, random_images
+    out = {}
+    for tag in ("unet1d_d1024", "unet2d_d12288"):
+        torch.manual_seed(0)
+        if tag == "unet1d_d1024":
+            from sdeflow_light_amd.NNUnet1D import UNet1D
+            B, d, lr = 4096, 1024, 1e-4
+            net = UNet1D(input_dim=d, base_channels=32, channel_mults=(1, 2, 4), num_res_blocks=2, emb_dim=128,
+                         premodule="NormalizeLogRadius").to(dev)
+            x = signals_1d(B, seed=1234, device=dev)
+            fwd = 0.4554e9
+        else:
+            from sdeflow_light_amd.NNUnet import VorticityUNet
+            B, d, lr = 256, 3 * 64 * 64, 1e-4
+            net = VorticityUNet(base_channels=32, channel_mults=(1, 2, 4), num_res_blocks=2, in_space=64, attention_resolutions=(2, 4),
+                                flatten_order="F", channels=3, premodule="NormalizeLogRadius").to(dev)
+            with torch.no_grad():
+                for p_ in net.parameters():
+                    if p_.dim() > 1 and float(p_.abs().sum()) == 0.0:
+                        p_.normal_(0, 0.02)
+            x = random_images(B, seed=1234, device=dev)
+            fwd = UNET_FWD_FLOP["c4"]
+        T = torch.nn.Parameter(torch.FloatTensor([1.0]), requires_grad=False)
+        base = MSGMsde(x[:1024].cpu(), beta_min=0.1, beta_max=20.0, t_epsilon=1e-3, T=T, num_steps_forward=16, device=dev,
+                       denseTensor=False, norm_map="log")
+        gen = PluginReverseSDE(base, net, T, vtype="rademacher", deviceReverseSDE=dev).to(dev)
+        tr = UNetScoreTrainer(gen, B, d, lr=lr, world=1, seed=1)
+        tr.set_data(x)
+        log(f"msgm {tag}: capture + timing")
+        med, blocks = timed_blocks(tr.step, steps, warmup, dev, min_seconds=0.5)
+        per = med / steps
+        n = B * d
+        xs, o = torch.randn(B, d, device=dev), torch.empty(B, d, device=dev)
+        st = base.struct()
+        tk = time_kernel_events(lambda: ops.sde_stage(o, xs, 0.5, xs, None, st, L.PROC_FORWARD, True, 0.1, 1.0 / 16, 0.0,
+                                                      rng=tr.rng, rng_step=1), 30, dev)
+        out[tag] = {"workload": f"MSGM sparse tensor, nsf=16, {'UNet1D L=1024' if d == 1024 else 'VorticityUNet 64x64x3'}, batch {B}, "
+                                "NormalizeLogRadius, SSM + Adam, hipGraph-captured step (kernel nodes only)",
+                    "train_steps_per_s": 1.0 / per, "ms_per_step": per * 1e3, "final_loss": float(tr.loss),
+                    "whole_step_frac_of_f32_mfma_peak": 6 * fwd * B / per / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                    "graph_kernel_nodes": ops.graph_node_kinds(tr.graph).get("kernel"),
+                    "forward_sde_stage": {"kernel": "k_stage_rows (msgm_sde_stage, sparse stencil, Stratonovich stage)", "bound": "hbm",
+                                          "achieved": 12 * n / tk / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                          "frac": 12 * n / tk / 1e9 / PEAK_HBM_GBS, "us_per_launch": tk * 1e6,
+                                          "launches_per_step": 4 * 16 + 4}}
+        del tr, gen, net, xs, o
+        free_gpu()
+    return out
 
 
 # ----------------------------------------------------------------------------------------------------- worker
@@ -458,6 +645,7 @@ def worker(a):
                              "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": r["frac_of_f32_mfma_peak"], "traffic": None},
                    cpu_baseline=None)
     else:
+        log(f"{w}: training leg")
         r, gen, d = leg_train_unet(w, a, rank, world, dev)
         name = {"c3": "C3: UNet1D L=1024, batch 4096/GPU, SGM, SSM + Adam",
                 "c4": "C4: VorticityUNet 2-D 64x64x3 (4.02 M params), GLOBAL batch 256, SGM, SSM loss + Adam"}[w]
@@ -468,17 +656,30 @@ def worker(a):
                    final_loss=r["final_loss"], timed_blocks_s=r["blocks_s"], whole_step=r["whole_step"])
         free_gpu()
         if w == "c4" and a.sample_steps > 0:
+            log("c5: sampling leg")
             s = leg_sample_unet(gen, d, a, rank, world, dev)
             out.update(sample_steps_per_s=s["sample_steps_per_s"], sample=s)
         del gen
         free_gpu()
         if solo:
-            probes = kernel_probes(dev, GLOBAL_BATCH[w]) if w == "c4" else []
-            if probes:
-                # the dominant kernel of the C4 step (largest share in profiles/r02's rocprofv3 kernel stats) first
-                out["roofline"] = dict(probes[0], whole_step_frac=r["whole_step"]["frac_of_f32_mfma_peak"])
-                out["roofline"].setdefault("traffic_source", "not measured in this run; PMC passes are under profiles/")
-                out["roofline_other_kernels"] = probes[1:]
+            if w == "c4":
+                log("c4: per-launch profile of one eager step")
+                fams, total = leg_step_profile(dev, GLOBAL_BATCH[w])
+                top = next(f for f in fams if f.get("bound") == "mfma")          # largest measured share among the MFMA families
+                kern = "k_conv_tile" if "k_conv_tile" in top["family"] else ("k_attn_dual_bwd" if "backward" in top["family"] else
+                                                                             "k_wgrad_tile" if "wgrad" in top["family"] else None)
+                traffic, src = pmc_traffic(kern) if kern else (None, None)
+                out["roofline"] = {"kernel": top["family"], "bound": "mfma", "achieved": top["achieved"], "peak": PEAK_F32_MFMA_TFLOPS,
+                                   "unit": "TFLOP/s", "frac": top["frac"], "traffic": traffic,
+                                   "traffic_source": src or "no PMC pass committed for this kernel",
+                                   "kernel_ms_per_step": top["ms"], "launches_per_step": top["calls"], "flop_per_step": top["flop"],
+                                   "share_of_c4_step": top["share_of_step"],
+                                   "measured": "this run: one eager C4 step, every launch bracketed by HIP events on the launch stream",
+                                   "whole_step_frac": r["whole_step"]["frac_of_f32_mfma_peak"]}
+                out["step_profile"] = {"eager_step_ms": total, "families": fams}
+                free_gpu()
+                log("HBM-bound kernels")
+                out["roofline_hbm"] = hbm_rooflines(dev)
             else:
                 ws = r["whole_step"]
                 out["roofline"] = {"kernel": "whole step (all kernels)", "bound": "mfma", "achieved": ws["algorithmic_tflops_per_gpu"],
@@ -486,16 +687,23 @@ def worker(a):
             free_gpu()
             if w == "c4" and not a.no_extra:
                 extra = {}
+                log("extra: c2")
                 extra["c2"] = leg_mlp(a, rank, world, dev)
                 free_gpu()
+                log("extra: c3")
                 ac3 = argparse.Namespace(steps=5, warmup=2)
                 r3, g3, _ = leg_train_unet("c3", ac3, rank, world, dev)
                 del g3
                 extra["c3"] = {"workload": "C3: UNet1D L=1024, batch 4096, SGM, SSM + Adam", "train_steps_per_s": r3["value"],
                                "ms_per_step": r3["ms_per_step"], "whole_step": r3["whole_step"], "final_loss": r3["final_loss"]}
+                free_gpu()
+                log("extra: msgm")
+                extra["msgm"] = leg_msgm(dev)
                 out["extra"] = extra
                 free_gpu()
+            log("cpu baseline (oracle on the host cores)")
             out["cpu_baseline"] = None if a.no_cpu_baseline else cpu_baseline_unet(w)
+            log("done")
         else:
             ws = r["whole_step"]
             out["roofline"] = {"kernel": "whole step (all kernels), per GPU", "bound": "mfma", "achieved": ws["algorithmic_tflops_per_gpu"],

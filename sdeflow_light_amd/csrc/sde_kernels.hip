@@ -137,6 +137,27 @@ __global__ void k_rademacher(float* __restrict__ v, int64_t n, const float* __re
   }
 }
 
+// Sum over the GS lanes that share a row.  GS <= 64: a lane group inside a wave (xor tree).  GS = 256: the whole workgroup
+// owns the row (long rows: n >= 2048 — 12288-element images have too few rows per launch to fill the chip with 64-lane
+// groups: 32 rows were 8 workgroups and 67-82 us per launch); wave sums meet through LDS in a fixed order.  The group size
+// depends on n only, never on the batch: a row's sum is the same bits in every batch size.
+template <int GS>
+__device__ __forceinline__ float group_sum(float v) {
+  if constexpr (GS <= 64) {
+#pragma unroll
+    for (int o = GS >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, GS);
+    return v;
+  } else {
+    __shared__ float red[4];
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float r = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    return r;
+  }
+}
+
 // ============================================================ integrator stage
 struct StageArgs {
   float* out; const float* base; float c_out;
@@ -223,6 +244,87 @@ __global__ void k_stage_diag_flat(StageArgs A) {
   }
 }
 
+// Multiplicative SDE, SPARSE rotation tensor, no norm correction (the RK4 stages of the forward perturbation and of the
+// Stratonovich samplers): the update is a 3-point circular stencil along the row,
+//   dx_i = c sqrt(beta) (x_{i+1} w_i - x_{i-1} w_{i-1})        (SDEs.py:369-399,425-430; sde_scheme.py:27-32),
+// so it runs as a FLAT float4 kernel like the additive one — 12-16 B / element — instead of one 64-lane group per row
+// (256 rows of 12288 elements were 309 us per stage = 0.12 TB/s).  n % 4 == 0: a quad never straddles two rows.
+// Same expressions, in the same order, as k_stage_rows (bit-identical results).
+__global__ void __launch_bounds__(256) k_stage_sparse_flat(StageArgs A) {
+  const int64_t n = A.n, nq = (A.B * n) >> 2;
+  const float l = A.lmbd;
+  const float sig_scale = (A.proc == MSGM_PROC_REVERSE) ? sqrtf(1.0f - l) : 1.0f;
+  const float cV = 0.5f * sqrtf(2.0f);
+  const float tnow = stage_time(A);
+  const int lane = threadIdx.x & 63;
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e0 = q << 2, b = e0 / n, i0 = e0 - b * n;
+    const float delta = A.delta_rows ? A.delta_rows[b] : A.delta;
+    const float sqd = A.delta_rows ? sqrtf(delta) : A.sqrt_delta;
+    const float tb = A.delta_rows ? tnow + A.t_frac * delta : tnow;
+    const float s = A.proc == MSGM_PROC_REVERSE ? A.T - tb : tb;
+    const float beta = sde_beta(A.b0, A.b1, s);
+    const float sb = sqrtf(beta);
+    const int64_t row = b * n;
+    const int64_t em = row + (i0 == 0 ? n - 1 : i0 - 1), ep = row + (i0 + 4 == n ? 0 : i0 + 4);
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(A.x + e0);
+    const float xm0 = A.x[em], xp3 = A.x[ep];
+    f32x4 av = {0, 0, 0, 0}, bv = {0, 0, 0, 0}, wv;
+    float am0 = 0.f, wm0;
+    if (A.a) { av = *reinterpret_cast<const f32x4*>(A.a + e0); am0 = A.a[em]; }
+    if (A.base) bv = (A.base == A.x) ? xv : *reinterpret_cast<const f32x4*>(A.base + e0);
+    if (A.dW) { wv = *reinterpret_cast<const f32x4*>(A.dW + e0); wm0 = A.dW[em]; }
+    else if (A.z) { wv = sqd * *reinterpret_cast<const f32x4*>(A.z + e0); wm0 = sqd * A.z[em]; }
+    else {
+      const f32x4 zz = philox_normal4(A.rng, stage_step(A), RNG_STREAM_DW, (uint64_t)q);
+      wv = sqd * zz;
+      // the previous element's draw sits in the neighbouring lane's quad (same row unless this quad opens the row)
+      const float zprev = __shfl_up(zz[3], 1, 64);
+      wm0 = sqd * ((lane == 0 || i0 == 0) ? philox_normal1(A.rng, stage_step(A), RNG_STREAM_DW, (uint64_t)em) : zprev);
+    }
+    f32x4 o, iv;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float xi = xv[k];
+      const float xp = k < 3 ? xv[k + 1] : xp3, xm = k > 0 ? xv[k - 1] : xm0;
+      const float w_i = wv[k], w_m = k > 0 ? wv[k - 1] : wm0;
+      const float f = 0.5f * beta * xi, div = 2.0f * f;
+      const float gw = (cV * (sb * xp)) * w_i + (-cV * (sb * xm)) * w_m;
+      float ga = 0.f;
+      if (A.a) ga = (cV * (sb * xp)) * av[k] + (-cV * (sb * xm)) * (k > 0 ? av[k - 1] : am0);
+      float mu;
+      if (A.proc == MSGM_PROC_REVERSE) {
+        mu = (1.0f - 0.5f * l) * ga - f + (1.0f - l) * div;
+        if (A.strato) mu = mu - 0.5f * (1.0f - l) * div;
+      } else {
+        mu = 0.f;
+        if (!A.strato) mu = mu + 0.5f * div;
+      }
+      iv[k] = mu * delta + sig_scale * gw;
+      o[k] = bv[k] + A.c_out * iv[k];
+    }
+    *reinterpret_cast<f32x4*>(A.out + e0) = o;
+    if (A.dW_out) *reinterpret_cast<f32x4*>(A.dW_out + e0) = wv;
+    if (A.inc_out) *reinterpret_cast<f32x4*>(A.inc_out + e0) = iv;
+  }
+}
+
+// x + (k1 + 2k2 + 2k3 + k4)/6 without norm correction: flat float4 pass (24 B / element)
+__global__ void __launch_bounds__(256) k_rk4_combine_flat(float* __restrict__ out, const float* __restrict__ x,
+                                                          const float* __restrict__ k1, const float* __restrict__ k2,
+                                                          const float* __restrict__ k3, const float* __restrict__ k4, int64_t nq) {
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = q << 2;
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + e), a = *reinterpret_cast<const f32x4*>(k1 + e);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(k2 + e), c = *reinterpret_cast<const f32x4*>(k3 + e);
+    const f32x4 d = *reinterpret_cast<const f32x4*>(k4 + e);
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = xv[k] + (a[k] + 2.0f * b[k] + 2.0f * c[k] + d[k]) / 6.0f;
+    *reinterpret_cast<f32x4*>(out + e) = o;
+  }
+}
+
 // Row kernel: a group of GS lanes owns one row; handles all three layouts and
 // the optional norm correction (x <- x * norm0/||x||, sde_scheme.py:85-86).
 //  sparse: dx_i = c sb (x_{i+1} w_i - x_{i-1} w_{i-1}), c = sqrt(2)/2, circular
@@ -304,8 +406,7 @@ __global__ void k_stage_rows(StageArgs A) {
       }
     }
     if (A.norm0) {
-#pragma unroll
-      for (int o = GS >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, GS);
+ss = group_sum<GS>(ss);
       if (live) {
         const float scale = A.norm0[b] / sqrtf(ss);
         for (int64_t i = lane; i < n; i += GS) A.out[b * n + i] *= scale;   // own writes, same lane
@@ -334,8 +435,7 @@ __global__ void k_rk4_combine(float* __restrict__ out, const float* __restrict__
         out[e] = o; ss += o * o;
       }
     if (norm0) {
-#pragma unroll
-      for (int o = GS >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, GS);
+ss = group_sum<GS>(ss);
       if (live) {
         const float sc = norm0[b] / sqrtf(ss);
         for (int64_t i = lane; i < n; i += GS) out[b * n + i] *= sc;
@@ -369,8 +469,7 @@ __global__ void k_ssm_loss_diag(const float* __restrict__ out, const float* __re
         g[(B + b) * n + i] = sb * vi * w;
       }
     }
-#pragma unroll
-    for (int o = GS >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, GS);
+acc = group_sum<GS>(acc);
     if (b < B && lane == 0) per[b] = acc;
   }
 }
@@ -419,8 +518,7 @@ __global__ void k_ssm_terms(const float* __restrict__ y, const float* __restrict
         u[b * n + k] = uk;
       }
     }
-#pragma unroll
-    for (int o = GS >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, GS);
+acc = group_sum<GS>(acc);
     if (b < B && lane == 0) cst[b] = acc;
   }
 }
@@ -443,8 +541,7 @@ __global__ void k_ssm_loss_generic(const float* __restrict__ out, const float* _
         g[b * n + i] = a * w;
         g[(B + b) * n + i] = ui * w;
       }
-#pragma unroll
-    for (int o = GS >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, GS);
+acc = group_sum<GS>(acc);
     if (b < B && lane == 0) per[b] = acc + cst[b];
   }
 }
@@ -470,8 +567,7 @@ __global__ void k_row_norm(const float* __restrict__ x, float* __restrict__ out,
   for (int64_t b = gid; b < rows_pad; b += gstride) {
     float ss = 0.f;
     if (b < B) for (int64_t i = lane; i < n; i += GS) { float v = x[b * n + i]; ss += v * v; }
-#pragma unroll
-    for (int o = GS >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, GS);
+ss = group_sum<GS>(ss);
     if (b < B && lane == 0) out[b] = sqrtf(ss);
   }
 }
@@ -537,6 +633,7 @@ static int launch_rows(int64_t B, int64_t n, F&& f) {
   // lanes per row: next power of two >= min(n,64), at least 2
   int gs = 2;
   while (gs < 64 && gs < n) gs <<= 1;
+  if (n >= 2048) gs = 256;             // long rows: the whole workgroup owns a row (group_sum<256>); a function of n only
   const int block = 256;
   int64_t groups = (int64_t)block / gs;
   int grid = (int)((B + groups - 1) / groups);
@@ -659,6 +756,15 @@ int msgm_sde_stage(float* out, const float* base, float c_out, const float* x, c
     hipLaunchKernelGGL(k_stage_diag_flat, dim3(grid_for((B * n + 3) / 4, 256)), dim3(256), 0, S(stream), A);
     return msgm_check_launch();
   }
+  {
+    const uintptr_t al = reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(a) |
+                         reinterpret_cast<uintptr_t>(dW) | reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(base) |
+                         reinterpret_cast<uintptr_t>(dW_out) | reinterpret_cast<uintptr_t>(inc_out);
+    if (sde->kind == MSGM_SDE_MSGM_SPARSE && !norm0 && n % 4 == 0 && n >= 8 && (al & 15) == 0 && out != x) {
+      hipLaunchKernelGGL(k_stage_sparse_flat, dim3(grid_for((B * n) / 4, 256)), dim3(256), 0, S(stream), A);
+      return msgm_check_launch();
+    }
+  }
   return launch_rows(B, n, [&](int gs, int grid, int block) {
     switch (gs) {
       case 2: hipLaunchKernelGGL(k_stage_rows<2>, dim3(grid), dim3(block), 0, S(stream), A); break;
@@ -666,6 +772,7 @@ int msgm_sde_stage(float* out, const float* base, float c_out, const float* x, c
       case 8: hipLaunchKernelGGL(k_stage_rows<8>, dim3(grid), dim3(block), 0, S(stream), A); break;
       case 16: hipLaunchKernelGGL(k_stage_rows<16>, dim3(grid), dim3(block), 0, S(stream), A); break;
       case 32: hipLaunchKernelGGL(k_stage_rows<32>, dim3(grid), dim3(block), 0, S(stream), A); break;
+      case 256: hipLaunchKernelGGL(k_stage_rows<256>, dim3(grid), dim3(block), 0, S(stream), A); break;
       default: hipLaunchKernelGGL(k_stage_rows<64>, dim3(grid), dim3(block), 0, S(stream), A); break;
     }
   });
@@ -674,6 +781,14 @@ int msgm_sde_stage(float* out, const float* base, float c_out, const float* x, c
 int msgm_rk4_combine(float* out, const float* x, const float* k1, const float* k2, const float* k3, const float* k4,
                      int64_t B, int64_t n, const float* norm0, msgm_stream_t stream) {
   if (!out || !x || !k1 || !k2 || !k3 || !k4 || B <= 0 || n <= 0) return MSGM_E_BADARG;
+  {
+    const uintptr_t al = reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(k1) |
+                         reinterpret_cast<uintptr_t>(k2) | reinterpret_cast<uintptr_t>(k3) | reinterpret_cast<uintptr_t>(k4);
+    if (!norm0 && (B * n) % 4 == 0 && (al & 15) == 0) {
+      hipLaunchKernelGGL(k_rk4_combine_flat, dim3(grid_for((B * n) / 4, 256)), dim3(256), 0, S(stream), out, x, k1, k2, k3, k4, (B * n) / 4);
+      return msgm_check_launch();
+    }
+  }
   return launch_rows(B, n, [&](int gs, int grid, int block) {
     switch (gs) {
       case 2: hipLaunchKernelGGL(k_rk4_combine<2>, dim3(grid), dim3(block), 0, S(stream), out, x, k1, k2, k3, k4, B, n, norm0); break;
@@ -681,6 +796,7 @@ int msgm_rk4_combine(float* out, const float* x, const float* k1, const float* k
       case 8: hipLaunchKernelGGL(k_rk4_combine<8>, dim3(grid), dim3(block), 0, S(stream), out, x, k1, k2, k3, k4, B, n, norm0); break;
       case 16: hipLaunchKernelGGL(k_rk4_combine<16>, dim3(grid), dim3(block), 0, S(stream), out, x, k1, k2, k3, k4, B, n, norm0); break;
       case 32: hipLaunchKernelGGL(k_rk4_combine<32>, dim3(grid), dim3(block), 0, S(stream), out, x, k1, k2, k3, k4, B, n, norm0); break;
+      case 256: hipLaunchKernelGGL(k_rk4_combine<256>, dim3(grid), dim3(block), 0, S(stream), out, x, k1, k2, k3, k4, B, n, norm0); break;
       default: hipLaunchKernelGGL(k_rk4_combine<64>, dim3(grid), dim3(block), 0, S(stream), out, x, k1, k2, k3, k4, B, n, norm0); break;
     }
   });
@@ -697,6 +813,7 @@ int msgm_ssm_loss_diag(const float* out, const float* v, const float* t, float* 
       case 8: hipLaunchKernelGGL(k_ssm_loss_diag<8>, dim3(grid), dim3(block), 0, S(stream), out, v, t, per, g, B, n, sde->beta_min, sde->beta_max, inv_batch); break;
       case 16: hipLaunchKernelGGL(k_ssm_loss_diag<16>, dim3(grid), dim3(block), 0, S(stream), out, v, t, per, g, B, n, sde->beta_min, sde->beta_max, inv_batch); break;
       case 32: hipLaunchKernelGGL(k_ssm_loss_diag<32>, dim3(grid), dim3(block), 0, S(stream), out, v, t, per, g, B, n, sde->beta_min, sde->beta_max, inv_batch); break;
+      case 256: hipLaunchKernelGGL(k_ssm_loss_diag<256>, dim3(grid), dim3(block), 0, S(stream), out, v, t, per, g, B, n, sde->beta_min, sde->beta_max, inv_batch); break;
       default: hipLaunchKernelGGL(k_ssm_loss_diag<64>, dim3(grid), dim3(block), 0, S(stream), out, v, t, per, g, B, n, sde->beta_min, sde->beta_max, inv_batch); break;
     }
   });
@@ -709,6 +826,7 @@ int msgm_ssm_loss_diag(const float* out, const float* v, const float* t, float* 
     case 8: hipLaunchKernelGGL(KERNEL<8>, dim3(grid), dim3(block), 0, S(stream), __VA_ARGS__); break;           \
     case 16: hipLaunchKernelGGL(KERNEL<16>, dim3(grid), dim3(block), 0, S(stream), __VA_ARGS__); break;         \
     case 32: hipLaunchKernelGGL(KERNEL<32>, dim3(grid), dim3(block), 0, S(stream), __VA_ARGS__); break;         \
+    case 256: hipLaunchKernelGGL(KERNEL<256>, dim3(grid), dim3(block), 0, S(stream), __VA_ARGS__); break;       \
     default: hipLaunchKernelGGL(KERNEL<64>, dim3(grid), dim3(block), 0, S(stream), __VA_ARGS__); break;         \
   }
 
@@ -746,6 +864,7 @@ int msgm_row_norm(const float* x, float* out, int64_t B, int64_t n, msgm_stream_
       case 8: hipLaunchKernelGGL(k_row_norm<8>, dim3(grid), dim3(block), 0, S(stream), x, out, B, n); break;
       case 16: hipLaunchKernelGGL(k_row_norm<16>, dim3(grid), dim3(block), 0, S(stream), x, out, B, n); break;
       case 32: hipLaunchKernelGGL(k_row_norm<32>, dim3(grid), dim3(block), 0, S(stream), x, out, B, n); break;
+      case 256: hipLaunchKernelGGL(k_row_norm<256>, dim3(grid), dim3(block), 0, S(stream), x, out, B, n); break;
       default: hipLaunchKernelGGL(k_row_norm<64>, dim3(grid), dim3(block), 0, S(stream), x, out, B, n); break;
     }
   });
