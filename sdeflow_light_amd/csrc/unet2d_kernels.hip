@@ -1048,37 +1048,49 @@ __global__ void __launch_bounds__(256) k_emb_bank(const msgm_emb_job_t* __restri
   }
 }
 
-// dsemb[r][k] = sum over jobs and their channels, in order.  Grid (row tiles of 16, k tiles of 32); a thread owns one k
-// and two rows; the dout rows of a job are staged through LDS 64 channels at a time.
+// dsemb[r][k] = sum over jobs and their channels, in a fixed order.  Grid (row tiles of 8, k tiles of 32); thread (k, cs):
+// channel slice cs of 8 takes the channels c = cs (mod 8) of every 64-channel chunk, the 8 slices meet through LDS in slice
+// order.  (One thread per k walking all ~1400 channels alone was 125 us at 32 rows: a serial chain of dependent loads.)
 __global__ void __launch_bounds__(256) k_emb_bank_dgrad(const msgm_emb_job_t* __restrict__ jobs, int n_jobs, float* __restrict__ dsemb,
                                                         int R, int K) {
-  __shared__ float sG[16][68];
-  const int tid = threadIdx.x, kl = tid & 31, rs = tid >> 5;
-  const int k = blockIdx.y * 32 + kl, r0 = blockIdx.x * 16;
-  float a0 = 0.f, a1 = 0.f;
+  __shared__ float sG[8][68];
+  __shared__ float red[8][8][33];
+  const int tid = threadIdx.x, kl = tid & 31, cs = tid >> 5;
+  const int k = blockIdx.y * 32 + kl, r0 = blockIdx.x * 8;
+  const bool okk = k < K;
+  float acc[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) acc[r] = 0.f;
   for (int j = 0; j < n_jobs; ++j) {
     const msgm_emb_job_t J = jobs[j];
     for (int cb = 0; cb < J.co; cb += 64) {
       __syncthreads();
-      for (int i = tid; i < 16 * 64; i += 256) {
+      for (int i = tid; i < 8 * 64; i += 256) {
         const int r = i >> 6, c = i & 63;
         sG[r][c] = (r0 + r < R && cb + c < J.co) ? J.dout[(size_t)(r0 + r) * J.co + cb + c] : 0.f;
       }
       __syncthreads();
-      const int cend = min(64, J.co - cb);
-      if (k < K) {
-#pragma unroll 8
-        for (int c = 0; c < cend; ++c) {
-          const float w = J.W[(size_t)(cb + c) * K + k];
-          a0 = fmaf(sG[rs][c], w, a0);
-          a1 = fmaf(sG[rs + 8][c], w, a1);
-        }
+      float w[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {                      // this slice's 8 channels of the chunk: loads first, then the FMAs
+        const int c = cb + cs + 8 * i;
+        w[i] = (okk && c < J.co) ? J.W[(size_t)c * K + k] : 0.f;
       }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc[r] = fmaf(sG[r][cs + 8 * i], w[i], acc[r]);
     }
   }
-  if (k < K) {
-    if (r0 + rs < R) dsemb[(size_t)(r0 + rs) * K + k] = a0;
-    if (r0 + rs + 8 < R) dsemb[(size_t)(r0 + rs + 8) * K + k] = a1;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) red[cs][r][kl] = acc[r];
+  __syncthreads();
+  {                                                      // thread (kl, r = cs): the 8 slices of row r in slice order
+    const int r = cs;
+    float t = red[0][r][kl];
+#pragma unroll
+    for (int sl = 1; sl < 8; ++sl) t += red[sl][r][kl];
+    if (okk && r0 + r < R) dsemb[(size_t)(r0 + r) * K + k] = t;
   }
 }
 
@@ -1463,7 +1475,7 @@ int msgm_emb_bank_backward(const msgm_emb_job_t* jobs_dev, int32_t n_jobs, int32
   }();
   (void)once;
   hipLaunchKernelGGL(k_emb_bank<1>, dim3((unsigned)total_blocks), dim3(256), lds, S(stream), jobs_dev, n_jobs, semb, R, K, n_bias);
-  hipLaunchKernelGGL(k_emb_bank_dgrad, dim3((unsigned)((R + 15) / 16), (unsigned)((K + 31) / 32)), dim3(256), 0, S(stream), jobs_dev,
+  hipLaunchKernelGGL(k_emb_bank_dgrad, dim3((unsigned)((R + 7) / 8), (unsigned)((K + 31) / 32)), dim3(256), 0, S(stream), jobs_dev,
                      n_jobs, dsemb, R, K);
   return msgm_check_launch();
 }
