@@ -18,6 +18,7 @@
 // second half of the batch (n >= n_bias): convolutions are linear, only the bias
 // distinguishes the halves.
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 #define CONV_MAX_SRC 2
@@ -1393,6 +1394,9 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_tile(WgradArgs A, int tiles_x,
       t4 += *reinterpret_cast<const f32x4*>(gr + 12);
       bsum += (t4[0] + t4[1]) + (t4[2] + t4[3]);
     }
+    // (Round 3 tried a branch-free tap loop — no per-tap `continue`, the next tap's LDS fragments requested ahead: hipcc then
+    // keeps more fragments live, spills 19 registers at the 256-register budget of two workgroups per CU, and the C4 step
+    // got SLOWER, 125.7 -> 133.6 ms.  The per-tap branch stays; the second resident wave covers the LDS latency.)
 #pragma unroll
     for (int pg2 = 0; pg2 < 2; ++pg2) {
       const int pg = 2 * w + pg2;                           // this wave's 16-pixel group
@@ -1440,39 +1444,195 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_tile(WgradArgs A, int tiles_x,
       else atomicAdd(A.dbias + co, bsum);
     }
   }
-  // cross-wave reduction through LDS (reuse the staging area), then atomics
+  // cross-wave reduction through LDS (reuse the staging area): up to four taps per round — every wave parks its partial
+  // tiles of the round's taps, one barrier, then wave w adds the four partials of tap (round base + w) in wave order and
+  // stores that tap's 32 x 32 block.  (One tap per round with wave 0 doing every store was 18 barriers and 144 scattered
+  // stores by a single wave per workgroup: 10-15 % of a workgroup's time at 8 tiles per workgroup.)
   float* red = wt_lds;
+  constexpr int TR = TAPS == 9 ? 4 : (TAPS == 3 ? 2 : 1);   // taps per round: TR * 4 waves * 1024 floats fit the staging area
+  constexpr int STG = (WT_DBUF(TAPS) ? 2 : 1) * BUF;
+  static_assert(TR * 4096 <= (STG > 4096 ? STG : 4096), "reduction scratch exceeds the staging area");
   __syncthreads();
 #pragma unroll
-  for (int t = 0; t < TAPS; ++t) {
-    // workgroup-uniform: the barriers below stay matched.  With slabs a skipped block still stores its zeros (the
-    // slab reduction reads every slot of every element)
-    if (!((tmask >> t) & 1u) && !A.slab) continue;
+  for (int t0 = 0; t0 < TAPS; t0 += TR) {
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int tt = 0; tt < TR; ++tt) {
+      const int t = t0 + tt;
+      if (t < TAPS) {
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[w * 1024 + ((m * 2 + kt) * 4 + r) * 64 + lane] = acc[t][m][kt][r];
+          for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(tt * 4 + w) * 1024 + ((m * 2 + kt) * 4 + r) * 64 + lane] = acc[t][m][kt][r];
+      }
+    }
     __syncthreads();
-    if (w == 0) {
+    {
+      const int tt = w, t = t0 + tt;                       // wave-uniform
+      // a skipped (structurally zero) block still stores its zeros into a slab (the slab reduction reads every slot)
+      if (tt < TR && t < TAPS && (((tmask >> t) & 1u) || A.slab)) {
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+          for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int idx = ((m * 2 + kt) * 4 + r) * 64 + lane;
-            const float sum = (red[idx] + red[1024 + idx]) + (red[2048 + idx] + red[3072 + idx]);
-            const int co = co0 + 16 * m + 4 * q + r, c = c0 + 16 * kt + il;
-            if (co < A.Cout && c < A.C) {
-              if (A.slab) A.slab[(size_t)blockIdx.x * A.slab_stride + (size_t)(t * A.CoutP + co) * A.C + c] = sum;
-              else atomicAdd(A.dWp + ((size_t)(t * A.CoutP + co) * A.Ktot + A.koff + c), sum);
+            for (int r = 0; r < 4; ++r) {
+              const int idx = tt * 4096 + ((m * 2 + kt) * 4 + r) * 64 + lane;
+              const float sum = (red[idx] + red[1024 + idx]) + (red[2048 + idx] + red[3072 + idx]);
+              const int co = co0 + 16 * m + 4 * q + r, c = c0 + 16 * kt + il;
+              if (co < A.Cout && c < A.C) {
+                if (A.slab) A.slab[(size_t)blockIdx.x * A.slab_stride + (size_t)(t * A.CoutP + co) * A.C + c] = sum;
+                else atomicAdd(A.dWp + ((size_t)(t * A.CoutP + co) * A.Ktot + A.koff + c), sum);
+              }
             }
-          }
+      }
     }
     __syncthreads();
   }
+}
+
+// ------------------------------------------------------------------ wgrad of 3x3 "same" convolutions, OUTPUT-stationary waves
+// k_wgrad_tile splits a tile's 128 pixels over the four waves: every wave carries the full 32 x 32 x 9 block (144
+// accumulator registers -> 251 VGPRs, two workgroups per CU, nothing left for the compiler to keep LDS fragments in flight)
+// and the four partial blocks meet through LDS at the end.  Here the waves split the OUTPUT instead: wave (m, kt) owns the
+// 16 co x 16 c tile (m, kt) of all nine taps — 36 accumulator registers — and walks all 128 pixels of every tile itself:
+//   * no cross-wave reduction, no epilogue barriers: a wave stores its own tiles;
+//   * ~130 VGPRs: three workgroups (12 waves) per CU instead of two (8);
+//   * a tap row's fragments overlap: pixels 4q..4q+3 shifted by kw = 0..2 are 6 consecutive halo values, read once per
+//     (pixel group, kh) — 9 LDS read pairs per 36 MFMAs.
+// Same staging (coalesced 16-byte global loads one tile ahead, transposed [channel][pixel] LDS images), ONE LDS buffer
+// (40 KB), same slab / bias outputs as k_wgrad_tile<8, 16, 9>.  Aligned channel counts, no tap masks, no folded upsample
+// restrictions beyond the old kernel's.
+__global__ void __launch_bounds__(256, 3) k_wgrad_tile9(WgradArgs A, int tiles_x, int tiles_y, int tiles_per_wg, int n_tiles) {
+  extern __shared__ __attribute__((aligned(16))) float wt_lds[];
+  constexpr int TH = 8, TW = 16, KW = 3, KH = 3, TAPS = 9;
+  constexpr int HH = TH + KH - 1, HW = TW + KW - 1, halo = HH * HW;
+  constexpr int IP = ((halo + 2) & ~7) + 5;
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, il = lane & 15, q = lane >> 4;
+  const int m = w >> 1, kt = w & 1;                         // this wave's 16 x 16 output tile of every tap
+  const ConvGeom g = A.g;
+  float* gT = wt_lds;                                       // gy^T    [32][WT_GP]
+  float* iT = wt_lds + 32 * WT_GP;                          // input^T [32][IP]
+  const int cblocks = (A.C + 31) / 32;
+  const int coblk = blockIdx.y / cblocks, cblk = blockIdx.y - coblk * cblocks;
+  const int co0 = coblk * 32, c0 = cblk * 32;
+  const int t_beg = blockIdx.x * tiles_per_wg, t_end = min(t_beg + tiles_per_wg, n_tiles);
+  if (t_beg >= t_end) return;
+  f32x4 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) acc[t] = f32x4{0, 0, 0, 0};
+  constexpr int MAXIN = (halo * 8 + 255) / 256;
+  f32x4 sg[4], si[MAXIN];
+  const int up = g.ups ? 1 : 0;
+  constexpr int n_in = halo * 8;
+  auto stage_load = [&](int tile) {
+    int bx = tile;
+    const int tx_i = bx % tiles_x; bx /= tiles_x;
+    const int ty_i = bx % tiles_y;
+    const int n = bx / tiles_y;
+    const int y0 = ty_i * TH, x0 = tx_i * TW;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int idx = tid + 256 * k;
+      const int p = idx >> 3, c4 = idx & 7;
+      const int py = p / TW, px = p - py * TW;
+      const int oy = y0 + py, ox = x0 + px, co = co0 + 4 * c4;
+      f32x4 v = {0, 0, 0, 0};
+      if (oy < g.Ho && ox < g.Wo && co < A.Cout)
+        v = *reinterpret_cast<const f32x4*>(A.gy + (((size_t)n * g.Ho + oy) * g.Wo + ox) * A.Cout + co);
+      sg[k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < MAXIN; ++k) {
+      const int idx = tid + 256 * k;
+      f32x4 v = {0, 0, 0, 0};
+      if (idx < n_in) {
+        const int hp = idx >> 3, c4 = idx & 7;
+        const int hy = hp / HW, hx = hp - hy * HW;
+        const int iy = y0 + hy - g.padH, ix = x0 + hx - g.padW, c = c0 + 4 * c4;
+        if (iy >= 0 && iy < (g.Hi << up) && ix >= 0 && ix < (g.Wi << up) && c < A.C)
+          v = *reinterpret_cast<const f32x4*>(A.src + (((size_t)n * g.Hi + (iy >> up)) * g.Wi + (ix >> up)) * A.C + c);
+      }
+      si[k] = v;
+    }
+  };
+  auto stage_store = [&]() {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int idx = tid + 256 * k;
+      const int p = idx >> 3, c4 = idx & 7;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gT[(4 * c4 + r) * WT_GP + p] = sg[k][r];
+    }
+#pragma unroll
+    for (int k = 0; k < MAXIN; ++k) {
+      const int idx = tid + 256 * k;
+      if (idx < n_in) {
+        const int hp = idx >> 3, c4 = idx & 7;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) iT[(4 * c4 + r) * IP + hp] = si[k][r];
+      }
+    }
+  };
+  const bool do_bias = A.dbias != nullptr && cblk == 0;
+  const int tiles_per_sample = tiles_x * tiles_y;
+  float bsum = 0.f;                                        // thread (co = tid>>3, 16-pixel part = tid&7)
+  stage_load(t_beg);
+  stage_store();
+  __syncthreads();
+  const float* ga = gT + (16 * m + il) * WT_GP + 4 * q;    // + 16 pg
+  const float* ib = iT + (16 * kt + il) * IP + 4 * q;      // + (pg + kh) * HW   (TW = 16: pixel group pg is tile row pg)
+  for (int tile = t_beg; tile < t_end; ++tile) {
+    const bool more = tile + 1 < t_end;
+    if (more) stage_load(tile + 1);
+    if (do_bias && tile / tiles_per_sample < A.n_bias) {
+      const float* gr = gT + (tid >> 3) * WT_GP + 16 * (tid & 7);
+      f32x4 t4 = *reinterpret_cast<const f32x4*>(gr);
+      t4 += *reinterpret_cast<const f32x4*>(gr + 4);
+      t4 += *reinterpret_cast<const f32x4*>(gr + 8);
+      t4 += *reinterpret_cast<const f32x4*>(gr + 12);
+      bsum += (t4[0] + t4[1]) + (t4[2] + t4[3]);
+    }
+#pragma unroll
+    for (int pg = 0; pg < 8; ++pg) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(ga + 16 * pg);
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const float* vp = ib + (pg + kh) * HW;
+        float v[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) v[j] = vp[j];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] = mfma16c(a[r], v[kw + r], acc[kh * 3 + kw]);
+      }
+    }
+    __syncthreads();                                        // every wave is done reading the buffer
+    if (more) { stage_store(); __syncthreads(); }
+  }
+  if (do_bias) {
+    bsum += __shfl_xor(bsum, 1, 64);
+    bsum += __shfl_xor(bsum, 2, 64);
+    bsum += __shfl_xor(bsum, 4, 64);
+    const int co = co0 + (tid >> 3);
+    if ((tid & 7) == 0 && co < A.Cout) {
+      if (A.slab) A.slab[(size_t)blockIdx.x * A.slab_stride + (size_t)TAPS * A.CoutP * A.C + co] = bsum;
+      else atomicAdd(A.dbias + co, bsum);
+    }
+  }
+  const int c = c0 + 16 * kt + il;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = co0 + 16 * m + 4 * q + r;
+      if (co < A.Cout && c < A.C) {
+        if (A.slab) A.slab[(size_t)blockIdx.x * A.slab_stride + (size_t)(t * A.CoutP + co) * A.C + c] = acc[t][r];
+        else atomicAdd(A.dWp + ((size_t)(t * A.CoutP + co) * A.Ktot + A.koff + c), acc[t][r]);
+      }
+    }
 }
 
 // ------------------------------------------------------------------ weight (un)packing
@@ -2006,7 +2166,7 @@ static WgradPlan wgrad_plan(const msgm_conv_geom_t* geom, int C, int Cout, int n
     p.tiles_x = (geom->Wo + TW - 1) / TW; p.tiles_y = (geom->Ho + TH - 1) / TH;
     p.n_tiles = p.tiles_x * p.tiles_y * geom->N;
     p.yblocks = ((Cout + 31) / 32) * ((C + 31) / 32);
-    static const int wg_target = getenv("MSGM_WGRAD_WGS") ? (atoi(getenv("MSGM_WGRAD_WGS")) > 0 ? atoi(getenv("MSGM_WGRAD_WGS")) : 1) : 1024;   // measured 512 / 768 / 1536: 127.2 / 131.3 / 128.7 vs 127.6 ms per C4 step
+    static const int wg_target = getenv("MSGM_WGRAD_WGS") ? (atoi(getenv("MSGM_WGRAD_WGS")) > 0 ? atoi(getenv("MSGM_WGRAD_WGS")) : 1) : 768;    // = 3 resident workgroups per CU (k_wgrad_tile9 and the 1- / 3-tap forms); r3 measured 768 / 1024 / 1536 / 3072: 124.0 / 126.4 / 124.7 / 124.9 ms per C4 step (r2, two workgroups per CU: 1024 was best)
     int wgs = wg_target / p.yblocks;                       // ~4 workgroups per CU overall
     if (wgs < 1) wgs = 1;
     int per = (p.n_tiles + wgs - 1) / wgs;
@@ -2134,7 +2294,15 @@ static int wgrad_impl(const msgm_conv_geom_t* geom, const float* gy, const float
   } while (0)
     const bool rag = (C & 3) || (Cout & 3);
     if (two_d) {
-      if (taps == 9) { if (rag) WT_LAUNCH2(8, 16, 9, true); else WT_LAUNCH(8, 16, 9); }
+      if (taps == 9) {
+        static const bool old9 = getenv("MSGM_WGRAD_OLD9") != nullptr;      // A/B: the pixel-split kernel
+        if (rag) WT_LAUNCH2(8, 16, 9, true);
+        else if (old9 || tapmask_c32 || tapmask_co32) WT_LAUNCH(8, 16, 9);
+        else {
+          const size_t lds9 = (size_t)(32 * WT_GP + 32 * IP) * sizeof(float);
+          hipLaunchKernelGGL(k_wgrad_tile9, grid, dim3(256), lds9, S(stream), A, tiles_x, tiles_y, per, n_tiles);
+        }
+      }
       else if (taps == 3) WT_LAUNCH(8, 16, 3); else WT_LAUNCH(8, 16, 1);
     }
     else { if (taps == 3) WT_LAUNCH(1, 128, 3); else WT_LAUNCH(1, 128, 1); }
