@@ -73,3 +73,40 @@ def test_c5_chunk_rows_are_independent():
     other = net(x2, s)
     assert torch.equal(other[:1], full[:1])
     assert rel_l2(other[1:].cpu(), full[1:].cpu()) > 1e-2
+
+
+def test_c4_full_batch_256_matches_its_32_row_shards():
+    """VERDICT r2 #5d: the N = 1 bench shape itself — C4 at B = 256 in ONE launch — against its eight 32-row shards (the
+    8-GPU partition): per-sample losses bit for bit, the mean gradient = the average of the shard gradients (1e-4)."""
+    gen = make_gen("sgm", _vunet(64, "F", channels=3))
+    B, d = 256, 3 * 64 * 64
+    torch.manual_seed(12)
+    x, u, eps, uv = torch.randn(B, d), torch.rand(B), torch.randn(B, d), torch.rand(B, d)
+    pf, gf = _ssm(gen, x, u, eps, uv, slice(0, B))
+    assert torch.isfinite(pf).all() and torch.isfinite(gf).all() and float(gf.abs().max()) > 0
+    ps, gs = [], torch.zeros_like(gf)
+    for r in range(8):
+        p, g = _ssm(gen, x, u, eps, uv, slice(32 * r, 32 * (r + 1)))
+        ps.append(p)
+        gs += g / 8
+    assert torch.equal(torch.cat(ps), pf)
+    e = rel_l2(gs, gf)
+    print(f"C4 B=256: mean of the eight 32-row shard gradients vs the full-batch gradient: rel-L2 {e:.2e}")
+    assert e <= 1e-4
+
+
+def test_c5_4096_row_chunk_rows_are_independent():
+    """VERDICT r2 #5d: the sampler's N = 1 chunk size (4096 rows of d = 12 288 per launch, bench.py CHUNK): a row's score
+    is the same bits in the 4096-row launch and in the 1024-row launch an 8-GPU rank runs."""
+    net = _vunet(64, "F", channels=3)
+    torch.manual_seed(6)
+    B, d = 4096, 3 * 64 * 64
+    x = torch.randn(B, d, device=DEV)
+    s = torch.rand(B, device=DEV) * 0.9 + 0.05
+    full = net(x, s)
+    assert full.shape == (B, d) and torch.isfinite(full).all()
+    for c0 in (0, 3072):
+        part = net(x[c0:c0 + 1024].contiguous(), s[c0:c0 + 1024].contiguous())
+        assert torch.equal(part, full[c0:c0 + 1024])
+    del full
+    torch.cuda.empty_cache()
