@@ -381,6 +381,7 @@ class StepProfiler:
         if name in ("msgm_conv_forward", "msgm_conv_forward_fused") and g is not None:
             cin = int(args[2]) + (int(args[4]) if args[3] else 0)
             flop = 2.0 * g.KH * g.KW * cin * int(args[6]) * g.N * g.Ho * g.Wo
+            self._bytes = 4.0 * g.N * (g.Hi * g.Wi * cin + g.Ho * g.Wo * int(args[6]))      # input + output once
             k3 = g.KH * g.KW == 9 or (g.KH == 1 and g.KW == 3)
             same = g.strideH == 1 and g.strideW == 1
             if k3 and same and cin >= 16 and int(args[6]) >= 16:
@@ -390,14 +391,17 @@ class StepProfiler:
             return "other conv forward + dgrad (strided / 3-channel in-out)", "mfma", flop
         if name in ("msgm_conv_wgrad_slabs", "msgm_conv_wgrad_det", "msgm_conv_wgrad") and g is not None:
             flop = 2.0 * g.KH * g.KW * int(args[3]) * int(args[6]) * g.N * g.Ho * g.Wo
+            self._bytes = 4.0 * g.N * (g.Hi * g.Wi * int(args[3]) + g.Ho * g.Wo * int(args[6]))
             if g.KH * g.KW == 9 and g.strideH == 1:
                 return "3x3 stride-1 conv wgrad (k_wgrad_tile; msgm_conv_wgrad_slabs)", "mfma", flop
             return "1x1 / strided conv wgrad", "mfma", flop
         if name == "msgm_attention_dual_forward":
             Bp, T, C = int(args[3]), int(args[4]), int(args[5])
+            self._bytes = 4.0 * 2 * Bp * T * 4 * C                     # q, k, v in, o out (dual)
             return f"dual attention forward C={C} (k_attn_dual_fwd)", "mfma", 6 * 2.0 * T * T * C * Bp
         if name == "msgm_attention_dual_backward":
             Bp, T, C = int(args[5]), int(args[6]), int(args[7])
+            self._bytes = 4.0 * 2 * Bp * T * 8 * C                     # q, k, v, o, obar in, qbar, kbar, vbar out (dual)
             return f"dual attention backward C={C} (delta + k_attn_dual_bwd + slab reduce)", "mfma", 12 * 2.0 * T * T * C * Bp
         if name in ("msgm_groupnorm_dual_forward", "msgm_groupnorm_dual_forward2"):
             if name.endswith("2"):
@@ -433,7 +437,9 @@ class StepProfiler:
                 e0.record()
                 rc = _fn(*args)
                 e1.record()
-                self.recs.append((_name, self._family(_name, args), e0, e1))
+                self._bytes = 0.0
+                fam = self._family(_name, args)
+                self.recs.append((_name, fam + (self._bytes,), e0, e1))
                 return rc
             setattr(lib, name, wrap)
         self._lib = lib
@@ -447,18 +453,18 @@ class StepProfiler:
         torch.cuda.synchronize(dev)
         fam = {}
         total = 0.0
-        for name, (family, bound, work), e0, e1 in self.recs:
+        for name, (family, bound, work, byts), e0, e1 in self.recs:
             ms = e0.elapsed_time(e1)
             total += ms
-            f = fam.setdefault(family, {"family": family, "bound": bound, "calls": 0, "ms": 0.0, "work": 0.0})
-            f["calls"] += 1; f["ms"] += ms; f["work"] += work
+            f = fam.setdefault(family, {"family": family, "bound": bound, "calls": 0, "ms": 0.0, "work": 0.0, "bytes": 0.0})
+            f["calls"] += 1; f["ms"] += ms; f["work"] += work; f["bytes"] += byts
         out = []
         for f in sorted(fam.values(), key=lambda v: -v["ms"]):
             r = {"family": f["family"], "calls": f["calls"], "ms": round(f["ms"], 3), "share_of_step": round(f["ms"] / total, 4)}
             if f["bound"] == "mfma":
                 tf = f["work"] / (f["ms"] * 1e-3) / 1e12
                 r.update(bound="mfma", achieved=tf, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=tf / PEAK_F32_MFMA_TFLOPS,
-                         flop=f["work"])
+                         flop=f["work"], algorithmic_bytes_per_launch=f["bytes"] / max(f["calls"], 1))
             elif f["bound"] == "hbm":
                 gbs = f["work"] / (f["ms"] * 1e-3) / 1e9
                 r.update(bound="hbm", achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s", frac=gbs / PEAK_HBM_GBS, bytes=f["work"])
@@ -498,11 +504,14 @@ def pmc_traffic(kernel_prefix):
         ks = json.load(open(pj))["kernels"]
     except Exception:
         return None, None
-    hits = [v for k, v in ks.items() if k.startswith(kernel_prefix) and v.get("hbm_bytes")]
+    hits = [v for k, v in ks.items() if kernel_prefix in k and v.get("hbm_bytes")]
     if not hits:
         return None, None
-    n = sum(v.get("launches", 1) for v in hits)
-    return sum(v["hbm_bytes"] * v.get("launches", 1) for v in hits) / n, "profiles/r03/pmc_c4_step.json (PMC passes of the C4 step, not measured in this run)"
+    n = sum(v.get("dispatches", 1) for v in hits)
+    return (sum(v["hbm_bytes"] * v.get("dispatches", 1) for v in hits) / n,
+            f"profiles/r03/pmc_c4_step.json: average HBM bytes per launch of {kernel_prefix}* over the C4 step's {n // 3} launches "
+            "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of tools/time_unet2d.py 256 1, 2 x FETCH + WRITE; "
+            "not measured in this run)")
 
 
 def hbm_rooflines(dev):
@@ -672,6 +681,7 @@ def worker(a):
                 out["roofline"] = {"kernel": top["family"], "bound": "mfma", "achieved": top["achieved"], "peak": PEAK_F32_MFMA_TFLOPS,
                                    "unit": "TFLOP/s", "frac": top["frac"], "traffic": traffic,
                                    "traffic_source": src or "no PMC pass committed for this kernel",
+                                   "algorithmic_bytes_per_launch": top.get("algorithmic_bytes_per_launch"),
                                    "kernel_ms_per_step": top["ms"], "launches_per_step": top["calls"], "flop_per_step": top["flop"],
                                    "share_of_c4_step": top["share_of_step"],
                                    "measured": "this run: one eager C4 step, every launch bracketed by HIP events on the launch stream",
