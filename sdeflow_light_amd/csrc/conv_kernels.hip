@@ -1270,6 +1270,12 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(WgradArgs A) {
 // Each wave reduces its own 32 pixels; the four partial sums meet in LDS at the end and are added to dWp with one
 // float atomic per element per workgroup.
 #define WT_GP 132
+// gy^T rows are [channel][pixel ^ WT_SWZ(channel)]: the transposed store of a staged float4 (lane = 4 channels of one pixel, 8
+// lanes per pixel) put 32 lanes on 8 banks (pitch 132 = 4 mod 32: channel quads c4 and c4 + 2 collide, 4-way) — measured
+// SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.52 in the 3x3 wgrad (profiles/r03/pmc_c4_step.json).  XOR-ing the pixel with
+// 4 * (channel quad & 7) spreads the eight channel quads over all 32 banks and keeps groups of 4 consecutive pixels (the
+// 16-byte MFMA fragments) intact.  Readers apply the same XOR (an involution).
+#define WT_SWZ(ch) ((((ch) >> 2) & 7) << 2)
 #ifndef WT_DBUF
 #define WT_DBUF(TAPS) ((TAPS) == 9)
 #endif
@@ -1354,7 +1360,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_tile(WgradArgs A, int tiles_x,
       const int idx = tid + 256 * k;
       const int p = idx >> 3, c4 = idx & 7;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) gyT(b)[(4 * c4 + r) * WT_GP + p] = sg[k][r];
+      for (int r = 0; r < 4; ++r) gyT(b)[(4 * c4 + r) * WT_GP + (p ^ WT_SWZ(4 * c4))] = sg[k][r];
     }
 #pragma unroll
     for (int k = 0; k < MAXIN; ++k) {
@@ -1403,8 +1409,8 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_tile(WgradArgs A, int tiles_x,
       const int p0 = 16 * pg + 4 * q;                       // pixels p0..p0+3 <-> MFMA steps r = 0..3
       const int ty = p0 / TW, tx = p0 - ty * TW;
       f32x4 a[2];
-      a[0] = *reinterpret_cast<const f32x4*>(gT + il * WT_GP + p0);
-      a[1] = *reinterpret_cast<const f32x4*>(gT + (16 + il) * WT_GP + p0);
+      a[0] = *reinterpret_cast<const f32x4*>(gT + il * WT_GP + (p0 ^ WT_SWZ(il)));
+      a[1] = *reinterpret_cast<const f32x4*>(gT + (16 + il) * WT_GP + (p0 ^ WT_SWZ(16 + il)));
 #pragma unroll
       for (int t = 0; t < TAPS; ++t) {
         if (!((tmask >> t) & 1u)) continue;                 // this (tap, block) of the weight is structurally zero
@@ -1563,7 +1569,7 @@ __global__ void __launch_bounds__(256, 3) k_wgrad_tile9(WgradArgs A, int tiles_x
       const int idx = tid + 256 * k;
       const int p = idx >> 3, c4 = idx & 7;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) gT[(4 * c4 + r) * WT_GP + p] = sg[k][r];
+      for (int r = 0; r < 4; ++r) gT[(4 * c4 + r) * WT_GP + (p ^ WT_SWZ(4 * c4))] = sg[k][r];
     }
 #pragma unroll
     for (int k = 0; k < MAXIN; ++k) {
@@ -1581,7 +1587,8 @@ __global__ void __launch_bounds__(256, 3) k_wgrad_tile9(WgradArgs A, int tiles_x
   stage_load(t_beg);
   stage_store();
   __syncthreads();
-  const float* ga = gT + (16 * m + il) * WT_GP + 4 * q;    // + 16 pg
+  const float* ga = gT + (16 * m + il) * WT_GP;            // + ((16 pg + 4 q) ^ swizzle of this lane's channel)
+  const int gsw = WT_SWZ(16 * m + il);
   const float* ib = iT + (16 * kt + il) * IP + 4 * q;      // + (pg + kh) * HW   (TW = 16: pixel group pg is tile row pg)
   for (int tile = t_beg; tile < t_end; ++tile) {
     const bool more = tile + 1 < t_end;
@@ -1596,7 +1603,7 @@ __global__ void __launch_bounds__(256, 3) k_wgrad_tile9(WgradArgs A, int tiles_x
     }
 #pragma unroll
     for (int pg = 0; pg < 8; ++pg) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(ga + 16 * pg);
+      const f32x4 a = *reinterpret_cast<const f32x4*>(ga + ((16 * pg + 4 * q) ^ gsw));
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh) {
         const float* vp = ib + (pg + kh) * HW;
