@@ -404,14 +404,22 @@ class PluginReverseSDE(nn.Module):
     # ---- drift / diffusion (integrators call the stage kernel directly; these
     # keep the reference's call surface) ---------------------------------------
     def _stage(self, t, y, lmbd, strato):
-        tt = float(t.reshape(-1)[0]) if torch.is_tensor(t) else float(t)
         T = self.base_sde.T_float()
-        s = torch.full((y.shape[0],), T - tt, dtype=torch.float32, device=y.device)
+        B = y.shape[0]
+        if torch.is_tensor(t) and t.is_cuda:
+            # the reference passes t as a (B,1) device tensor filled with one value (sde_scheme.py:81): keep it on the device
+            # — the stage kernel reads its clock from t_dev — instead of a .item() round trip per mu() call
+            t0 = t.reshape(-1)[:1].to(device=y.device, dtype=torch.float32).contiguous()
+            s = (T - t0).expand(B).contiguous()
+            tt, t_dev = 0.0, t0
+        else:
+            tt, t_dev = (float(t.reshape(-1)[0]) if torch.is_tensor(t) else float(t)), None
+            s = torch.full((B,), T - tt, dtype=torch.float32, device=y.device)
         a = self.a(y, s)
         out = torch.empty_like(y)
         zero = torch.zeros_like(y)
         ops.sde_stage(out, None, 1.0, y.contiguous(), a, self.base_sde.struct(), L.PROC_REVERSE, strato, tt, 1.0,
-                      lmbd, dW=zero)
+                      lmbd, dW=zero, t_dev=t_dev)
         return out
 
     def mu(self, t, y, lmbd=0.):

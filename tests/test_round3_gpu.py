@@ -223,3 +223,18 @@ def test_msgm_trainer_graph_equals_eager_and_matches_ssm(kind):
     (l0, f0, s0), (l1, f1, s1) = out[False], out[True]
     assert l0 == l1 and torch.equal(f0, f1) and torch.equal(s0, s1)
     assert all(v == v for v in l0) and float((f0 - p0).abs().max()) > 0
+
+
+def test_mu_with_a_device_time_tensor_equals_the_scalar_call():
+    """The reference calls sde.mu(t, x) with t a (B,1) DEVICE tensor filled with one value (sde_scheme.py:81-83).  That form
+    stays on the device (the stage kernel reads its clock from the tensor: no .item() round trip per call) and equals the
+    host-scalar form bit for bit."""
+    from sdeflow_light_amd.NN import MLP
+    torch.manual_seed(2)
+    gen = make_gen("sgm", MLP(2))
+    y = torch.randn(64, 2, device=DEV)
+    t = 0.3125
+    for fn in (gen.mu, gen.mu_Strato):
+        a = fn(t, y, 0.5)
+        b = fn(torch.full((64, 1), t, device=DEV), y, 0.5)
+        assert torch.equal(a, b)
