@@ -24,7 +24,7 @@ with torch.no_grad():        # non-zero "zero-init" layers (model/nn_utils.py:15
 T = torch.nn.Parameter(torch.FloatTensor([1.0]), requires_grad=False)
 gen = PluginReverseSDE(SGMsde(T=T, num_steps_forward=16, device=dev), net, T, deviceReverseSDE=dev).to(dev)
 if not os.environ.get("EM_ONLY"):
-    tr = UNetScoreTrainer(gen, B, d, lr=1e-4)
+    tr = UNetScoreTrainer(gen, B, d, lr=1e-4, use_graph=not os.environ.get("NO_GRAPH"))
     tr.set_data(random_images(B, Cc, S_, S_, device=dev))
     for _ in range(2):
         l = tr.step()
