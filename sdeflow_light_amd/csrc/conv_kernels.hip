@@ -938,7 +938,14 @@ __global__ void __launch_bounds__(256) k_conv3x3_cout_small(ConvArgs A, int tile
 //     lanes: the 16 position-accumulators of a tile sit in the same lane;
 //   * the transformed weights U[pos][co][ci] (packed like Wp with 16 "taps" by k_wino_pack) stream L2 -> registers one
 //     position ahead.
-template <int NCO>
+//   * WL (weights through LDS, the default): the register form above keeps ONE position's weight fragments in flight — 8 MFMAs
+//     (256 cycles) to cover an L2 round trip of 500-900, and at 256 registers (two workgroups per CU) a deeper ring spills:
+//     MfmaUtil 32 %, 62 % of the wave cycles waiting (profiles/r03, PMC of the 1024-row EM step).  With WL the transformed
+//     weights of HALF a channel group (8 positions x 32 channels x 16 inputs = 16 KB) travel L2 -> LDS by LDS-DMA
+//     (global_load_lds_dwordx4: no registers), laid out as the A fragments themselves (one 1-KB piece per (position, co tile),
+//     lane-linear, conflict-free ds_read_b128), double-buffered: the DMA of half-group s + 1 is issued right after the barrier
+//     that opens half-group s and has that half-group's 64 MFMAs per wave (2 k cycles) to land.  LDS = halo 46.7 KB + 2 x 16 KB.
+template <int NCO, bool WL = false>
 __global__ void __launch_bounds__(256, 2) k_conv_wino(ConvArgs A, int tiles_x, int tiles_y, int n_tiles, int n_cob, int n_tgrp) {
   extern __shared__ __attribute__((aligned(16))) float cw_lds[];
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, il = lane & 15, q = lane >> 4;
@@ -1016,6 +1023,84 @@ __global__ void __launch_bounds__(256, 2) k_conv_wino(ConvArgs A, int tiles_x, i
   };
 
   const size_t a_co_stride = (size_t)16 * A.Ktot, pos_stride = (size_t)A.CoutP * A.Ktot;
+  if constexpr (WL) {
+    static_assert(NCO == 2, "the LDS weight image is laid out for two output-channel tiles");
+    float* wbuf = cw_lds + halo * CT_P;                       // [2 buffers][8 positions][2 co tiles][64 lanes][4]
+    auto ngrp_of = [&](int s_, int c_) { const int rem = A.C[s_] - c_ * CT_KC; return rem >= CT_KC ? 2 : ((rem + 15) >> 4); };
+    // the 16 pieces of one half-group: wave w copies pieces 4w .. 4w+3 (piece = 2 (position in the half) + co tile); lane
+    // (il, q) brings U[pos][co0 + 16 c + il][k .. k+3], k = 4 q of the group — exactly its A fragment
+    auto wfill = [&](int s_, int c_, int g_, int half, int b) __attribute__((always_inline)) {
+      const float* src = A.Wp + (size_t)(co0 + il) * A.Ktot + A.koff[s_] + c_ * CT_KC + 16 * g_ + 4 * q + (size_t)(8 * half) * pos_stride;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int pw = 4 * w + j;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)(pw >> 1) * pos_stride + (pw & 1) * a_co_stride),
+                                         (__attribute__((address_space(3))) void*)(wbuf + b * 4096 + pw * 256), 16, 0, 0);
+      }
+    };
+    int cs = 0, cc = 0, grp = 0, step = 0;
+    wfill(0, 0, 0, 0, 0);
+    for (;;) {
+      if (grp == 0) {                                         // a new 32-channel chunk: restage the halo
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");         // the previous chunk's readers are done
+        stage(cs, cc * CT_KC);
+      }
+      // the group that follows this one (its first half-group is requested during this group's second)
+      int ns = cs, nc = cc, ng = grp + 1;
+      bool more = true;
+      if (ng >= ngrp_of(cs, cc)) {
+        ng = 0; ++nc;
+        if (nc >= nch[cs]) { nc = 0; ++ns; more = ns < A.nsrc; }
+      }
+      f32x4 d[4][4];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        // this half-group's weights have landed (every wave waits for its own pieces, then all meet); the halo stores and
+        // the previous half-group's reads of the other buffer are behind the same barrier
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (half == 0) wfill(cs, cc, grp, 1, (step + 1) & 1);
+        else if (more) wfill(ns, nc, ng, 0, (step + 1) & 1);
+        if (half == 0) {
+          // ---- the lane's 4x4 patch (4 channels) and its transform V = B^T d B, in place
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[i][j] = *reinterpret_cast<const f32x4*>(cur + pbase + (i * HW + j) * CT_P + 16 * grp);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f32x4 r0 = d[0][j] - d[2][j], r1 = d[1][j] + d[2][j], r2 = d[2][j] - d[1][j], r3 = d[1][j] - d[3][j];
+            d[0][j] = r0; d[1][j] = r1; d[2][j] = r2; d[3][j] = r3;
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const f32x4 c0_ = d[i][0] - d[i][2], c1_ = d[i][1] + d[i][2], c2_ = d[i][2] - d[i][1], c3_ = d[i][1] - d[i][3];
+            d[i][0] = c0_; d[i][1] = c1_; d[i][2] = c2_; d[i][3] = c3_;
+          }
+        }
+        const float* wb = wbuf + (step & 1) * 4096 + lane * 4;
+        f32x4 a0 = *reinterpret_cast<const f32x4*>(wb), a1 = *reinterpret_cast<const f32x4*>(wb + 256);
+#pragma unroll
+        for (int pl = 0; pl < 8; ++pl) {
+          const f32x4 x0 = a0, x1 = a1;
+          if (pl < 7) {
+            a0 = *reinterpret_cast<const f32x4*>(wb + (2 * pl + 2) * 256);
+            a1 = *reinterpret_cast<const f32x4*>(wb + (2 * pl + 3) * 256);
+          }
+          const int pos = 8 * half + pl;
+          const f32x4 b = d[pos >> 2][pos & 3];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            acc[pos][0] = mfma16c(x0[r], b[r], acc[pos][0]);
+            acc[pos][1] = mfma16c(x1[r], b[r], acc[pos][1]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        ++step;
+      }
+      if (!more) break;
+      cs = ns; cc = nc; grp = ng;
+    }
+  } else
   for (int cs = 0; cs < A.nsrc; ++cs)
     for (int cc = 0; cc < (cs ? nch[1] : nch[0]); ++cc) {
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");           // the previous chunk's readers are done
@@ -1642,6 +1727,159 @@ __global__ void __launch_bounds__(256, 3) k_wgrad_tile9(WgradArgs A, int tiles_x
     }
 }
 
+// ------------------------------------------------------------------ wgrad of 1x1 convolutions: pixel-streaming kernel
+// dW[co][c] = sum_p gy[p][co] x[p][c] with the pixel as the reduction index: 2 Cout C / (4 (Cout + C)) = 8..48 FLOPs per
+// byte, i.e. HBM-bound below ~128 x 128 channels and MFMA-bound above.  k_wgrad_tile<., ., 1> splits dW into 32 x 32
+// blocks over blockIdx.y: every block re-stages its 128-pixel tile of gy and x (transposed, scalar LDS stores) for 8
+// MFMAs per wave between two barriers, and gy / x are fetched C / 32 and Cout / 32 times — it measured 51 TFLOP/s and
+// 2.4 TB/s whatever the shape (profiles/r03/bench_default_c4.json, "1x1 / strided conv wgrad").
+// Here ONE workgroup owns the whole C and up to 192 output channels, and streams over pixels: per PX-pixel tile it copies
+// the rows [gy | x] into LDS as they lie in memory (16-byte loads and stores, no transposition: the MFMA fragments are
+// dword reads, pixel = 16 g + 4 q + r for lane (il, q) and step r, conflict-free with a row pitch = 4 (mod 8) floats), the
+// four waves split the OUTPUT block (wave tile MT x NT: MT + NT LDS reads per MT NT MFMAs), two LDS buffers, one barrier
+// per tile, the next tile's global loads in flight under this tile's MFMAs.  Every gy / x byte is read once per output-
+// channel block (one block for Cout <= 192); the workgroup's partial dW goes to its slab (slot = blockIdx.x, reduced in
+// slot order like every other wgrad) or to dWp with float atomics, the bias gradient (column sums of the primal pixels'
+// gy rows) comes from the staged tile.
+// Pixels per staged tile for a row of W floats: the largest multiple of 16 with PX W <= 8192 floats (2 x 33 KB of LDS, two
+// workgroups per CU) whose float4 count is a multiple of 256, so that every thread stages exactly PX W / 1024 items.
+__host__ __device__ constexpr int w1_px(int W) {
+  int px = (8192 / W) / 16 * 16;
+  while (px > 16 && (px * W) % 1024) px -= 16;
+  return px > 128 ? 128 : px;
+}
+template <int MT, int NT, int WM>      // wave grid WM x (4 / WM) over (co, c); the workgroup covers 16 MT WM x 16 NT (4 / WM)
+__global__ void __launch_bounds__(256, 2) k_wgrad1x1(WgradArgs A, long Mtot, long Mbias, int tiles_per_wg, long n_tiles) {
+  extern __shared__ __attribute__((aligned(16))) float w1_lds[];
+  constexpr int WN = 4 / WM, COB = 16 * MT * WM, CB = 16 * NT * WN, W = COB + CB, PITCH = W + 4;
+  constexpr int G4 = COB / 4, R4 = W / 4;                       // float4 per row: gy part, both parts
+  constexpr int PX = w1_px(W), NST = PX * R4 / 256;             // staged items (float4) per thread and tile
+  static_assert(PX * R4 % 256 == 0 && NST >= 1 && NST <= 8, "tile does not divide over the threads");
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, il = lane & 15, q = lane >> 4;
+  const int wm = w / WN, wn = w - wm * WN;
+  const int co_blk = blockIdx.y * COB;
+  const long t_beg = (long)blockIdx.x * tiles_per_wg, t_end = min(t_beg + (long)tiles_per_wg, n_tiles);
+  if (t_beg >= t_end) return;
+  constexpr int buf_floats = PX * PITCH;
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0, 0, 0, 0};
+  // staging: item k of thread tid = float4 (tid + 256 k) of the tile = (row, j).  Everything about an item except the tile
+  // is fixed: its global pointer (advanced by one tile per iteration: two adds per item — the first version recomputed
+  // row / column / predicate / 64-bit address per item and tile, ~250 vector instructions per tile in front of 3-4 k MFMA
+  // cycles, with a branch around every load) and its LDS offset
+  const float* gp[NST];
+  int lo[NST], rowk[NST];
+  long gstep[NST];
+#pragma unroll
+  for (int k = 0; k < NST; ++k) {
+    const int idx = tid + 256 * k, row = idx / R4, j = idx - row * R4;       // divisions by a compile-time constant
+    const bool isg = j < G4;
+    gp[k] = isg ? A.gy + (size_t)(t_beg * PX + row) * A.Cout + co_blk + 4 * j : A.src + (size_t)(t_beg * PX + row) * A.C + 4 * (j - G4);
+    gstep[k] = (long)PX * (isg ? A.Cout : A.C);
+    lo[k] = row * PITCH + 4 * j;
+    rowk[k] = row;
+  }
+  f32x4 stA[NST];
+  // all tiles but a ragged last one are whole (Mtot is a multiple of PX for every U-Net layer): no predicate, no branch
+  const long n_full = Mtot / PX;
+  auto stage_load = [&](f32x4* st, long tile) __attribute__((always_inline)) {
+    if (tile < n_full) {
+#pragma unroll
+      for (int k = 0; k < NST; ++k) st[k] = *reinterpret_cast<const f32x4*>(gp[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NST; ++k) {
+        f32x4 v = {0, 0, 0, 0};
+        if (tile < n_tiles && tile * PX + rowk[k] < Mtot) v = *reinterpret_cast<const f32x4*>(gp[k]);
+        st[k] = v;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NST; ++k) gp[k] += gstep[k];
+  };
+  auto stage_store = [&](const f32x4* st, float* buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < NST; ++k) *reinterpret_cast<f32x4*>(buf + lo[k]) = st[k];
+  };
+  // bias gradient = column sums of gy over the primal pixels (p < Mbias, a multiple of 16): the wn == 0 waves add up the A
+  // fragments they read anyway (one fma per fragment), the four q lanes of a channel meet at the end
+  const bool do_bias = A.dbias != nullptr && wn == 0;
+  float ab[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) ab[m] = 0.f;
+  const int a_off = 4 * q * PITCH + 16 * wm * MT + il, b_off = 4 * q * PITCH + COB + 16 * wn * NT + il;
+  auto compute = [&](const float* buf, long tile) __attribute__((always_inline)) {
+#pragma unroll 2
+    for (int g = 0; g < PX / 16; ++g) {
+      const float* ap = buf + a_off + 16 * g * PITCH;
+      const float* bp = buf + b_off + 16 * g * PITCH;
+      const float pf = (do_bias && tile * PX + 16 * g < Mbias) ? 1.f : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a[MT], b[NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a[m] = ap[r * PITCH + 16 * m];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) b[n] = bp[r * PITCH + 16 * n];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) ab[m] = fmaf(pf, a[m], ab[m]);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[m][n] = mfma16c(a[m], b[n], acc[m][n]);
+      }
+    }
+  };
+  float* buf0 = w1_lds;
+  float* buf1 = w1_lds + buf_floats;
+  auto tl = [&](long t) { return t < t_end ? t : n_tiles; };    // past the workgroup's range: the ragged form, nothing loaded
+  stage_load(stA, t_beg);
+  stage_store(stA, buf0);
+  __syncthreads();
+  // (two tiles in flight — a second register set — and half-size tiles with four workgroups per CU were both measured:
+  // neither is faster, tools/bench_wgrad1x1.py; what paid was taking the address arithmetic out of the tile loop)
+  for (long tile = t_beg; tile < t_end; ++tile) {
+    stage_load(stA, tl(tile + 1));
+    compute(((tile - t_beg) & 1) ? buf1 : buf0, tile);
+    stage_store(stA, ((tile - t_beg) & 1) ? buf0 : buf1);
+    __syncthreads();
+  }
+  if (do_bias) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      float t = ab[m];
+      t += __shfl_xor(t, 16, 64);
+      t += __shfl_xor(t, 32, 64);
+      const int co = co_blk + 16 * (wm * MT + m) + il;
+      if (q == 0) {
+        if (A.slab) A.slab[(size_t)blockIdx.x * A.slab_stride + (size_t)A.CoutP * A.C + co] = t;
+        else atomicAdd(A.dbias + co, t);
+      }
+    }
+  }
+  if (A.slab) {
+    float* sl = A.slab + (size_t)blockIdx.x * A.slab_stride;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          sl[(size_t)(co_blk + 16 * (wm * MT + m) + 4 * q + r) * A.C + 16 * (wn * NT + n) + il] = acc[m][n][r];
+  } else {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          atomicAdd(A.dWp + ((size_t)(co_blk + 16 * (wm * MT + m) + 4 * q + r) * A.Ktot + A.koff + 16 * (wn * NT + n) + il), acc[m][n][r]);
+  }
+}
+
 // ------------------------------------------------------------------ weight (un)packing
 // Wp[t][r][kp_off + c] = W[r*sr + (col_off + c)*sc + t*st]   (r < rows, c < ncols); zero elsewhere is
 // provided by a memset of Wp before packing.
@@ -1915,7 +2153,19 @@ int msgm_conv_forward_wino(const msgm_conv_geom_t* geom, const float* src0, int3
   const int n_tiles = tiles_x * tiles_y * geom->N, gy = CoutP / 32;
   const size_t lds = (size_t)18 * 18 * CT_P * sizeof(float);
   dim3 grid((unsigned)(8 * gy * ((n_tiles + 7) / 8)));
-  hipLaunchKernelGGL((k_conv_wino<2>), grid, dim3(256), lds, S(stream), A, tiles_x, tiles_y, n_tiles, gy, n_tiles);
+  // one 32-channel chunk (Ktot = 32: the 64x64 32 -> 32 layers) has nothing to pipeline and pays the extra barriers: 96 vs
+  // 104 TFLOP/s as written; from 64 input channels on the LDS weights win, +2 .. +18 % (AFF=1 tools/bench_wino.py)
+  static const bool reg_weights = getenv("MSGM_WINO_REGW") != nullptr;    // A/B: the register weight ring everywhere
+  if (reg_weights || Ktot < 64) {
+    hipLaunchKernelGGL((k_conv_wino<2, false>), grid, dim3(256), lds, S(stream), A, tiles_x, tiles_y, n_tiles, gy, n_tiles);
+    return msgm_check_launch();
+  }
+  static const int once = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wino<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return 0;
+  }();
+  (void)once;
+  hipLaunchKernelGGL((k_conv_wino<2, true>), grid, dim3(256), lds + 2 * 4096 * sizeof(float), S(stream), A, tiles_x, tiles_y, n_tiles, gy, n_tiles);
   return msgm_check_launch();
 }
 
@@ -1947,10 +2197,12 @@ static ConvRoute conv_route(const msgm_conv_geom_t* geom, int32_t C0, bool has1,
   const int kg = Ktot / 16;
   if (!no1 && geom->KH == 1 && geom->KW == 1 && geom->strideH == 1 && geom->strideW == 1 && geom->padH == 0 && geom->padW == 0 &&
       !geom->ups && geom->Hi == geom->Ho && geom->Wi == geom->Wo && fast && !masks && (Mtot >= 4096 || any_size) &&
-      (kg == 2 || kg == 4 || kg == 6 || kg == 8 || kg == 12 || kg == 16) && Cout % 16 == 0 && !both_extra) {
+      (kg == 2 || kg == 4 || kg == 6 || kg == 8 || kg == 12 || kg == 16 || (kg == 24 && getenv("MSGM_C1_K24"))) && Cout % 16 == 0 && !both_extra) {
     // resident activations: PT * KG float4 per lane (<= 64 registers).  Fewer pixels per wave (more waves per SIMD) measured
     // equal at 64 input channels and 1.4x slower at 128 (tools/bench_1x1.py)
-    const int pt = kg <= 4 ? 4 : (kg <= 8 ? 2 : 1);
+    int pt = kg <= 4 ? 4 : (kg <= 8 ? 2 : 1);
+    static const int pt_x = getenv("MSGM_C1_PT") ? atoi(getenv("MSGM_C1_PT")) : 0;      // diagnostic: 2x the pixels per wave
+    if (pt_x && (kg == 8 || kg == 12)) pt *= 2;
     if ((geom->Ho * geom->Wo) % (16 * pt) == 0) { r.kind = 1; r.kg = kg; r.pt = pt; return r; }
   }
   static const float dummy = 0.f;
@@ -2098,8 +2350,9 @@ int msgm_conv_forward_fused(const msgm_conv_geom_t* geom, const float* src0, int
       case 2: C1_LAUNCH(4, 2); break;
       case 4: C1_LAUNCH(4, 4); break;
       case 6: C1_LAUNCH(2, 6); break;
-      case 8: C1_LAUNCH(2, 8); break;
-      case 12: C1_LAUNCH(1, 12); break;
+      case 8: if (rt.pt == 4) C1_LAUNCH(4, 8); else C1_LAUNCH(2, 8); break;
+      case 12: if (rt.pt == 2) C1_LAUNCH(2, 12); else C1_LAUNCH(1, 12); break;
+      case 24: C1_LAUNCH(1, 24); break;
       default: C1_LAUNCH(1, 16); break;
     }
 #undef C1_LAUNCH
@@ -2155,7 +2408,18 @@ int msgm_conv_forward_fused(const msgm_conv_geom_t* geom, const float* src0, int
 }
 
 // launch geometry shared by the launcher and the workspace query
-struct WgradPlan { bool tile; int wgs, per, tiles_x, tiles_y, n_tiles, yblocks; int64_t nchunks, chunk; int64_t bias_slots, bias_chunk; };
+struct WgradPlan { bool tile; int wgs, per, tiles_x, tiles_y, n_tiles, yblocks; int64_t nchunks, chunk; int64_t bias_slots, bias_chunk;
+                   bool one; int mt, nt, wm, px; int64_t n_tiles1; };
+// The pixel-streaming 1x1 wgrad (k_wgrad1x1): instance (MT, NT, WM) for (Cout, C), or mt = 0
+static void wgrad1x1_shape(int C, int Cout, int* mt, int* nt, int* wm) {
+  *mt = 0; *nt = 0; *wm = 4;
+  if (C != 32 && C != 64 && C != 128 && C != 256) return;
+  if (Cout == 32 && C <= 128) { *mt = 1; *nt = C / 32; *wm = 2; return; }
+  if (Cout % 64) return;
+  *nt = C / 16;
+  if (C == 256) { *mt = 1; return; }
+  *mt = Cout % 192 == 0 ? 3 : (Cout % 128 == 0 ? 2 : 1);
+}
 static WgradPlan wgrad_plan(const msgm_conv_geom_t* geom, int C, int Cout, int n_bias) {
   WgradPlan p{};
   const int64_t Mtot = (int64_t)geom->N * geom->Ho * geom->Wo;
@@ -2164,6 +2428,25 @@ static WgradPlan wgrad_plan(const msgm_conv_geom_t* geom, int C, int Cout, int n
   const bool same = geom->mode == 0 && geom->strideH == 1 && geom->strideW == 1 && (geom->Hi << ups_sh) == geom->Ho &&
                     (geom->Wi << ups_sh) == geom->Wo && (geom->KH & 1) && (geom->KW & 1) && geom->padH == (geom->KH - 1) / 2 &&
                     geom->padW == (geom->KW - 1) / 2 && geom->KH <= 3 && geom->KW <= 3;
+  if (taps == 1 && same && !geom->ups && geom->padH == 0 && geom->padW == 0 && ((int64_t)n_bias * geom->Ho * geom->Wo) % 16 == 0 &&
+      !getenv("MSGM_NO_WGRAD1X1")) {
+    wgrad1x1_shape(C, Cout, &p.mt, &p.nt, &p.wm);
+    if (p.mt) {
+      p.one = true;
+      const int COB = 16 * p.mt * p.wm, Wd = COB + C;
+      p.px = w1_px(Wd);                                     // = k_wgrad1x1's PX
+      p.yblocks = Cout / COB;
+      p.n_tiles1 = (Mtot + p.px - 1) / p.px;
+      int wgs = 512 / p.yblocks;                            // two resident workgroups per CU (2 x 33 KB of LDS each)
+      int64_t per = (p.n_tiles1 + wgs - 1) / wgs;
+      int per_min = COB * C / 4096;                         // a workgroup's slab (COB x C) should stay well below what it reads
+      per_min = per_min < 2 ? 2 : (per_min > 8 ? 8 : per_min);
+      if (per < per_min) per = p.n_tiles1 < per_min ? p.n_tiles1 : per_min;
+      p.per = (int)per;
+      p.wgs = (int)((p.n_tiles1 + per - 1) / per);
+      return p;
+    }
+  }
   const bool aligned = C % 4 == 0 && Cout % 4 == 0;      // otherwise only the 2-D 3x3 form has the element-wise staging (RAG)
   p.tile = same && (aligned || (taps == 9 && geom->Ho > 1 && !getenv("MSGM_NO_WGRAD_RAG"))) && (int64_t)geom->Ho * geom->Wo >= 64 &&
            (taps == 1 || taps == 3 || (taps == 9 && geom->Ho > 1)) && (geom->Ho > 1 || geom->KH == 1) && !getenv("MSGM_NO_WGRAD_TILE");
@@ -2214,7 +2497,7 @@ size_t msgm_conv_wgrad_workspace(const msgm_conv_geom_t* geom, int32_t C, int32_
   if (check_geom(geom) || C <= 0 || Cout <= 0 || CoutP < Cout) return 0;
   const WgradPlan p = wgrad_plan(geom, C, Cout, n_bias);
   const size_t stride = (size_t)geom->KH * geom->KW * CoutP * C + CoutP;
-  const size_t slots = p.tile ? (size_t)p.wgs : (size_t)p.nchunks;
+  const size_t slots = (p.tile || p.one) ? (size_t)p.wgs : (size_t)p.nchunks;
   return (slots * stride + (size_t)p.bias_slots * Cout) * sizeof(float);
 }
 
@@ -2278,6 +2561,43 @@ static int wgrad_impl(const msgm_conv_geom_t* geom, const float* gy, const float
     hipLaunchKernelGGL(k_slot_reduce, dim3((unsigned)nb), dim3(256), 0, S(stream), (const float*)ws, nslots, A.slab_stride, img,
                        dWp, C, Ktot, koff, 1, CoutP, Cout, with_bias ? (long)Cout : 0L, dbias);
   };
+  if (pl.one) {
+    if (tapmask_c32 || tapmask_co32) return MSGM_E_UNSUPPORTED;      // a 1x1 kernel has no taps to mask
+    const long Mtot = (long)geom->N * geom->Ho * geom->Wo, Mbias = dbias ? (long)n_bias * geom->Ho * geom->Wo : 0;
+    const int COB = 16 * pl.mt * pl.wm;
+    const size_t lds = (size_t)2 * pl.px * (COB + C + 4) * sizeof(float);
+    dim3 grid((unsigned)pl.wgs, (unsigned)pl.yblocks);
+#define W1_LAUNCH(MT_, NT_, WM_)                                                                                      \
+  do {                                                                                                               \
+    static const int once = [] {                                                                                     \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad1x1<MT_, NT_, WM_>),                           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                             \
+      return 0;                                                                                                      \
+    }();                                                                                                             \
+    (void)once;                                                                                                      \
+    hipLaunchKernelGGL((k_wgrad1x1<MT_, NT_, WM_>), grid, dim3(256), lds, S(stream), A, Mtot, Mbias, pl.per, (long)pl.n_tiles1); \
+  } while (0)
+    const int key = pl.wm * 10000 + pl.mt * 100 + pl.nt;
+    switch (key) {
+      case 20101: W1_LAUNCH(1, 1, 2); break;
+      case 20102: W1_LAUNCH(1, 2, 2); break;
+      case 20104: W1_LAUNCH(1, 4, 2); break;
+      case 40102: W1_LAUNCH(1, 2, 4); break;
+      case 40202: W1_LAUNCH(2, 2, 4); break;
+      case 40302: W1_LAUNCH(3, 2, 4); break;
+      case 40104: W1_LAUNCH(1, 4, 4); break;
+      case 40204: W1_LAUNCH(2, 4, 4); break;
+      case 40304: W1_LAUNCH(3, 4, 4); break;
+      case 40108: W1_LAUNCH(1, 8, 4); break;
+      case 40208: W1_LAUNCH(2, 8, 4); break;
+      case 40308: W1_LAUNCH(3, 8, 4); break;
+      case 40116: W1_LAUNCH(1, 16, 4); break;
+      default: return MSGM_E_UNSUPPORTED;
+    }
+#undef W1_LAUNCH
+    if (det) reduce_slabs(pl.wgs, dbias != nullptr);
+    return msgm_check_launch();
+  }
   if (pl.tile) {
     const bool two_d = geom->Ho > 1;
     const int TH = two_d ? 8 : 1, TW = two_d ? 16 : 128;

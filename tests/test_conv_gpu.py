@@ -294,7 +294,10 @@ def test_stride2_pair_op_fwd_bwd(kind, N, Cin, Cout, L):
 
 @pytest.mark.parametrize("N,H,Ci,Co,two,ups,aff", [(3, 32, 64, 64, False, False, False), (2, 64, 32, 32, False, False, True),
                                                    (2, 32, 64, 32, True, False, True), (2, 16, 128, 128, False, False, False),
-                                                   (2, 16, 64, 64, False, True, False), (1, 16, 32, 96, False, False, True)])
+                                                   (2, 16, 64, 64, False, True, False), (1, 16, 32, 96, False, False, True),
+                                                   # the LDS-weight form (>= 64 input channels) with ragged 16-channel tails
+                                                   (2, 16, 48, 64, True, False, True), (1, 32, 80, 32, False, False, False),
+                                                   (2, 16, 144, 96, True, True, True)])
 def test_winograd_forward_equals_direct_conv(N, H, Ci, Co, two, ups, aff):
     """Winograd F(2x2,3x3) forward (sampler path) vs the direct halo-tile kernel on the same inputs and fused options:
     second source, folded 2x upsample, GroupNorm(+SiLU) input transform, bias, per-sample bias, residual.  Both are fp32;
@@ -508,3 +511,40 @@ def test_pixel_stationary_1x1_kernel(N, C0, C1, Cout, T, aff, extra):
     o = out.view(N, T, Cout).double()
     tot = cs.view(N, S, 2, Cout).double().sum(1)
     assert rel_l2(tot[:, 0].cpu(), o.sum(1).cpu()) <= 2e-6 and rel_l2(tot[:, 1].cpu(), (o * o).sum(1).cpu()) <= 2e-6
+
+
+# every (MT, NT, WM) instance of the pixel-streaming 1x1 wgrad (k_wgrad1x1), 1-D and 2-D pixel grids, pixel counts that are
+# not a multiple of the staged tile, primal rows < N (the bias gradient stops at n_bias), both the slot-ordered
+# (deterministic, default) and the float-atomic form, accumulation into a non-zero packed image at a K offset
+@pytest.mark.parametrize("N,nb,C,Cout,H,W_", [(3, 2, 32, 32, 8, 8), (2, 1, 64, 32, 16, 16), (2, 2, 128, 32, 8, 8),
+                                              (3, 2, 32, 64, 1, 80), (2, 1, 32, 128, 8, 8), (2, 1, 32, 192, 4, 4),
+                                              (5, 3, 64, 64, 1, 48), (2, 1, 64, 128, 8, 8), (3, 2, 64, 192, 1, 272),
+                                              (2, 1, 128, 64, 8, 8), (3, 2, 128, 128, 16, 16), (2, 1, 128, 384, 1, 256),
+                                              (2, 1, 256, 64, 8, 8), (2, 2, 256, 128, 8, 8)])
+@pytest.mark.parametrize("atomic", [False, True])
+def test_wgrad_1x1_pixel_streaming(N, nb, C, Cout, H, W_, atomic, monkeypatch):
+    from sdeflow_light_amd import ops
+    if atomic:
+        monkeypatch.setenv("MSGM_ATOMIC_WGRAD", "1")
+    torch.manual_seed(C + Cout + H)
+    P = H * W_
+    gy = torch.randn(N * P, Cout)
+    x = torch.randn(N * P, C)
+    koff, Ktot = 16, C + 32                                   # this source sits at K offset 16 of a wider packed image
+    geom = ops.conv_geom(N, H, W_, H, W_, 1, 1, 1, 0, 0, 0)
+    dWp0 = torch.randn(Cout * Ktot)
+    db0 = torch.randn(Cout)
+    dWp, db = dWp0.clone().to(DEV), db0.clone().to(DEV)
+    ops.conv_wgrad(geom, gy.to(DEV), x.to(DEV), C, koff, dWp, Cout, Cout, Ktot, dbias=db, n_bias=nb)
+    want = dWp0.view(Cout, Ktot).double().clone()
+    want[:, koff:koff + C] += gy.double().t() @ x.double()
+    assert rel_l2(dWp.view(Cout, Ktot).cpu().double(), want) <= 1e-6
+    # columns outside this source's K range are untouched
+    got = dWp.view(Cout, Ktot).cpu()
+    assert torch.equal(got[:, :koff], dWp0.view(Cout, Ktot)[:, :koff]) and torch.equal(got[:, koff + C:], dWp0.view(Cout, Ktot)[:, koff + C:])
+    wb = db0.double() + gy[: nb * P].double().sum(0)
+    assert rel_l2(db.cpu().double(), wb) <= 1e-6
+    if not atomic:                                            # slot order: the same bits every time
+        dWp2, db2 = dWp0.clone().to(DEV), db0.clone().to(DEV)
+        ops.conv_wgrad(geom, gy.to(DEV), x.to(DEV), C, koff, dWp2, Cout, Cout, Ktot, dbias=db2, n_bias=nb)
+        assert torch.equal(dWp2, dWp) and torch.equal(db2, db)

@@ -13,7 +13,8 @@ def timeit(fn, it=10):
         a.record(); fn(); b.record()
     torch.cuda.synchronize()
     return sum(a.elapsed_time(b) for a, b in ev) / it * 1e-3
-for (T, Ci, Co) in ((1024, 64, 64), (1024, 64, 192), (256, 128, 128), (256, 128, 384), (4096, 96, 32)):
+for (T, Ci, Co) in ((1024, 64, 64), (1024, 64, 192), (1024, 192, 64), (256, 128, 128), (256, 128, 384), (256, 384, 128), (256, 256, 128), (256, 192, 128),
+                    (1024, 128, 64), (4096, 96, 32)):
     x = torch.randn(N * T * Ci, device=dev)
     Wp = torch.randn(ops.pad16(Co) * ops.pad16(Ci), device=dev) * 0.05
     out = torch.empty(N * T * Co, device=dev)
