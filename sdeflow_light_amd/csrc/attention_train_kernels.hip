@@ -228,12 +228,20 @@ __global__ void __launch_bounds__(256) k_attn_dual_delta(const float* __restrict
 //            waves (wave (qs, kg) takes channel tiles kg, kg + KG, ...) -> one slab row per (key block, query).
 // KG = 4 (64 keys, 8 waves) for C <= 64; KG = 2 (32 keys, 4 waves) for C = 128, where the four resident key-side tiles of
 // 64 keys alone would be 135 KB of LDS (the T = 256 blocks of the C4 network, model/unet.py:236-250 at (ch, T) = (128, 256)).
-template <int CT, int KG>
+// Key-block SEQUENCING (the query-gradient slabs): at T = 1024 a sample has 16 key blocks, i.e. 16 slabs of [2Bp][T][C] that
+// k_attn_dq_reduce read back (3.4 ms of the C4 step, HBM-bound).  The launcher may run the kernel kseq times over every
+// kseq-th key block (launch ks takes key blocks kgi kseq + ks): launches ks > 0 (ACC) ADD their partial sums to the slab
+// rows of their group instead of writing rows of their own — one 16-byte load per store, requested before the MFMAs whose
+// result it joins — so the reduction reads nkg = T / (KB kseq) slabs.  Same fixed summation order every run.  (An in-kernel
+// loop over the key blocks of a group was tried first: it needs ~37 more registers than the 246 the kernel has, spilled, and
+// ran the whole step 1 ms SLOWER at kseq = 1; it also exposed a hipcc hazard bug — no wait states between an MFMA and a global
+// store of its result when a branch sits in between — which a compile-time ACC cannot hit.)
+template <int CT, int KG, bool ACC = false>
 __global__ void __launch_bounds__(128 * KG) k_attn_dual_bwd(const float* __restrict__ qkv, const float* __restrict__ datt,
                                                         const float* __restrict__ stats /* [2][Bp*T]: lse | rbar */,
                                                         const float* __restrict__ ccde /* [2][Bp*T]: c | delta */,
-                                                        float* __restrict__ dqkv, float* __restrict__ slab, int T, int nkb,
-                                                        int64_t Bp, float scale) {
+                                                        float* __restrict__ dqkv, float* __restrict__ slab, int T, int nkg,
+                                                        int kseq, int ks, int64_t Bp, float scale) {
   constexpr int C = 16 * CT, KP = C + 4, LD = 3 * C, KB = 16 * KG, DP = KB + 4, QB = 32, NT = 128 * KG;
   constexpr int NK = (KB * C / 4) / NT;                   // float4 per thread per resident matrix
   constexpr int NQ = (QB * C / 4 + NT - 1) / NT;          // float4 per thread per streamed matrix and query block
@@ -253,12 +261,13 @@ __global__ void __launch_bounds__(128 * KG) k_attn_dual_bwd(const float* __restr
                                                           // next block's phase 1 may start while a slow wave is still in phase 2
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, il = lane & 15, q = lane >> 4;
   const int qs = w & 1, kg = w >> 1;
-  int smp, kb;                                             // XCD-aware order (see the forward kernel): the key blocks
+  int smp, kgi;                                            // XCD-aware order (see the forward kernel): the key groups
   {                                                        // of one sample stream the same q / g rows
-    const int full = (int)(Bp / 8) * 8 * nkb, b = blockIdx.x;
-    if (b < full) { const int loc = b >> 3; smp = (loc / nkb) * 8 + (b & 7); kb = loc % nkb; }
-    else { const int r = b - full; smp = (int)(Bp / 8) * 8 + r / nkb; kb = r % nkb; }
+    const int full = (int)(Bp / 8) * 8 * nkg, b = blockIdx.x;
+    if (b < full) { const int loc = b >> 3; smp = (loc / nkg) * 8 + (b & 7); kgi = loc % nkg; }
+    else { const int r = b - full; smp = (int)(Bp / 8) * 8 + r / nkg; kgi = r % nkg; }
   }
+  const int kb = kgi * kseq + ks;
   const size_t half_qkv = (size_t)Bp * T * LD, half_att = (size_t)Bp * T * C;
   const float* bp = qkv + (size_t)smp * T * LD;
   const float* gp = datt + (size_t)smp * T * C;
@@ -379,7 +388,14 @@ __global__ void __launch_bounds__(128 * KG) k_attn_dual_bwd(const float* __restr
     // ---- phase 2: qbar^T[c][query] += K^T Sbar^T + Kd^T Sdbar^T ; qdbar^T += K^T Sdbar^T   (wave (qs, kg): tiles ct = kg, kg+KG, ..)
 #pragma unroll
     for (int ct = kg; ct < CT; ct += KG) {
-      f32x4 dq = {0, 0, 0, 0}, dqd = {0, 0, 0, 0};
+      const size_t row = (size_t)qb * QB + 16 * qs + il;
+      float* sp = slab + (((size_t)smp * nkg + kgi) * T + row) * C + 16 * ct + 4 * q;
+      float* sdp = slab + (((size_t)(Bp + smp) * nkg + kgi) * T + row) * C + 16 * ct + 4 * q;
+      f32x4 dq = {0, 0, 0, 0}, dqd = {0, 0, 0, 0}, pdq = {0, 0, 0, 0}, pdqd = {0, 0, 0, 0};
+      if (ACC) {          // compile-time: what the earlier launches left for this key group — requested BEFORE the MFMAs it joins
+        pdq = *reinterpret_cast<const f32x4*>(sp);
+        pdqd = *reinterpret_cast<const f32x4*>(sdp);
+      }
 #pragma unroll
       for (int kt = 0; kt < KG; ++kt) {
         const f32x4 b1 = *reinterpret_cast<const f32x4*>(dS + (16 * qs + il) * DP + 16 * kt + 4 * q);
@@ -397,12 +413,10 @@ __global__ void __launch_bounds__(128 * KG) k_attn_dual_bwd(const float* __restr
           dq = mfma16t(a2[r], b2[r], dq);
         }
       }
-      const size_t row = (size_t)qb * QB + 16 * qs + il;
-      float* sp = slab + (((size_t)smp * nkb + kb) * T + row) * C + 16 * ct + 4 * q;
-      float* sdp = slab + (((size_t)(Bp + smp) * nkb + kb) * T + row) * C + 16 * ct + 4 * q;
 #ifdef ATT_EXP_NODQ           // diagnostic (WRONG results): what the query-gradient slab stores cost inside the loop
       if (dq[0] == 12345.678f) { *reinterpret_cast<f32x4*>(sp) = dq; *reinterpret_cast<f32x4*>(sdp) = dqd; }
 #else
+      if (ACC) { dq += pdq; dqd += pdqd; }
       *reinterpret_cast<f32x4*>(sp) = dq;
       *reinterpret_cast<f32x4*>(sdp) = dqd;
 #endif
@@ -478,23 +492,38 @@ static int launch_bwd(const float* qkv, const float* att, const float* datt, con
   constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
   static_assert(lds <= 160 * 1024, "backward tiles exceed the CU's LDS");
   static const int once = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_dual_bwd<CT, KG>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_dual_bwd<CT, KG, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_dual_bwd<CT, KG, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
     return 0;
   }();
   (void)once;
   const int64_t rows = Bp * T;
   const int nkb = T / KB;
+  // launches over the key blocks: two while each launch still has two full rounds of resident workgroups (two per CU).
+  // Measured at B = 256 (rocprofv3, 7 steps): one launch 147.2 + 29.1 ms in the two backward kernels + 24.0 ms of reduce;
+  // two launches 154.1 + 32.4 + 10.5; four 157.5 + 34.4 + 5.3 — the ACC launches run 7 % (C = 64) to 20 % (C = 128) longer
+  // than the plain ones (their slab reads are not free under the MFMAs), so two and four both end 0.8 ms per step ahead.
+  static const int kseq_x = getenv("MSGM_ATTN_KSEQ") ? atoi(getenv("MSGM_ATTN_KSEQ")) : 0;      // diagnostic override
+  int kseq = 1;
+  for (int k = 2; k > 1; k >>= 1)
+    if (nkb % k == 0 && Bp * (int64_t)(nkb / k) >= 1024) { kseq = k; break; }
+  if (kseq_x > 0 && nkb % kseq_x == 0) kseq = kseq_x;
+  const int nkg = nkb / kseq;
   float* cc = ws;
   float* de = ws + rows;
   float* slab = ws + 2 * rows;
   hipLaunchKernelGGL(k_attn_dual_delta, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, att, datt, stats + rows, cc, de,
                      rows, C);
-  hipLaunchKernelGGL((k_attn_dual_bwd<CT, KG>), dim3((unsigned)(Bp * nkb)), dim3(128 * KG), lds, st, qkv, datt, stats, cc, dqkv, slab, T,
-                     nkb, Bp, scale);
+  hipLaunchKernelGGL((k_attn_dual_bwd<CT, KG, false>), dim3((unsigned)(Bp * nkg)), dim3(128 * KG), lds, st, qkv, datt, stats, cc, dqkv, slab,
+                     T, nkg, kseq, 0, Bp, scale);
+  for (int ks = 1; ks < kseq; ++ks)
+    hipLaunchKernelGGL((k_attn_dual_bwd<CT, KG, true>), dim3((unsigned)(Bp * nkg)), dim3(128 * KG), lds, st, qkv, datt, stats, cc, dqkv, slab,
+                       T, nkg, kseq, ks, Bp, scale);
   const int64_t work = 2 * Bp * T * (C / 4);
   hipLaunchKernelGGL(k_attn_dq_reduce, dim3((unsigned)grid_for(work, 256, 16384)), dim3(256), 0, st, slab, dqkv, 2 * Bp, T, C,
-                     nkb, scale);
+                     nkg, scale);
   return msgm_check_launch();
 }
 

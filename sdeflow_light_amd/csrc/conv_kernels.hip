@@ -2197,12 +2197,13 @@ static ConvRoute conv_route(const msgm_conv_geom_t* geom, int32_t C0, bool has1,
   const int kg = Ktot / 16;
   if (!no1 && geom->KH == 1 && geom->KW == 1 && geom->strideH == 1 && geom->strideW == 1 && geom->padH == 0 && geom->padW == 0 &&
       !geom->ups && geom->Hi == geom->Ho && geom->Wi == geom->Wo && fast && !masks && (Mtot >= 4096 || any_size) &&
-      (kg == 2 || kg == 4 || kg == 6 || kg == 8 || kg == 12 || kg == 16 || (kg == 24 && getenv("MSGM_C1_K24"))) && Cout % 16 == 0 && !both_extra) {
+      (kg == 2 || kg == 4 || kg == 6 || kg == 8 || kg == 12 || kg == 16) && Cout % 16 == 0 && !both_extra) {
     // resident activations: PT * KG float4 per lane (<= 64 registers).  Fewer pixels per wave (more waves per SIMD) measured
     // equal at 64 input channels and 1.4x slower at 128 (tools/bench_1x1.py)
-    int pt = kg <= 4 ? 4 : (kg <= 8 ? 2 : 1);
-    static const int pt_x = getenv("MSGM_C1_PT") ? atoi(getenv("MSGM_C1_PT")) : 0;      // diagnostic: 2x the pixels per wave
-    if (pt_x && (kg == 8 || kg == 12)) pt *= 2;
+    // r3: 192 input channels with 32 pixels per wave (96 resident registers) 268 -> 207 us (192 -> 64 at 524 k pixels) and
+    // 111 -> 78 us (192 -> 128 at 131 k); 128 channels with 64 pixels per wave were SLOWER (60 -> 74 us), and a 384-channel
+    // instance lost to the halo-tile kernel (223 vs 203 us) — tools/bench_1x1.py
+    const int pt = kg <= 4 ? 4 : (kg <= 8 ? 2 : (kg == 12 && (geom->Ho * geom->Wo) % 32 == 0 ? 2 : 1));
     if ((geom->Ho * geom->Wo) % (16 * pt) == 0) { r.kind = 1; r.kg = kg; r.pt = pt; return r; }
   }
   static const float dummy = 0.f;
@@ -2350,9 +2351,8 @@ int msgm_conv_forward_fused(const msgm_conv_geom_t* geom, const float* src0, int
       case 2: C1_LAUNCH(4, 2); break;
       case 4: C1_LAUNCH(4, 4); break;
       case 6: C1_LAUNCH(2, 6); break;
-      case 8: if (rt.pt == 4) C1_LAUNCH(4, 8); else C1_LAUNCH(2, 8); break;
+      case 8: C1_LAUNCH(2, 8); break;
       case 12: if (rt.pt == 2) C1_LAUNCH(2, 12); else C1_LAUNCH(1, 12); break;
-      case 24: C1_LAUNCH(1, 24); break;
       default: C1_LAUNCH(1, 16); break;
     }
 #undef C1_LAUNCH

@@ -465,7 +465,9 @@ def test_unet_output_conv_small_cout(N, nb, Cout, H, W_, aff):
                                                         (6, 64, 0, 64, 1024, False, "residual"),   # proj_out + x
                                                         (24, 128, 64, 128, 256, False, None),      # decoder skip conv, two sources
                                                         (10, 128, 0, 384, 512, True, "accumulate"),
-                                                        (3, 32, 0, 32, 4096, False, "residual")])
+                                                        (3, 32, 0, 32, 4096, False, "residual"),
+                                                        (20, 192, 0, 64, 272, False, None),        # 192 channels, 16 pixels per wave (T % 32 != 0)
+                                                        (16, 192, 0, 64, 256, True, "residual")])  # ... and 32 per wave
 def test_pixel_stationary_1x1_kernel(N, C0, C1, Cout, T, aff, extra):
     """k_conv1x1 (1x1 convolutions with >= 4096 pixels: qkv / proj_out / skip convs, model/unet.py:216-232,158) with its
     fused options — folded GroupNorm(+SiLU) on the input, second source, residual / accumulate in the epilogue, per-sample

@@ -9,7 +9,7 @@ LL = "/opt/rocm/lib/llvm/bin"
 obj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "sdeflow_light_amd", "build", sys.argv[1] + ".o")
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
 with tempfile.TemporaryDirectory() as T:
-    subprocess.check_call([f"{LL}/llvm-objcopy", f"--dump-section=.hip_fatbin={T}/fat.bin", obj])
+    subprocess.check_call([f"{LL}/llvm-objcopy", f"--dump-section=.hip_fatbin={T}/fat.bin", obj, f"{T}/copy.o"])   # an output file: objcopy rewrites its input otherwise
     subprocess.check_call([f"{LL}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={T}/fat.bin",
                            "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={T}/k.co"])
     txt = subprocess.check_output([f"{LL}/llvm-readelf", "--notes", f"{T}/k.co"], text=True)
