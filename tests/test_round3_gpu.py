@@ -244,13 +244,18 @@ def test_unet2d_reference_loop_adam_steps_wellconditioned():
     """The reference loop (zero_grad / ssm(x).mean() / backward / Adam.step, MSGM_higherDim.py:803-809) for two iterations
     on the 2-D U-Net at 32x32 (fused dual attention at T = 256, C = 64 and T = 64, C = 128) with the WELL-CONDITIONED fill,
     against the oracle doing the same on the CPU.  With the sinusoidal fill of test_unet2d_gpu.py this comparison is the
-    loosest pin of the suite (loss sequence 2.4e-4); here the loss sequence is held to 2e-6 (measured 5.6e-7) — it sees every parameter that
-    matters after each update.  (Parameters themselves: tensors with an analytically zero gradient — conv biases in front
+    loosest pin of the suite (loss sequence 2.4e-4); here the loss sequence is held to 1e-5 — it sees every parameter that
+    matters after each update.  The measured value moves with ROUNDING on either side, because Adam's first steps are
+    lr * sign(g) wherever |g| >> eps: 5.6e-7 with the oracle on all host threads, 3.6e-6 with the oracle on 16 threads (an
+    earlier test of the suite sets that; the CPU convolutions then add in another order) and the pixel-streaming 1x1 weight-gradient
+    kernel of r3 — same HIP bits in both runs (tools/debug_poison.py: no kernel of the pass reads memory it did not write).
+    The oracle's thread count is pinned here so that the number does not depend on which tests ran before.  (Parameters themselves: tensors with an analytically zero gradient — conv biases in front
     of a GroupNorm — take +-lr rounding-noise steps under Adam in ANY implementation, so they are bounded, not compared.)"""
     from conftest import within
     from oracle import sde_ref as S, nets_ref as N, ssm_ref as LR
     from oracle.det_params import load_init_like_
     from sdeflow_light_amd.NNUnet import VorticityUNet
+    torch.set_num_threads(min(16, torch.get_num_threads()))
     torch.manual_seed(8)
     net = VorticityUNet(base_channels=32, channel_mults=(1, 2, 4), num_res_blocks=2, premodule=None, in_space=32,
                         attention_resolutions=(2, 4), flatten_order="F")
@@ -277,8 +282,8 @@ def test_unet2d_reference_loop_adam_steps_wellconditioned():
         losses_ref.append(float(lref))
         for k in ref:
             ref[k], m[k], vv[k] = LR.adam_step(ref[k], gref[k], m[k], vv[k], it + 1, lr=1e-4)
-    within(max(abs(a_ - b_) / abs(b_) for a_, b_ in zip(losses, losses_ref)), 2e-6,
-           "2 Adam steps, 2-D U-Net 32x32, well-conditioned fill: loss sequence rel. error")          # measured 5.6e-07
+    within(max(abs(a_ - b_) / abs(b_) for a_, b_ in zip(losses, losses_ref)), 1e-5,
+           "2 Adam steps, 2-D U-Net 32x32, well-conditioned fill: loss sequence rel. error")          # measured 3.6e-06 (see above)
     flat = torch.cat([p_.detach().reshape(-1).cpu() for _, p_ in net.named_parameters()])
     flat_ref = torch.cat([ref[k].reshape(-1) for k, _ in net.named_parameters()])
     assert float((flat - flat_ref).abs().max()) <= 2 * 2 * 1e-4 + 1e-7          # nobody moved further than Adam allows

@@ -518,7 +518,10 @@ def test_flat_img_helpers_match_reference_semantics(order):
 
 
 @pytest.mark.parametrize("Bp,T,C", [(3, 64, 32), (2, 128, 64), (2, 320, 64), (1, 1024, 64), (5, 192, 32),
-                                    (2, 256, 128), (3, 64, 128), (1, 32, 128), (9, 96, 128), (40, 256, 128)])   # C = 128: the 16x16 / 8x8 blocks (r3)
+                                    (2, 256, 128), (3, 64, 128), (1, 32, 128), (9, 96, 128), (40, 256, 128),   # C = 128: the 16x16 / 8x8 blocks (r3)
+                                    # launches big enough for the backward's TWO passes over the key blocks (the second adds to
+                                    # the first's query-gradient slab rows): Bp * T / keys-per-workgroup >= 2048
+                                    (1024, 128, 32), (512, 256, 64), (1024, 64, 128)])
 def test_fused_dual_attention_forward_backward(Bp, T, C):
     """K8 (training path): attention on dual numbers, forward and backward, without the (T,T) tensors — vs plain PyTorch
     fp32 (torch.func.jvp of QKVAttention.forward's arithmetic, model/unet.py:236-250, then autograd of the pair)."""
