@@ -504,7 +504,7 @@ static int launch_bwd(const float* qkv, const float* att, const float* datt, con
   // launches over the key blocks: two while each launch still has two full rounds of resident workgroups (two per CU).
   // Measured at B = 256 (rocprofv3, 7 steps): one launch 147.2 + 29.1 ms in the two backward kernels + 24.0 ms of reduce;
   // two launches 154.1 + 32.4 + 10.5; four 157.5 + 34.4 + 5.3 — the ACC launches run 7 % (C = 64) to 20 % (C = 128) longer
-  // than the plain ones (their slab reads are not free under the MFMAs), so two and four both end 0.8 ms per step ahead.
+  // than the plain ones (their slab reads are not free under the MFMAs), so two and four both end 0.5 ms per step ahead.
   static const int kseq_x = getenv("MSGM_ATTN_KSEQ") ? atoi(getenv("MSGM_ATTN_KSEQ")) : 0;      // diagnostic override
   int kseq = 1;
   for (int k = 2; k > 1; k >>= 1)
