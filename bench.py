@@ -668,6 +668,20 @@ def worker(a):
             log("c5: sampling leg")
             s = leg_sample_unet(gen, d, a, rank, world, dev)
             out.update(sample_steps_per_s=s["sample_steps_per_s"], sample=s)
+            if world == 1 and not a.no_extra:
+                # opt-in experiment, reported beside the line, never on it: the SAME sampling leg with the 3x3
+                # convolutions in bf16-split arithmetic (tests: fp32-grade against float64 and against the default sampler)
+                log("c5: sampling leg, bf16-split 3x3 convolutions (opt-in experiment)")
+                free_gpu()
+                os.environ["MSGM_SAMPLER_BF16X3"] = "1"
+                try:
+                    s6 = leg_sample_unet(gen, d, a, rank, world, dev)
+                finally:
+                    del os.environ["MSGM_SAMPLER_BF16X3"]
+                s6["dtype"] = ("3x3 convolutions: bf16 split, 3 bf16 pieces per fp32 operand, 6 v_mfma_f32_16x16x32_bf16 products per fp32 "
+                               "product, fp32 accumulate (fp32-grade: tests/test_conv_gpu.py::test_bf16_split_conv_is_fp32_grade); everything else f32")
+                s6["switch"] = "MSGM_SAMPLER_BF16X3=1 (opt-in; the default line and `sample` above stay f32)"
+                out["sample_bf16_split_experiment"] = s6
         del gen
         free_gpu()
         if solo:

@@ -408,6 +408,20 @@ typedef struct {
   int32_t rows, ncols, col_off, taps, rowsP, Ktot, kp_off, reserved;
 } msgm_pack_job_t;
 int msgm_pack_weights_batched(const msgm_pack_job_t* jobs, int32_t n_jobs, int32_t unpack, msgm_stream_t stream);
+/* OPT-IN EXPERIMENT (never the default path; MSGM_SAMPLER_BF16X3=1 on the host side): the same 3x3 stride-1 pad-1 forward
+ * convolution of the sampler (sde_scheme.py:82 -> model/unet.py:140-158; Ho, Wo multiples of 16; C0, C1, CoutP multiples of
+ * 32) with its matrix work in bf16-SPLIT arithmetic: every fp32 operand as three bf16 pieces (24 mantissa bits), six
+ * v_mfma_f32_16x16x32_bf16 products per fp32 product, fp32 accumulate — as accurate as the fp32 MFMA (tools/probe_bf16x3.hip).
+ * Same arguments and fused options as msgm_conv_forward_wino (no tap masks); Wb = [3][9][CoutP][Ktot] bf16 written by
+ * msgm_b6_split_weights from the packed fp32 image Wp ([9][CoutP][Ktot], n_elem = 9 CoutP Ktot; Wb needs 3 n_elem bf16 + 64
+ * bytes).  fuse->chanstats: [N][(Ho/16) (Wo/16) 4][2][Cout] (Cout % 4 == 0). */
+int msgm_conv_b6_supported(const msgm_conv_geom_t* geom, int32_t C0, int32_t C1, int32_t CoutP);
+int msgm_b6_split_weights(const float* Wp, void* Wb, int64_t n_elem, msgm_stream_t stream);
+int msgm_conv_forward_b6(const msgm_conv_geom_t* geom, const float* src0, int32_t C0, const float* src1, int32_t C1,
+                         const void* Wb, int32_t Cout, int32_t CoutP, int32_t Ktot, const float* bias,
+                         const float* samp_bias, int32_t n_bias, int32_t n_samp, float* out, int32_t accumulate,
+                         const msgm_conv_fuse_t* fuse, msgm_stream_t stream);
+
 /* The Winograd images of msgm_conv_forward_wino: same job table (taps = 9), Wp = [16][rowsP][Ktot]. */
 int msgm_wino_pack_weights_batched(const msgm_pack_job_t* jobs, int32_t n_jobs, msgm_stream_t stream);
 

@@ -407,6 +407,10 @@ class VorticityUNet(nn.Module, FlatParamMixin):
         self._cs_on = not os.environ.get("MSGM_NO_CHANSTATS")            # diagnostic A/B: GroupNorm statistics by a pass over the tensor
         if self._wino:
             x["set"].pack_wino()
+        # opt-in experiment (never the default): the sampler's 3x3 convolutions with 32-multiple channel counts
+        # in bf16-split arithmetic (six bf16 MFMA products per fp32 product, fp32 accumulate) instead of Winograd
+        self._b6 = self._wino and bool(os.environ.get("MSGM_SAMPLER_BF16X3"))
+        x["set"].pack_b6(self._b6)
         core = self.core
         mc = core.model_channels
         H = W = self.in_space
@@ -462,6 +466,7 @@ class VorticityUNet(nn.Module, FlatParamMixin):
             x["set2"].pack()
             if self._wino:
                 x["set2"].pack_wino()
+            x["set2"].pack_b6(self._b6)
         if nocat_t:
             x["set2t"].pack()
         for blk in x["outb"]:

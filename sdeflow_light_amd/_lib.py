@@ -98,6 +98,9 @@ SIGNATURES = {
     "msgm_conv_wino_supported": (C.c_int, [C.POINTER(ConvGeomT), _I32, _I32, _I32]),
     "msgm_wino_pack_weights_batched": (C.c_int, [_P, _I32, _P]),
     "msgm_conv_forward_wino": (C.c_int, [C.POINTER(ConvGeomT), _P, _I32, _P, _I32, _P, _I32, _I32, _I32, _P, _P, _I32, _I32, _P, _I32, C.POINTER(ConvFuseT), _P]),
+    "msgm_conv_b6_supported": (C.c_int, [C.POINTER(ConvGeomT), _I32, _I32, _I32]),
+    "msgm_b6_split_weights": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "msgm_conv_forward_b6": (C.c_int, [C.POINTER(ConvGeomT), _P, _I32, _P, _I32, _P, _I32, _I32, _I32, _P, _P, _I32, _I32, _P, _I32, C.POINTER(ConvFuseT), _P]),
     "msgm_conv_input_transform_supported": (C.c_int, [C.POINTER(ConvGeomT), _I32, _I32, _I32]),
     "msgm_groupnorm_affine": (C.c_int, [_P, _I32, _P, _I32, _P, _P, _P, _P, _I32, _I32, _I32, _F, _P, C.c_size_t, _P]),
     "msgm_conv_chanstats_slots": (C.c_int32, [C.POINTER(ConvGeomT), _I32, _I32, _I32, _I32]),

@@ -69,6 +69,16 @@ class ConvOpSet:
             self._pack_w_sig = sig
         self._pack_w.run_wino()
 
+    def pack_b6(self, use: bool = True):
+        """bf16-split images of every 3x3 stride-1 convolution of the set from its packed fp32 image (opt-in experiment,
+        sampler path; run after pack()).  use = False only clears the ops' switch (a net that sampled with it before)."""
+        for o in self.ops:
+            cap = use and getattr(o, "b6_capable", lambda: False)()
+            if cap:
+                o.pack_b6()
+            if hasattr(o, "use_b6"):
+                o.use_b6 = bool(cap)
+
     def zero_grad_images(self, bias_grads_zeroed: bool = False):
         """bias_grads_zeroed: the caller has zeroed the flat gradient bucket for this step, so each op's next
         backward() may accumulate its bias gradient without a memset of its own."""
@@ -124,10 +134,21 @@ class ConvOp:
         self._E = None
         self._bias_zeroed = False      # set per step by ConvOpSet.zero_grad_images, consumed by the next backward
         self.WpW = None                # Winograd F(2x2,3x3) image [16][CoutP][Ktot] (sampler path), built on demand
+        self.Wb = None                 # bf16-split image [3][9][CoutP][Ktot] (opt-in experiment), built on demand
+        self.use_b6 = False            # forward(wino=True) takes the bf16-split kernel instead (ConvOpSet.pack_b6)
 
     def wino_capable(self) -> bool:
         return (self.kind == "conv" and self.KH == 3 and self.KW == 3 and self.stride == 1 and self.pad == 1 and not self.embC
                 and self.CoutP % 32 == 0 and all(c % 16 == 0 for c in self.srcC))
+
+    def b6_capable(self) -> bool:
+        return (self.kind == "conv" and self.KH == 3 and self.KW == 3 and self.stride == 1 and self.pad == 1 and not self.embC
+                and self.CoutP % 32 == 0 and all(c % 32 == 0 for c in self.srcC))
+
+    def pack_b6(self):
+        if self.Wb is None:
+            self.Wb = torch.zeros(3 * self.Wp.numel() + 32, dtype=torch.bfloat16, device=self.weight.device)
+        ops.b6_split_weights(self.Wp, self.Wb)
 
     def wino_jobs(self):
         if self.WpW is None:
@@ -222,14 +243,16 @@ class ConvOp:
     def forward(self, srcs: List[torch.Tensor], N: int, Hi: int, Wi: int, n_bias: int, emb: Optional[torch.Tensor] = None,
                 samp_bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, accumulate=False,
                 emb_rows: Optional[int] = None, residual: Optional[torch.Tensor] = None,
-                in_affine: Optional[tuple] = None, in_act: int = 0, wino: bool = False, stats: bool = False):
+                in_affine: Optional[tuple] = None, in_act: int = 0, wino: bool = False, stats: bool = False, b6: bool = False):
         """emb_rows: rows that carry an embedding / per-sample bias (n_bias by default; N when the embedding itself
         has a tangent — NormalizeLogRadius conditioning).  wino: take the Winograd F(2x2,3x3) forward kernel when this
         op has its image (ConvOpSet.pack_wino) and the geometry allows it (sampler path).
         stats: if the kernel serving this convolution can, leave the per-channel sums of the output on the returned
         tensor as ``out._msgm_cs = (chanstats, slots)`` for the GroupNorm that reads it next."""
         geom, Ho, Wo = self._geom(N, Hi, Wi)
-        wino = bool(wino and self.WpW is not None and
+        b6 = bool((b6 or (wino and self.use_b6)) and self.Wb is not None and
+                  ops.conv_b6_supported(geom, self.srcC[0], self.srcC[1] if len(srcs) > 1 else 0, self.CoutP))
+        wino = bool(not b6 and wino and self.WpW is not None and
                     ops.conv_wino_supported(geom, self.srcC[0], self.srcC[1] if len(srcs) > 1 else 0, self.CoutP))
         dev = srcs[0].device
         if out is None:
@@ -249,16 +272,16 @@ class ConvOp:
         cs, S = None, 0
         out._msgm_cs = None                      # whatever was there described the values about to be overwritten
         if stats and not self.embC:
-            S = ((Ho // 16) * (Wo // 16) * 4 if wino and self.Cout % 4 == 0 else 0 if wino else
+            S = ((Ho // 16) * (Wo // 16) * 4 if (wino or b6) and self.Cout % 4 == 0 else 0 if (wino or b6) else
                  ops.conv_chanstats_slots(geom, self.srcC[0], self.srcC[1] if len(srcs) > 1 else 0, self.Cout, self.CoutP))
             if S > 0:
                 cs = torch.empty(N * S * 2 * self.Cout, device=dev)
-        ops.conv_forward(geom, srcs[0], self.srcC[0], self.WpW if wino else self.Wp, self.Cout, out,
+        ops.conv_forward(geom, srcs[0], self.srcC[0], self.Wb if b6 else (self.WpW if wino else self.Wp), self.Cout, out,
                          src1=srcs[1] if len(srcs) > 1 else None, C1=self.srcC[1] if len(srcs) > 1 else 0,
                          bias=self.bias.detach() if self.bias is not None else None, samp_bias=sb, n_bias=n_bias,
                          accumulate=accumulate, CoutP=self.CoutP, n_samp=er, residual=residual,
                          in_scale=in_affine[0] if in_affine is not None else None,
-                         in_shift=in_affine[1] if in_affine is not None else None, in_act=in_act, wino=wino, chanstats=cs)
+                         in_shift=in_affine[1] if in_affine is not None else None, in_act=in_act, wino=wino, chanstats=cs, b6=b6)
         if cs is not None:
             out._msgm_cs = (cs, S)
         if self.embC:

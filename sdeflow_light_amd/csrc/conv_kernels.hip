@@ -292,7 +292,15 @@ __global__ void __launch_bounds__(256) k_conv_gemm(ConvArgs A) {
 // the second costs the third resident workgroup (55 KB of LDS) and was 5-10 % slower.
 // Also measured and removed: requesting the next item's halo two pairs before the end of the single-buffered 1-D
 // NCO = 4 form (36 more registers, still two waves per SIMD) — 4-8 % slower (C3 106.6 -> 109 ms).
-template <int TH, int TW, int NCO, int KS, int PT = 2, bool DB = true>
+// B6 (opt-in experiment; sampler forward, wide 2-D form only): the MFMA work in bf16-SPLIT arithmetic — every fp32
+// operand as three bf16 pieces (h, m, l: 24 mantissa bits), six v_mfma_f32_16x16x32_bf16 products (lh, hl, mm, mh, hm, hh;
+// fp32 accumulate) per 32-channel chunk and tap instead of eight fp32 MFMAs: as accurate as the fp32 MFMA and 1.96x its
+// LDS-fed register-tile rate (tools/probe_bf16x3.hip).  The staging splits each halo element once (after the folded
+// GroupNorm + SiLU) into three bf16 planes of the pixel's LDS row (208 B per pixel: 3 x 64 B + 16 B pad, conflict-free
+// 16-byte fragment reads), the weight image is pre-split ([3 planes][tap][CoutP][Ktot] bf16, msgm_b6_split_weights).
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+template <int TH, int TW, int NCO, int KS, int PT = 2, bool DB = true, bool B6 = false>
 #ifndef CT_MINWG
 #define CT_MINWG 1
 #endif
@@ -306,8 +314,10 @@ __global__ void __launch_bounds__(256, (PT == 4 && !DB && NCO == 4) ? CT_WIDE_MI
   const ConvGeom g = A.g;
   constexpr int KH = TH == 1 ? 1 : KS, KW = KS, taps = KH * KW;
   constexpr int HH = TH + KH - 1, HW = TW + KW - 1, halo = HH * HW;
+  constexpr int PITCH = B6 ? 52 : CT_P;                   // floats per halo pixel in LDS
+  static_assert(!B6 || (!DB && PT == 4 && KS == 3 && TH == 16), "the bf16-split form exists for the wide 2-D kernel only");
   float* cur = ct_lds;
-  float* nxt = ct_lds + halo * CT_P;
+  float* nxt = ct_lds + halo * PITCH;
   // XCD-aware 1-D grid: workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2), so the n_cob
   // output-channel blocks that read the SAME input tiles are given ids 8 apart — same XCD, dispatched back to back —
   // and the re-reads of the input hit that L2 instead of HBM (matters for the 1x1 convolutions, which are HBM-bound).
@@ -430,10 +440,32 @@ __global__ void __launch_bounds__(256, (PT == 4 && !DB && NCO == 4) ? CT_WIDE_MI
         }
       }
     }
+    if constexpr (B6) {
+#pragma unroll
+      for (int k = K0; k < K1; ++k) {
+        const int idx = tv + 256 * k;
+        if (idx < n_items) {
+          bf16x4_t h4, m4, l4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float x = st[k - K0][r];
+            const __bf16 h = (__bf16)x;
+            const float r1 = x - (float)h;
+            const __bf16 m = (__bf16)r1;
+            h4[r] = h; m4[r] = m; l4[r] = (__bf16)(r1 - (float)m);
+          }
+          float* pp = buf + (idx >> 3) * PITCH + 2 * (idx & 7);          // 4 channels = 8 bytes in each plane
+          *reinterpret_cast<bf16x4_t*>(pp) = h4;
+          *reinterpret_cast<bf16x4_t*>(pp + 16) = m4;
+          *reinterpret_cast<bf16x4_t*>(pp + 32) = l4;
+        }
+      }
+    } else {
 #pragma unroll
     for (int k = K0; k < K1; ++k) {
       const int idx = tv + 256 * k;
       if (idx < n_items) *reinterpret_cast<f32x4*>(buf + (idx >> 3) * CT_P + 4 * (idx & 7)) = st[k - K0];
+    }
     }
   };
   auto stage_all = [&](float* buf, int t, int s, int c0) __attribute__((always_inline)) {     // global -> registers -> LDS
@@ -441,12 +473,23 @@ __global__ void __launch_bounds__(256, (PT == 4 && !DB && NCO == 4) ? CT_WIDE_MI
   };
 
   const size_t a_co_stride = (size_t)16 * A.Ktot;
-  f32x4 an[NCO];                         // the next (tap, group) pair's weight fragments
-  auto fetch_w = [&](const float* wp) {
+  f32x4 an[B6 ? 1 : NCO];                // the next (tap, group) pair's weight fragments
+  bf16x8_t an6[B6 ? NCO : 1][3];         // B6: the next tap's fragments, three planes (the whole 32-channel chunk: K = 32)
+  using WT = typename std::conditional<B6, __bf16, float>::type;       // weight pointers count ELEMENTS of the image
+  const WT* Wimg = reinterpret_cast<const WT*>(A.Wp);
+  const size_t plane_stride = (size_t)taps * A.CoutP * A.Ktot;
+  auto fetch_w = [&](const WT* wp) {
+    if constexpr (B6) {
+#pragma unroll
+      for (int c = 0; c < NCO; ++c)
+#pragma unroll
+        for (int p_ = 0; p_ < 3; ++p_) an6[c][p_] = *reinterpret_cast<const bf16x8_t*>(wp + c * a_co_stride + p_ * plane_stride);
+    } else {
 #pragma unroll
     for (int c = 0; c < NCO; ++c) an[c] = *reinterpret_cast<const f32x4*>(wp + c * a_co_stride);
+    }
   };
-  auto wptr = [&](int s_, int c_) { return A.Wp + (size_t)(co0 + il) * A.Ktot + A.koff[s_] + c_ * CT_KC + 4 * q; };
+  auto wptr = [&](int s_, int c_) { return Wimg + (size_t)(co0 + il) * A.Ktot + A.koff[s_] + c_ * CT_KC + (B6 ? 8 : 4) * q; };
   auto chunk_mask = [&](int s_, int c_) {
     unsigned tm = (1u << taps) - 1u;
     const int chunk_flat = (s_ ? nch[0] : 0) + c_;
@@ -477,8 +520,8 @@ __global__ void __launch_bounds__(256, (PT == 4 && !DB && NCO == 4) ? CT_WIDE_MI
     // ---- MFMAs of this chunk: (tap, 16-channel group) pairs, weight fragments one pair ahead
     const int C = A.C[cs];
     const int c0 = cc * CT_KC;
-    const int ngrp = (C - c0 >= CT_KC) ? 2 : ((C - c0 + 15) >> 4);
-    const float* wbase = wptr(cs, cc);
+    const int ngrp = B6 ? 1 : ((C - c0 >= CT_KC) ? 2 : ((C - c0 + 15) >> 4));       // B6: one K = 32 step per tap (host: C % 32 == 0)
+    const WT* wbase = wptr(cs, cc);
     // taps whose weight block is structurally zero for this (input chunk, output block) are skipped (Stride2PairOp)
     const unsigned tmask = chunk_mask(cs, cc);
     auto next_tap = [&](int t) { const unsigned rem = tmask & ~((2u << t) - 1u); return rem ? __ffs(rem) - 1 : taps; };
@@ -496,9 +539,17 @@ __global__ void __launch_bounds__(256, (PT == 4 && !DB && NCO == 4) ? CT_WIDE_MI
     if (npairs == 0 && more) fetch_next_item();
     int tap = tap0, grp = 0;
     for (int pr = 0; pr < npairs; ++pr) {
-      f32x4 a[NCO];
+      f32x4 a[B6 ? 1 : NCO];
+      bf16x8_t a6[B6 ? NCO : 1][3];
+      if constexpr (B6) {
+#pragma unroll
+        for (int c = 0; c < NCO; ++c)
+#pragma unroll
+          for (int p_ = 0; p_ < 3; ++p_) a6[c][p_] = an6[c][p_];
+      } else {
 #pragma unroll
       for (int c = 0; c < NCO; ++c) a[c] = an[c];
+      }
       int ntap = tap, ngr = grp + 1;
       if (ngr == ngrp) { ngr = 0; ntap = next_tap(tap); }
       if (pr + 1 < npairs) {
@@ -509,6 +560,29 @@ __global__ void __launch_bounds__(256, (PT == 4 && !DB && NCO == 4) ? CT_WIDE_MI
       }
       const int kh = tap / KW, kw = tap - kh * KW;
       const int oy = flip ? (KH - 1 - kh) : kh, ox = flip ? (KW - 1 - kw) : kw;
+      if constexpr (B6) {
+        bf16x8_t b6[PT][3];
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+          for (int p_ = 0; p_ < 3; ++p_)
+            b6[pt][p_] = *reinterpret_cast<const bf16x8_t*>(cur + ((pty_of(pt) + oy) * HW + ptx_of(pt) + ox) * PITCH + 16 * p_ + 4 * q);
+#pragma unroll
+        for (int c = 0; c < NCO; ++c)
+#pragma unroll
+          for (int pt = 0; pt < PT; ++pt) {
+            f32x4 d = acc[c][pt];                            // small terms first
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a6[c][2], b6[pt][0], d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a6[c][0], b6[pt][2], d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a6[c][1], b6[pt][1], d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a6[c][1], b6[pt][0], d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a6[c][0], b6[pt][1], d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a6[c][0], b6[pt][0], d, 0, 0, 0);
+            acc[c][pt] = d;
+          }
+        tap = ntap; grp = ngr;
+        continue;
+      }
       f32x4 b[PT];
 #ifndef CT_EXP_NOLDS    // diagnostic: -DCT_EXP_NOLDS feeds the MFMAs from registers (no activation reads)
 #pragma unroll
@@ -2166,6 +2240,82 @@ int msgm_conv_forward_wino(const msgm_conv_geom_t* geom, const float* src0, int3
   }();
   (void)once;
   hipLaunchKernelGGL((k_conv_wino<2, true>), grid, dim3(256), lds + 2 * 4096 * sizeof(float), S(stream), A, tiles_x, tiles_y, n_tiles, gy, n_tiles);
+  return msgm_check_launch();
+}
+
+// ------------------------------------------------------------------ bf16-split 3x3 forward (opt-in experiment, sampler path)
+// Wb[p][e] = piece p (h, m, l) of the packed fp32 image Wp[e] ([tap][CoutP][Ktot]): x = h + m + l, each piece a bf16
+__global__ void __launch_bounds__(256) k_b6_split(const float* __restrict__ Wp, __bf16* __restrict__ Wb, long n) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    const float x = Wp[e];
+    const __bf16 h = (__bf16)x;
+    const float r1 = x - (float)h;
+    const __bf16 m = (__bf16)r1;
+    Wb[e] = h; Wb[n + e] = m; Wb[2 * n + e] = (__bf16)(r1 - (float)m);
+  }
+}
+
+static bool conv_b6_eligible(const msgm_conv_geom_t* geom, int32_t C0, int32_t C1, int32_t CoutP) {
+  const int ups_sh = geom->ups ? 1 : 0;
+  return geom->mode == 0 && geom->KH == 3 && geom->KW == 3 && geom->strideH == 1 && geom->strideW == 1 && geom->padH == 1 &&
+         geom->padW == 1 && (geom->Hi << ups_sh) == geom->Ho && (geom->Wi << ups_sh) == geom->Wo && geom->Ho % 16 == 0 && geom->Wo % 16 == 0 &&
+         C0 % 32 == 0 && C1 % 32 == 0 && CoutP % 32 == 0;
+}
+
+int msgm_conv_b6_supported(const msgm_conv_geom_t* geom, int32_t C0, int32_t C1, int32_t CoutP) {
+  if (check_geom(geom)) return 0;
+  return conv_b6_eligible(geom, C0, C1, CoutP) ? 1 : 0;
+}
+
+int msgm_b6_split_weights(const float* Wp, void* Wb, int64_t n_elem, msgm_stream_t stream) {
+  if (!Wp || !Wb || n_elem <= 0) return MSGM_E_BADARG;
+  hipLaunchKernelGGL(k_b6_split, dim3((unsigned)grid_for(n_elem, 256, 2048)), dim3(256), 0, S(stream), Wp, static_cast<__bf16*>(Wb), (long)n_elem);
+  return msgm_check_launch();
+}
+
+int msgm_conv_forward_b6(const msgm_conv_geom_t* geom, const float* src0, int32_t C0, const float* src1, int32_t C1,
+                         const void* Wb, int32_t Cout, int32_t CoutP, int32_t Ktot, const float* bias,
+                         const float* samp_bias, int32_t n_bias, int32_t n_samp, float* out, int32_t accumulate,
+                         const msgm_conv_fuse_t* fuse, msgm_stream_t stream) {
+  int rc = check_geom(geom);
+  if (rc) return rc;
+  if (fuse && ((fuse->in_scale == nullptr) != (fuse->in_shift == nullptr) || (fuse->in_act != 0 && fuse->in_act != 1)))
+    return MSGM_E_BADARG;
+  if (!src0 || !Wb || !out || C0 <= 0 || Cout <= 0 || (src1 && C1 <= 0)) return MSGM_E_BADARG;
+  if (!conv_b6_eligible(geom, C0, src1 ? C1 : 0, CoutP)) return MSGM_E_UNSUPPORTED;
+  if (Ktot != C0 + (src1 ? C1 : 0) || CoutP < Cout) return MSGM_E_BADARG;
+  if (fuse)
+    for (int i = 0; i < 16; ++i)
+      if (fuse->tapmask_in[i] || (i < 8 && fuse->tapmask_out[i])) return MSGM_E_UNSUPPORTED;
+  ConvArgs A{};
+  A.g = to_geom(geom);
+  A.src[0] = src0; A.C[0] = C0; A.koff[0] = 0;
+  A.src[1] = src1; A.C[1] = src1 ? C1 : 0; A.koff[1] = C0;
+  A.nsrc = src1 ? 2 : 1;
+  A.Wp = static_cast<const float*>(Wb); A.Cout = Cout; A.CoutP = CoutP; A.Ktot = Ktot;
+  A.bias = bias; A.samp_bias = samp_bias; A.n_bias = n_bias; A.n_samp = n_samp; A.out = out; A.accumulate = accumulate;
+  if (fuse) { A.residual = fuse->residual; A.in_scale = fuse->in_scale; A.in_shift = fuse->in_shift; A.in_act = fuse->in_act; }
+  const int nco = (CoutP % 64 == 0) ? 4 : 2;
+  const int tiles_x = (geom->Wo + 15) / 16, tiles_y = (geom->Ho + 15) / 16;
+  if (fuse && fuse->chanstats) {                            // the direct wide kernel's layout: one slot per (16x16 tile, wave)
+    if (Cout & 3) return MSGM_E_UNSUPPORTED;
+    A.cstat = fuse->chanstats; A.cs_S = tiles_x * tiles_y * 4;
+  }
+  const int n_tiles = tiles_x * tiles_y * geom->N, gy = CoutP / (16 * nco);
+  int per = (int)(((int64_t)n_tiles * gy) / (512 * 8));     // two resident workgroups per CU (67 KB of LDS each)
+  if (per > 4) per = 4;
+  if (per < 1) per = 1;
+  const int n_tgrp = (n_tiles + per - 1) / per;
+  dim3 grid((unsigned)(8 * gy * ((n_tgrp + 7) / 8)));
+  const size_t lds = (size_t)18 * 18 * 52 * sizeof(float);
+  static const int once = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_tile<16, 16, 4, 3, 4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_tile<16, 16, 2, 3, 4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return 0;
+  }();
+  (void)once;
+  if (nco == 4) hipLaunchKernelGGL((k_conv_tile<16, 16, 4, 3, 4, false, true>), grid, dim3(256), lds, S(stream), A, 0, tiles_x, tiles_y, per, n_tiles, gy, n_tgrp);
+  else hipLaunchKernelGGL((k_conv_tile<16, 16, 2, 3, 4, false, true>), grid, dim3(256), lds, S(stream), A, 0, tiles_x, tiles_y, per, n_tiles, gy, n_tgrp);
   return msgm_check_launch();
 }
 

@@ -299,11 +299,13 @@ def conv_forward(geom: L.ConvGeomT, src0: torch.Tensor, C0: int, Wp: torch.Tenso
                  CoutP: Optional[int] = None, n_samp: Optional[int] = None, residual: Optional[torch.Tensor] = None,
                  in_scale: Optional[torch.Tensor] = None, in_shift: Optional[torch.Tensor] = None,
                  in_act: int = 0, tapmask_in=None, tapmask_out=None, wino: bool = False,
-                 chanstats: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 chanstats: Optional[torch.Tensor] = None, b6: bool = False) -> torch.Tensor:
     """out[N][Ho][Wo][Cout] (+)= implicit-GEMM convolution of channels-last inputs (K6/K11).
     chanstats [N][S][2][Cout] (S = conv_chanstats_slots(...) > 0): per-channel partial sums of the final output, for the
     GroupNorm that reads it next (groupnorm_affine_cs).
     wino: Wp is the Winograd image [16][CoutP][Ktot] and the F(2x2,3x3) forward kernel runs (sampler path).
+    b6 (opt-in experiment): Wp is the bf16-SPLIT image [3][9][CoutP][Ktot] (torch.bfloat16, b6_split_weights) and the 3x3
+    kernel does its matrix work as six bf16 MFMA products per fp32 product (fp32 accumulate).
     residual: added in the epilogue.  in_scale / in_shift [N][C0+C1] (+ in_act=1: SiLU): the conv reads
     act(a x + b) — GroupNorm(+SiLU) folded into the input staging (see conv_input_transform_supported)."""
     CoutP = pad16(Cout) if CoutP is None else CoutP
@@ -315,8 +317,8 @@ def conv_forward(geom: L.ConvGeomT, src0: torch.Tensor, C0: int, Wp: torch.Tenso
         raise MsgmError("src1 does not match the geometry")
     if out.numel() != geom.N * geom.Ho * geom.Wo * Cout:
         raise MsgmError(f"out has {out.numel()} elements, geometry says {geom.N * geom.Ho * geom.Wo * Cout}")
-    if Wp.numel() < taps * CoutP * Ktot:
-        raise MsgmError("packed weight too small")
+    if Wp.numel() < (3 if b6 else 1) * taps * CoutP * Ktot or (b6 and (wino or Wp.dtype != torch.bfloat16)):
+        raise MsgmError("packed weight too small (or not the image this kernel reads)")
     if bias is not None and bias.numel() != Cout:
         raise MsgmError("bias size")
     n_samp = n_bias if n_samp is None else n_samp
@@ -332,7 +334,7 @@ def conv_forward(geom: L.ConvGeomT, src0: torch.Tensor, C0: int, Wp: torch.Tenso
             raise MsgmError("in_scale / in_shift must both be [N][C0+C1]")
         fuse = L.ConvFuseT(ptr(residual), ptr(in_scale), ptr(in_shift), int(in_act), 0)
         if chanstats is not None:
-            S = ((geom.Ho // 16) * (geom.Wo // 16) * 4 if wino else
+            S = ((geom.Ho // 16) * (geom.Wo // 16) * 4 if (wino or b6) else
                  conv_chanstats_slots(geom, C0, C1 if src1 is not None else 0, Cout, CoutP))
             if S <= 0 or chanstats.numel() < geom.N * S * 2 * Cout or chanstats.dtype != torch.float32:
                 raise MsgmError("chanstats: this convolution has no statistics by-product, or the buffer is too small")
@@ -341,6 +343,13 @@ def conv_forward(geom: L.ConvGeomT, src0: torch.Tensor, C0: int, Wp: torch.Tenso
             fuse.tapmask_in[i] = int(m)
         for i, m in enumerate((tapmask_out or [])[:8]):
             fuse.tapmask_out[i] = int(m)
+    if b6:
+        if tapmask_in or tapmask_out:
+            raise MsgmError("the bf16-split kernel has no tap masks")
+        check(lib().msgm_conv_forward_b6(geom, ptr(f32(src0)), C0, ptr(src1), C1, ptr(Wp), Cout, CoutP, Ktot, ptr(bias),
+                                         ptr(samp_bias), int(n_bias), int(n_samp), ptr(f32(out)), int(bool(accumulate)),
+                                         fuse, stream()), "msgm_conv_forward_b6")
+        return out
     if wino:
         if tapmask_in or tapmask_out:
             raise MsgmError("the Winograd kernel has no tap masks")
@@ -391,6 +400,18 @@ def groupnorm_affine(x0, C0, gamma, beta, Bp, P, G, x1=None, C1=0, eps=1e-5):
     check(lib().msgm_groupnorm_affine(ptr(f32(x0)), C0, ptr(x1), C1, ptr(f32(gamma)), ptr(f32(beta)), ptr(scale), ptr(shift),
                                       Bp, P, G, float(eps), ptr(ws), ws.numel() * 8, stream()), "msgm_groupnorm_affine")
     return scale, shift
+
+
+def conv_b6_supported(geom: L.ConvGeomT, C0: int, C1: int, CoutP: int) -> bool:
+    return bool(lib().msgm_conv_b6_supported(geom, int(C0), int(C1), int(CoutP)))
+
+
+def b6_split_weights(Wp: torch.Tensor, Wb: torch.Tensor):
+    """Wb [3][n] (bfloat16) <- the three bf16 pieces (h, m, l) of every element of the packed fp32 image Wp [n]."""
+    n = Wp.numel()
+    if Wb.dtype != torch.bfloat16 or Wb.numel() < 3 * n:
+        raise MsgmError("b6_split_weights: Wb must be bfloat16 [3][n]")
+    check(lib().msgm_b6_split_weights(ptr(f32(Wp)), ptr(Wb), n, stream()), "msgm_b6_split_weights")
 
 
 def conv_wino_supported(geom: L.ConvGeomT, C0: int, C1: int, CoutP: int) -> bool:

@@ -550,3 +550,51 @@ def test_wgrad_1x1_pixel_streaming(N, nb, C, Cout, H, W_, atomic, monkeypatch):
         dWp2, db2 = dWp0.clone().to(DEV), db0.clone().to(DEV)
         ops.conv_wgrad(geom, gy.to(DEV), x.to(DEV), C, koff, dWp2, Cout, Cout, Ktot, dbias=db2, n_bias=nb)
         assert torch.equal(dWp2, dWp) and torch.equal(db2, db)
+
+
+# opt-in experiment: the sampler's 3x3 convolution in bf16-SPLIT arithmetic (three bf16 pieces per fp32 operand,
+# six bf16 MFMA products, fp32 accumulate) against the fp32 direct kernel and a float64 convolution: it must be fp32-grade
+@pytest.mark.parametrize("N,H,Ci,Co,two,ups,aff", [(3, 32, 64, 64, False, False, False), (2, 64, 32, 32, False, False, True),
+                                                   (2, 32, 64, 32, True, False, True), (2, 16, 128, 128, False, False, False),
+                                                   (2, 16, 64, 64, False, True, False), (1, 16, 32, 96, False, False, True),
+                                                   (2, 16, 128, 96, True, True, True)])
+def test_bf16_split_conv_is_fp32_grade(N, H, Ci, Co, two, ups, aff):
+    from sdeflow_light_amd import ops
+    from sdeflow_light_amd.convnet import ConvOp
+    torch.manual_seed(N * 1000 + H + Ci + Co)
+    dev = "cuda"
+    C0, C1 = (Ci, 32) if two else (Ci, 0)
+    w = torch.nn.Parameter(torch.randn(Co, C0 + C1, 3, 3, device=dev) * (2.0 / (9 * (C0 + C1))) ** 0.5)
+    b = torch.nn.Parameter(torch.randn(Co, device=dev) * 0.1)
+    op = ConvOp(w, b, "conv", (3, 3), 1, 1, [C0, C1] if two else [C0], ups=ups)
+    op.pack()
+    assert op.b6_capable()
+    op.pack_b6()
+    Hi = H // 2 if ups else H
+    srcs = [torch.randn(N * Hi * Hi * C0, device=dev)] + ([torch.randn(N * Hi * Hi * C1, device=dev)] if two else [])
+    sb = torch.randn(N * Co, device=dev) * 0.1
+    res = torch.randn(N * H * H * Co, device=dev)
+    in_aff = (1 + 0.3 * torch.randn(N * (C0 + C1), device=dev), 0.2 * torch.randn(N * (C0 + C1), device=dev)) if aff else None
+    kw = dict(samp_bias=sb, residual=res, in_affine=in_aff, in_act=1 if aff else 0)
+    ref, _, _ = op.forward(srcs, N, Hi, Hi, N, **kw)
+    got, _, _ = op.forward(srcs, N, Hi, Hi, N, b6=True, stats=True, **kw)
+    assert not torch.equal(got, ref)                       # it really took the other kernel
+    # float64 yardstick: the same convolution on the CPU in double precision
+    xs = [s_.view(N, Hi, Hi, c).permute(0, 3, 1, 2).double().cpu() for s_, c in zip(srcs, [C0, C1] if two else [C0])]
+    xin = torch.cat(xs, 1)
+    if aff:
+        a_, b_ = in_aff[0].view(N, -1, 1, 1).double().cpu(), in_aff[1].view(N, -1, 1, 1).double().cpu()
+        xin = torch.nn.functional.silu(xin * a_ + b_)
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    y64 = F.conv2d(xin, w.detach().double().cpu(), b.detach().double().cpu(), padding=1) + sb.view(N, Co, 1, 1).double().cpu()
+    y64 = cl2(y64) + res.view(N, H, H, Co).double().cpu()
+    e_ref, e_got = rel_l2(ref.view(N, H, H, Co).cpu().double(), y64), rel_l2(got.view(N, H, H, Co).cpu().double(), y64)
+    print(f"bf16-split 3x3 conv N={N} {H}x{H} {C0}+{C1}->{Co} ups={ups} affine={aff}: vs float64: fp32 direct {e_ref:.2e}, bf16 split {e_got:.2e}; "
+          f"split vs direct {rel_l2(got.cpu(), ref.cpu()):.2e}")
+    assert e_got <= max(2.0 * e_ref, 3e-7)                 # as accurate as the fp32 MFMA kernel (the folded SiLU dominates both)
+    cs, S = got._msgm_cs                                   # statistics by-product: one slot per (16x16 tile, wave)
+    assert S == (H // 16) ** 2 * 4
+    o = got.view(N, H * H, Co).double()
+    tot = cs.view(N, S, 2, Co).double().sum(1)
+    assert rel_l2(tot[:, 0].cpu(), o.sum(1).cpu()) <= 2e-6 and rel_l2(tot[:, 1].cpu(), (o * o).sum(1).cpu()) <= 2e-6

@@ -288,3 +288,30 @@ def test_unet2d_reference_loop_adam_steps_wellconditioned():
     flat_ref = torch.cat([ref[k].reshape(-1) for k, _ in net.named_parameters()])
     assert float((flat - flat_ref).abs().max()) <= 2 * 2 * 1e-4 + 1e-7          # nobody moved further than Adam allows
     print(f"  parameters after 2 steps: rel-L2 {rel_l2(flat, flat_ref):.2e}, max abs diff {float((flat - flat_ref).abs().max()):.2e}")
+
+
+def test_sampler_bf16_split_opt_in_matches_the_fp32_sampler(monkeypatch):
+    """Opt-in experiment: MSGM_SAMPLER_BF16X3=1 sends the sampler's 3x3 convolutions through the
+    bf16-split kernel (six bf16 MFMA products per fp32 product, fp32 accumulate).  A 16-step Euler-Maruyama run through the
+    2-D U-Net (32x32, attention at 16x16 and 8x8) must stay fp32-grade: against the default sampler (Winograd convs) with the
+    same injected noise, far inside north_star's 1e-4."""
+    from sdeflow_light_amd import sde_scheme as SS
+    from oracle.det_params import load_init_like_
+    from sdeflow_light_amd.NNUnet import VorticityUNet
+    torch.manual_seed(21)
+    net = VorticityUNet(base_channels=32, channel_mults=(1, 2, 4), num_res_blocks=2, premodule=None, in_space=32,
+                        attention_resolutions=(2, 4), flatten_order="F")
+    load_init_like_(net)
+    gen = make_gen("sgm", net)
+    B, n, steps = 4, 1024, 16
+    x0, z = torch.randn(B, n), torch.randn(steps, B, n)
+    ref = SS.euler_maruyama_sampler(gen, x0.to(DEV), num_steps=steps, keep_all_samples=True, include_t0=True, noise=z)
+    monkeypatch.setenv("MSGM_SAMPLER_BF16X3", "1")
+    got = SS.euler_maruyama_sampler(gen, x0.to(DEV), num_steps=steps, keep_all_samples=True, include_t0=True, noise=z)
+    monkeypatch.delenv("MSGM_SAMPLER_BF16X3")
+    back = SS.euler_maruyama_sampler(gen, x0.to(DEV), num_steps=steps, keep_all_samples=True, include_t0=True, noise=z)
+    e = [rel_l2(got[i], ref[i]) for i in (1, 4, 8, 16)]
+    print("bf16-split sampler vs fp32 sampler, 16-step U-Net EM, rel-L2 at steps 1,4,8,16: " + " ".join(f"{v:.1e}" for v in e))
+    assert not torch.equal(torch.as_tensor(got[16]), torch.as_tensor(ref[16]))      # the switch took the other kernels
+    assert max(e) <= 1e-5
+    assert torch.equal(torch.as_tensor(back[16]), torch.as_tensor(ref[16]))         # and switching it off restores the default bits
