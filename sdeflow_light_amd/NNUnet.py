@@ -405,8 +405,19 @@ class VorticityUNet(nn.Module, FlatParamMixin):
         # MSGM_NO_WINO=1 keeps the direct kernels (A/B).  The training path always uses the direct kernels.
         self._wino = not dual and tape is None and not os.environ.get("MSGM_NO_WINO")
         self._cs_on = not os.environ.get("MSGM_NO_CHANSTATS")            # diagnostic A/B: GroupNorm statistics by a pass over the tensor
-        if self._wino:
+        # r3: the TRAINING pass's 3x3 stride-1 convolutions — forward and dgrad, primal and tangent rows alike — take the
+        # Winograd kernel too (the dgrad as a Winograd forward of the cotangent with the flipped, transposed kernels): C4 step
+        # 122.5 -> 116.9 ms at B = 256, 19.9 -> 18.6 ms at the 32-row shard.  fp32 throughout; its transforms round about twice
+        # as much as the direct kernel (per conv 4-8e-7 against 3-4e-7 vs float64; on the ill-conditioned det_params benchmark
+        # the per-sample loss is 2.2x the fp32 oracle's own distance from float64 instead of 1.07x — tests/test_round2_gpu.py;
+        # the well-conditioned reference fixture g17 holds its absolute tolerances).  MSGM_TRAIN_WINO=0 keeps the direct kernels.
+        self._twino = tape is not None and os.environ.get("MSGM_TRAIN_WINO", "1") != "0" and not os.environ.get("MSGM_NO_WINO")
+        if self._twino:
+            x["set"].pack_wino(train=True)
+        elif self._wino:
             x["set"].pack_wino()
+        else:
+            x["set"].clear_train_wino()
         # opt-in experiment (never the default): the sampler's 3x3 convolutions with 32-multiple channel counts
         # in bf16-split arithmetic (six bf16 MFMA products per fp32 product, fp32 accumulate) instead of Winograd
         self._b6 = self._wino and bool(os.environ.get("MSGM_SAMPLER_BF16X3"))
@@ -469,6 +480,10 @@ class VorticityUNet(nn.Module, FlatParamMixin):
             x["set2"].pack_b6(self._b6)
         if nocat_t:
             x["set2t"].pack()
+            if self._twino:
+                x["set2t"].pack_wino(train=True)
+            else:
+                x["set2t"].clear_train_wino()
         for blk in x["outb"]:
             s, Cs = hs.pop()
             r0 = blk[0][1]

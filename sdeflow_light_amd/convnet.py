@@ -58,16 +58,33 @@ class ConvOpSet:
             self._pack_sig = sig
         self._pack.run(False)
 
-    def pack_wino(self):
-        """Winograd images G g G^T of every 3x3 stride-1 convolution of the set (sampler path), ONE launch."""
+    def pack_wino(self, train: bool = False):
+        """Winograd images G g G^T of every 3x3 stride-1 convolution of the set, ONE launch.  train = False (sampler path):
+        the forward images; the caller asks for the kernel per call (forward(wino=True)).  train = True (experiment switch
+        MSGM_TRAIN_WINO): also the images of the FLIPPED, transposed kernels (the dgrad as a Winograd forward), and every
+        capable op takes the Winograd kernel for its forward and its dgrad by itself."""
         wops = [o for o in self.ops if getattr(o, "wino_capable", lambda: False)()]
+        for o in self.ops:
+            if hasattr(o, "train_wino"):
+                o.train_wino = False
         if not wops:
             return
-        sig = tuple(o.weight.data_ptr() for o in wops)
+        sig = (bool(train),) + tuple(o.weight.data_ptr() for o in wops)
         if self._pack_w is None or sig != self._pack_w_sig:
-            self._pack_w = ops.PackTable([j for o in wops for j in o.wino_jobs()], self.gimg.device)
+            jobs = [j for o in wops for j in o.wino_jobs()]
+            if train:
+                jobs += [j for o in wops for j in o.wino_dgrad_jobs()]
+            self._pack_w = ops.PackTable(jobs, self.gimg.device)
             self._pack_w_sig = sig
         self._pack_w.run_wino()
+        if train:
+            for o in wops:
+                o.train_wino = True
+
+    def clear_train_wino(self):
+        for o in self.ops:
+            if hasattr(o, "train_wino"):
+                o.train_wino = False
 
     def pack_b6(self, use: bool = True):
         """bf16-split images of every 3x3 stride-1 convolution of the set from its packed fp32 image (opt-in experiment,
@@ -136,10 +153,26 @@ class ConvOp:
         self.WpW = None                # Winograd F(2x2,3x3) image [16][CoutP][Ktot] (sampler path), built on demand
         self.Wb = None                 # bf16-split image [3][9][CoutP][Ktot] (opt-in experiment), built on demand
         self.use_b6 = False            # forward(wino=True) takes the bf16-split kernel instead (ConvOpSet.pack_b6)
+        self.WdW = [None] * len(self.srcC)   # Winograd images of the flipped / transposed kernels (dgrad), per source
+        self.train_wino = False        # forward and dgrad take the Winograd kernel by themselves (ConvOpSet.pack_wino(train=True))
 
     def wino_capable(self) -> bool:
         return (self.kind == "conv" and self.KH == 3 and self.KW == 3 and self.stride == 1 and self.pad == 1 and not self.embC
                 and self.CoutP % 32 == 0 and all(c % 16 == 0 for c in self.srcC))
+
+    def wino_dgrad_jobs(self):
+        """The dgrad of a 3x3 stride-1 pad-1 convolution is the same convolution of gy with the kernels flipped and
+        transposed: g'[ci][co][t] = W[co][ci][8 - t] — a pack job that starts at tap 8 and walks the taps backwards."""
+        W = self.weight.detach()
+        jobs, off = [], 0
+        for s, C in enumerate(self.srcC):
+            if C % 32 == 0 and self.Cout % 16 == 0 and not self.ups:
+                if self.WdW[s] is None:
+                    self.WdW[s] = torch.zeros(16 * pad16(C) * pad16(self.Cout), device=W.device)
+                jobs.append((W, off * self.s_col + 8, self.WdW[s], C, self.Cout, 0, 9, self.s_col, self.s_row, -1, pad16(C),
+                             pad16(self.Cout), 0))
+            off += C
+        return jobs
 
     def b6_capable(self) -> bool:
         return (self.kind == "conv" and self.KH == 3 and self.KW == 3 and self.stride == 1 and self.pad == 1 and not self.embC
@@ -252,7 +285,7 @@ class ConvOp:
         geom, Ho, Wo = self._geom(N, Hi, Wi)
         b6 = bool((b6 or (wino and self.use_b6)) and self.Wb is not None and
                   ops.conv_b6_supported(geom, self.srcC[0], self.srcC[1] if len(srcs) > 1 else 0, self.CoutP))
-        wino = bool(not b6 and wino and self.WpW is not None and
+        wino = bool(not b6 and (wino or self.train_wino) and self.WpW is not None and
                     ops.conv_wino_supported(geom, self.srcC[0], self.srcC[1] if len(srcs) > 1 else 0, self.CoutP))
         dev = srcs[0].device
         if out is None:
@@ -345,8 +378,13 @@ class ConvOp:
             if self.ups:
                 raise MsgmError("dgrad through a folded upsample is handled by the caller (sum of 2x2 blocks)")
             d = dsrc[s] if (dsrc is not None and dsrc[s] is not None) else torch.empty(N * Hi * Wi * C, device=dev)
-            ops.conv_forward(gd, gy, self.Cout, self.Wd[s], C, d, accumulate=bool(dacc[s]) if dacc is not None else False,
-                             CoutP=pad16(C))
+            g0 = ops.conv_geom(N, Ho, Wo, Hi, Wi, self.KH, self.KW, 1, 1, 0, 0) if (self.train_wino and self.WdW[s] is not None) else None
+            if g0 is not None and ops.conv_wino_supported(g0, self.Cout, 0, pad16(C)):
+                ops.conv_forward(g0, gy, self.Cout, self.WdW[s], C, d, accumulate=bool(dacc[s]) if dacc is not None else False,
+                                 CoutP=pad16(C), wino=True)
+            else:
+                ops.conv_forward(gd, gy, self.Cout, self.Wd[s], C, d, accumulate=bool(dacc[s]) if dacc is not None else False,
+                                 CoutP=pad16(C))
             outs.append(d)
         return outs
 

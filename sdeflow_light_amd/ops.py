@@ -634,8 +634,10 @@ class PackTable:
         for i, job in enumerate(jobs):
             W, w_off, Wp, rows, ncols, col_off, taps, sr, sc, st, rowsP, Ktot, kp_off = job[:13]
             acc = int(bool(job[13])) if len(job) > 13 else 0          # unpack only: add (atomically) instead of overwrite
-            need = w_off + (rows - 1) * sr + (col_off + ncols - 1) * sc + (taps - 1) * st + 1
-            if need > W.numel() or Wp.numel() < taps * rowsP * Ktot or kp_off + ncols > Ktot or rowsP < rows:
+            span = (taps - 1) * st                              # st < 0: the taps are walked backwards from w_off
+            need = w_off + (rows - 1) * sr + (col_off + ncols - 1) * sc + max(span, 0) + 1
+            if (need > W.numel() or w_off + min(span, 0) < 0 or Wp.numel() < taps * rowsP * Ktot or kp_off + ncols > Ktot
+                    or rowsP < rows):
                 raise MsgmError("pack table: job out of range")
             arr[i] = L.PackJobT(ptr(f32(W)) + 4 * w_off, ptr(f32(Wp)), sr, sc, st, rows, ncols, col_off, taps, rowsP, Ktot,
                                 kp_off, acc)

@@ -598,3 +598,56 @@ def test_bf16_split_conv_is_fp32_grade(N, H, Ci, Co, two, ups, aff):
     o = got.view(N, H * H, Co).double()
     tot = cs.view(N, S, 2, Co).double().sum(1)
     assert rel_l2(tot[:, 0].cpu(), o.sum(1).cpu()) <= 2e-6 and rel_l2(tot[:, 1].cpu(), (o * o).sum(1).cpu()) <= 2e-6
+
+
+@pytest.mark.parametrize("N,H,C0,C1,Co,ups", [(3, 32, 64, 0, 64, False), (2, 16, 128, 64, 128, False), (2, 64, 32, 0, 32, False),
+                                              (2, 16, 64, 0, 64, True), (2, 32, 64, 32, 32, False)])
+def test_winograd_training_forward_and_dgrad(N, H, C0, C1, Co, ups):
+    """MSGM_TRAIN_WINO (ConvOpSet.pack_wino(train=True)): forward AND dgrad of a 3x3 stride-1 convolution on the Winograd
+    kernel — the dgrad as a Winograd forward of gy with the flipped, transposed kernels — against the direct kernels of the same
+    op and against PyTorch fp32; the weight gradient path is untouched."""
+    from sdeflow_light_amd.convnet import ConvOp, ConvOpSet
+    torch.manual_seed(N + H + C0 + Co)
+    dev = "cuda"
+    w = torch.nn.Parameter(torch.randn(Co, C0 + C1, 3, 3, device=dev) * (2.0 / (9 * (C0 + C1))) ** 0.5)
+    b = torch.nn.Parameter(torch.randn(Co, device=dev) * 0.1)
+    w.grad, b.grad = torch.zeros_like(w), torch.zeros_like(b)
+    op = ConvOp(w, b, "conv", (3, 3), 1, 1, [C0, C1] if C1 else [C0], ups=ups)
+    cs = ConvOpSet([op])
+    Hi = H // 2 if ups else H
+    srcs = [torch.randn(N * Hi * Hi * C0, device=dev)] + ([torch.randn(N * Hi * Hi * C1, device=dev)] if C1 else [])
+    gy = torch.randn(N * H * H * Co, device=dev)
+
+    def run(train_wino):
+        cs.pack()
+        if train_wino:
+            cs.pack_wino(train=True)
+        else:
+            cs.clear_train_wino()
+        cs.zero_grad_images()
+        b.grad.zero_()
+        out, _, _ = op.forward(srcs, N, Hi, Hi, N)
+        if ups:
+            dx = [op.backward_ups(gy, srcs[0], N, Hi, Hi, N)]
+        else:
+            dx = op.backward(gy, srcs, N, Hi, Hi, N)
+        return out.clone(), [d.clone() for d in dx]
+
+    o0, d0 = run(False)
+    o1, d1 = run(True)
+    assert op.train_wino and not torch.equal(o0, o1)
+    e = [rel_l2(o1.cpu(), o0.cpu())] + [rel_l2(a.cpu(), b_.cpu()) for a, b_ in zip(d1, d0)]
+    print(f"training Winograd N={N} {H}x{H} {C0}+{C1}->{Co} ups={ups}: forward / dgrad vs the direct kernels rel-L2 " + " ".join(f"{v:.1e}" for v in e))
+    assert max(e) <= 2e-6
+    if not ups:
+        assert not torch.equal(d0[0], d1[0])               # the dgrad took the Winograd kernel too
+    # and against PyTorch fp32 (CPU)
+    xs = [s_.view(N, Hi, Hi, c).permute(0, 3, 1, 2).cpu() for s_, c in zip(srcs, [C0, C1] if C1 else [C0])]
+    xin = torch.cat(xs, 1).requires_grad_(True)
+    xx = F.interpolate(xin, scale_factor=2, mode="nearest") if ups else xin
+    y = F.conv2d(xx, w.detach().cpu(), b.detach().cpu(), padding=1)
+    y.backward(gy.view(N, H, H, Co).permute(0, 3, 1, 2).cpu())
+    assert rel_l2(o1.view(N, H, H, Co).cpu(), cl2(y.detach())) <= 1e-5
+    dx_ref = cl2(xin.grad)
+    got = torch.cat([d.view(N, Hi, Hi, -1).cpu() for d in d1], -1)
+    assert rel_l2(got, dx_ref) <= 1e-5
