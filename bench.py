@@ -378,10 +378,13 @@ class StepProfiler:
     def _family(self, name, args):
         from sdeflow_light_amd import _lib as L
         g = args[0] if args and isinstance(args[0], L.ConvGeomT) else None
-        if name in ("msgm_conv_forward", "msgm_conv_forward_fused") and g is not None:
+        if name in ("msgm_conv_forward", "msgm_conv_forward_fused", "msgm_conv_forward_wino") and g is not None:
             cin = int(args[2]) + (int(args[4]) if args[3] else 0)
             flop = 2.0 * g.KH * g.KW * cin * int(args[6]) * g.N * g.Ho * g.Wo
             self._bytes = 4.0 * g.N * (g.Hi * g.Wi * cin + g.Ho * g.Wo * int(args[6]))      # input + output once
+            if name == "msgm_conv_forward_wino":
+                # AS-WRITTEN FLOPs of the 3x3 convolution (2 x 9 x Cin x Cout per pixel); the kernel executes 2.25x fewer
+                return "3x3 stride-1 conv forward + dgrad, Winograd F(2x2,3x3) (k_conv_wino; msgm_conv_forward_wino)", "mfma", flop
             k3 = g.KH * g.KW == 9 or (g.KH == 1 and g.KW == 3)
             same = g.strideH == 1 and g.strideW == 1
             if k3 and same and cin >= 16 and int(args[6]) >= 16:
@@ -689,8 +692,8 @@ def worker(a):
                 log("c4: per-launch profile of one eager step")
                 fams, total = leg_step_profile(dev, GLOBAL_BATCH[w])
                 top = next(f for f in fams if f.get("bound") == "mfma")          # largest measured share among the MFMA families
-                kern = "k_conv_tile" if "k_conv_tile" in top["family"] else ("k_attn_dual_bwd" if "backward" in top["family"] else
-                                                                             "k_wgrad_tile" if "wgrad" in top["family"] else None)
+                kern = ("k_conv_wino" if "k_conv_wino" in top["family"] else "k_conv_tile" if "k_conv_tile" in top["family"] else
+                        "k_attn_dual_bwd" if "backward" in top["family"] else "k_wgrad_tile" if "wgrad" in top["family"] else None)
                 traffic, src = pmc_traffic(kern) if kern else (None, None)
                 out["roofline"] = {"kernel": top["family"], "bound": "mfma", "achieved": top["achieved"], "peak": PEAK_F32_MFMA_TFLOPS,
                                    "unit": "TFLOP/s", "frac": top["frac"], "traffic": traffic,
@@ -700,6 +703,11 @@ def worker(a):
                                    "share_of_c4_step": top["share_of_step"],
                                    "measured": "this run: one eager C4 step, every launch bracketed by HIP events on the launch stream",
                                    "whole_step_frac": r["whole_step"]["frac_of_f32_mfma_peak"]}
+                if kern == "k_conv_wino":
+                    out["roofline"]["note"] = ("achieved = AS-WRITTEN FLOPs of the 3x3 convolutions (2 x 9 x Cin x Cout per output pixel) / measured "
+                                               "time; the Winograd F(2x2,3x3) kernel executes 2.25x fewer multiplications: executed rate = achieved / 2.25")
+                    out["roofline"]["executed_tflops"] = top["achieved"] / 2.25
+                    out["roofline"]["executed_frac"] = top["frac"] / 2.25
                 out["step_profile"] = {"eager_step_ms": total, "families": fams}
                 free_gpu()
                 log("HBM-bound kernels")

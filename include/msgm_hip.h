@@ -341,8 +341,9 @@ int msgm_conv_forward_fused(const msgm_conv_geom_t* geom, const float* src0, int
  * from msgm_conv_forward by rounding only).  Same arguments and fused options (second source, folded 2x upsample,
  * bias / per-sample bias, accumulate, residual, GroupNorm(+SiLU) input transform) as msgm_conv_forward_fused, except
  * that the weight image WpW is [16][CoutP][Ktot]: the transformed kernels G g G^T written by
- * msgm_wino_pack_weights_batched (same job table as msgm_pack_weights_batched, taps = 9).  No tangent-specific code and no
- * backward: the training path keeps the direct kernels.  fuse->chanstats: [N][(Ho/16) (Wo/16) 4][2][Cout] (Cout % 4 == 0). */
+ * msgm_wino_pack_weights_batched (same job table as msgm_pack_weights_batched, taps = 9).  No tangent-specific code: tangent
+ * rows are batch rows.  r3: the training step uses it too, for the forward and — with the image of the flipped, transposed
+ * kernels (a pack job with tap stride -1 starting at tap 8) — for the dgrad; weight gradients keep their own kernels.  fuse->chanstats: [N][(Ho/16) (Wo/16) 4][2][Cout] (Cout % 4 == 0). */
 int msgm_conv_wino_supported(const msgm_conv_geom_t* geom, int32_t C0, int32_t C1, int32_t CoutP);
 int msgm_conv_forward_wino(const msgm_conv_geom_t* geom, const float* src0, int32_t C0, const float* src1, int32_t C1,
                            const float* WpW, int32_t Cout, int32_t CoutP, int32_t Ktot, const float* bias,

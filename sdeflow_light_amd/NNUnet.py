@@ -402,7 +402,7 @@ class VorticityUNet(nn.Module, FlatParamMixin):
         # F(2x2,3x3) forward kernel — 2.25x fewer MFMAs, all fp32, 1.13-1.26x the direct kernel with the folded GroupNorm +
         # SiLU staging (tools/bench_wino.py), same fused options and statistics by-product; it differs from the direct form
         # by the rounding of its transforms (2-6e-7 per conv) and every sampler parity test runs through it.
-        # MSGM_NO_WINO=1 keeps the direct kernels (A/B).  The training path always uses the direct kernels.
+        # MSGM_NO_WINO=1 keeps the direct kernels (A/B).  (Training: see _twino below.)
         self._wino = not dual and tape is None and not os.environ.get("MSGM_NO_WINO")
         self._cs_on = not os.environ.get("MSGM_NO_CHANSTATS")            # diagnostic A/B: GroupNorm statistics by a pass over the tensor
         # r3: the TRAINING pass's 3x3 stride-1 convolutions — forward and dgrad, primal and tangent rows alike — take the

@@ -1002,7 +1002,8 @@ __global__ void __launch_bounds__(256) k_conv3x3_cout_small(ConvArgs A, int tile
 // half as many MFMAs).  For those convolutions the minimal-filtering form Y = A^T [ (G g G^T) o (B^T d B) ] A computes a
 // 2x2 output tile from a 4x4 input patch with 16 instead of 36 multiplications per (co, ci): 2.25x fewer MFMAs, all in
 // fp32 (the transforms are additions and halvings; the result differs from the direct form by fp32 rounding only —
-// measured in tests/test_conv_gpu.py).  No tangent, no backward: the training path keeps the direct kernels.
+// measured in tests/test_conv_gpu.py).  No tangent-specific code (tangent rows are batch rows); r3: the training step's forward
+// and dgrad (flipped, transposed kernel image) run on it as well, the weight gradients keep their own kernels.
 //   * workgroup = 16x16 output pixels = 8x8 Winograd tiles x 32 output channels, the (16+2)^2 halo of a 32-channel chunk
 //     staged in LDS exactly as k_conv_tile does (same fused GroupNorm(+SiLU) input transform, two sources, folded
 //     2x upsample);
@@ -1286,6 +1287,210 @@ __global__ void __launch_bounds__(256, 2) k_conv_wino(ConvArgs A, int tiles_x, i
       }
     // the wave's 16 Winograd tiles = 64 pixels: one statistics slot, as the direct kernel's 16x16 tiles (Cout % 4 == 0, host)
     if (A.cstat) cstat_store(A, n, (tile - n * tiles_x * tiles_y) * 4 + w, co, cs, css, il);
+  }
+}
+
+// ------------------------------------------------------------------ Winograd, 32 input channels: persistent workgroups
+// The 32 -> 32 convolutions of the 64x64 level (one 32-channel chunk: K = 32) were the slowest Winograd shape: nothing to
+// pipeline across chunks, the weight fragments one position ahead from L2 — MfmaUtil 26-31 % (profiles/r03/pmc_c4_step.json;
+// 14 launches per training step, 11 % of the sampler's step).  Their whole transformed weight image is 16 positions x 32
+// channels x 32 inputs = 64 KB: here it is copied into LDS ONCE per workgroup (LDS-DMA, fragment order as in the WL form) and the
+// workgroup — one per CU, its waves alone on their SIMDs with the whole register file — walks over tiles: the NEXT tile's halo
+// travels global -> registers under this tile's MFMAs (no weight loads in the loop, so the in-order vmcnt only ever waits
+// for halo data it needs) and is written (after the folded GroupNorm + SiLU) into the second halo buffer; one barrier per tile.
+// LDS: 64 KB weights + 2 x 46.7 KB halo = 155 KB.  Same staging options and epilogue as k_conv_wino.
+__global__ void __launch_bounds__(256, 1) k_conv_wino_p32(ConvArgs A, int tiles_x, int tiles_y, int n_tiles) {
+  extern __shared__ __attribute__((aligned(16))) float cw_lds[];
+  constexpr int NCO = 2, HW = 18, halo = 18 * 18;
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, il = lane & 15, q = lane >> 4;
+  const ConvGeom g = A.g;
+  float* wbuf = cw_lds;                                     // [2 groups][16 positions][2 co tiles][64 lanes][4]
+  float* hb0 = cw_lds + 2 * 16 * 2 * 256;
+  float* hb1 = hb0 + halo * CT_P;
+  const int tt = 16 * w + il, ty = tt >> 3, tx = tt & 7;
+  const int pbase = (2 * ty * HW + 2 * tx) * CT_P + 4 * q;
+  const size_t a_co_stride = (size_t)16 * A.Ktot, pos_stride = (size_t)A.CoutP * A.Ktot;
+  int t = blockIdx.x;
+  if (t >= n_tiles) return;
+  // ---- the weights, once: 64 pieces of 1 KB, 16 per wave (piece = (group, position, co tile))
+  {
+    const float* src = A.Wp + (size_t)il * A.Ktot + 4 * q;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int pw = 16 * w + j, grp = pw >> 5, pos = (pw >> 1) & 15, c = pw & 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)pos * pos_stride + c * a_co_stride + 16 * grp),
+                                       (__attribute__((address_space(3))) void*)(wbuf + pw * 256), 16, 0, 0);
+    }
+  }
+  constexpr int MAXST = (halo * (CT_KC / 4) + 255) / 256;
+  constexpr int n_items = halo * (CT_KC / 4);
+  const int up = g.ups ? 1 : 0;
+  const int C = A.C[0];
+  f32x4 st[MAXST];
+  f32x4 ga = {1.f, 1.f, 1.f, 1.f}, gb = {0.f, 0.f, 0.f, 0.f};
+  unsigned valid = 0;
+  auto origin = [&](int tile, int& n, int& y0, int& x0) {
+    const int tx_i = tile % tiles_x; tile /= tiles_x;
+    const int ty_i = tile % tiles_y; n = tile / tiles_y; y0 = ty_i * 16; x0 = tx_i * 16;
+  };
+  auto stage_load = [&](int tile) __attribute__((always_inline)) {
+    int n, y0, x0;
+    origin(tile, n, y0, x0);
+    const float* base = A.src[0] + (size_t)n * g.Hi * g.Wi * C;
+    const int cq = 4 * (tid & 7);
+    ga = f32x4{1.f, 1.f, 1.f, 1.f}; gb = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (A.in_scale && cq < C) {
+      const size_t o = (size_t)n * C + cq;
+      ga = *reinterpret_cast<const f32x4*>(A.in_scale + o);
+      gb = *reinterpret_cast<const f32x4*>(A.in_shift + o);
+    }
+    valid = 0;
+#pragma unroll
+    for (int k = 0; k < MAXST; ++k) {
+      const int idx = tid + 256 * k;
+      f32x4 v = {0, 0, 0, 0};
+      if (idx < n_items) {
+        const int hp = idx >> 3, hy = hp / HW, hx = hp - hy * HW;
+        const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+        const int c = 4 * (idx & 7);
+        if (iy >= 0 && iy < (g.Hi << up) && ix >= 0 && ix < (g.Wi << up) && c < C) {
+          v = *reinterpret_cast<const f32x4*>(base + ((size_t)(iy >> up) * g.Wi + (ix >> up)) * C + c);
+          valid |= 1u << k;
+        }
+      }
+      st[k] = v;
+    }
+  };
+  auto stage_store = [&](float* buf) __attribute__((always_inline)) {
+    if (A.in_scale) {
+#pragma unroll
+      for (int k = 0; k < MAXST; ++k) {
+        if ((valid >> k) & 1u) {
+          f32x4 v = st[k] * ga + gb;
+          if (A.in_act == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = v[r] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[r]));
+          }
+          st[k] = v;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < MAXST; ++k) {
+      const int idx = tid + 256 * k;
+      if (idx < n_items) *reinterpret_cast<f32x4*>(buf + (idx >> 3) * CT_P + 4 * (idx & 7)) = st[k];
+    }
+  };
+  stage_load(t);
+  stage_store(hb0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");        // weights and the first halo are in LDS
+  float* cur = hb0;
+  float* nxt = hb1;
+  const int ngrp = (C + 15) >> 4;
+  const bool vec = (A.Cout & 3) == 0;
+  for (; t < n_tiles; t += gridDim.x) {
+    const int tn = t + gridDim.x;
+    const bool more = tn < n_tiles;
+    if (more) stage_load(tn);                               // the next tile's halo: in flight under this tile's MFMAs
+    f32x4 acc[16][NCO];
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+      for (int c = 0; c < NCO; ++c) acc[p][c] = f32x4{0, 0, 0, 0};
+    for (int grp = 0; grp < ngrp; ++grp) {
+      // (computing group g + 1's transformed patch under group g's MFMAs — a second patch register set, no scheduling fences —
+      // measured SLOWER, 0.625 -> 0.666 ms at 1024 x 64 x 64: hipcc bunches the loads and additions in front of the MFMAs anyway)
+      f32x4 d[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[i][j] = *reinterpret_cast<const f32x4*>(cur + pbase + (i * HW + j) * CT_P + 16 * grp);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 r0 = d[0][j] - d[2][j], r1 = d[1][j] + d[2][j], r2 = d[2][j] - d[1][j], r3 = d[1][j] - d[3][j];
+        d[0][j] = r0; d[1][j] = r1; d[2][j] = r2; d[3][j] = r3;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f32x4 c0_ = d[i][0] - d[i][2], c1_ = d[i][1] + d[i][2], c2_ = d[i][2] - d[i][1], c3_ = d[i][1] - d[i][3];
+        d[i][0] = c0_; d[i][1] = c1_; d[i][2] = c2_; d[i][3] = c3_;
+      }
+      const float* wb = wbuf + grp * (16 * 2 * 256) + lane * 4;
+      f32x4 a0 = *reinterpret_cast<const f32x4*>(wb), a1 = *reinterpret_cast<const f32x4*>(wb + 256);
+#pragma unroll
+      for (int pos = 0; pos < 16; ++pos) {
+        const f32x4 x0_ = a0, x1_ = a1;
+        if (pos < 15) {
+          a0 = *reinterpret_cast<const f32x4*>(wb + (2 * pos + 2) * 256);
+          a1 = *reinterpret_cast<const f32x4*>(wb + (2 * pos + 3) * 256);
+        }
+        const f32x4 b = d[pos >> 2][pos & 3];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          acc[pos][0] = mfma16c(x0_[r], b[r], acc[pos][0]);
+          acc[pos][1] = mfma16c(x1_[r], b[r], acc[pos][1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // ---- output transform and epilogue (as k_conv_wino)
+    int n, y0, x0;
+    origin(t, n, y0, x0);
+    const bool primal = n < A.n_bias;
+#pragma unroll
+    for (int c = 0; c < NCO; ++c) {
+      const int co = 16 * c + 4 * q;
+      if (co >= A.Cout) continue;
+      const bool full = vec && (co + 3 < A.Cout);
+      f32x4 add = {0.f, 0.f, 0.f, 0.f};
+      if (primal && A.bias) {
+        if (full) add = *reinterpret_cast<const f32x4*>(A.bias + co);
+        else
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (co + r < A.Cout) add[r] = A.bias[co + r];
+      }
+      if (A.samp_bias && n < A.n_samp) {
+        const float* sbp = A.samp_bias + (size_t)n * A.Cout + co;
+        if (full) add += *reinterpret_cast<const f32x4*>(sbp);
+        else
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (co + r < A.Cout) add[r] += sbp[r];
+      }
+      f32x4 t0[4], t1[4];
+#pragma unroll
+      for (int nu = 0; nu < 4; ++nu) {
+        t0[nu] = acc[nu][c] + acc[4 + nu][c] + acc[8 + nu][c];
+        t1[nu] = acc[4 + nu][c] - acc[8 + nu][c] - acc[12 + nu][c];
+      }
+      f32x4 Y[2][2];
+      Y[0][0] = t0[0] + t0[1] + t0[2]; Y[0][1] = t0[1] - t0[2] - t0[3];
+      Y[1][0] = t1[0] + t1[1] + t1[2]; Y[1][1] = t1[1] - t1[2] - t1[3];
+      f32x4 cs = {0.f, 0.f, 0.f, 0.f}, css = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          const int oy = y0 + 2 * ty + dy, ox = x0 + 2 * tx + dx;
+          if (oy >= g.Ho || ox >= g.Wo) continue;
+          const size_t m = ((size_t)n * g.Ho + oy) * g.Wo + ox;
+          f32x4 v = Y[dy][dx] + add;
+          float* op = A.out + m * A.Cout + co;
+          if (full) {
+            if (A.accumulate) v += *reinterpret_cast<const f32x4*>(op);
+            if (A.residual) v += *reinterpret_cast<const f32x4*>(A.residual + (op - A.out));
+            *reinterpret_cast<f32x4*>(op) = v;
+            cs += v; css += v * v;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (co + r < A.Cout) op[r] = (A.accumulate ? op[r] + v[r] : v[r]) + (A.residual ? A.residual[(op - A.out) + r] : 0.f);
+          }
+        }
+      if (A.cstat) cstat_store(A, n, (t - n * tiles_x * tiles_y) * 4 + w, co, cs, css, il);
+    }
+    if (more) stage_store(nxt);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");               // the other buffer is complete; this one is free
+    float* sw = cur; cur = nxt; nxt = sw;
   }
 }
 
@@ -2230,6 +2435,20 @@ int msgm_conv_forward_wino(const msgm_conv_geom_t* geom, const float* src0, int3
   // one 32-channel chunk (Ktot = 32: the 64x64 32 -> 32 layers) has nothing to pipeline and pays the extra barriers: 96 vs
   // 104 TFLOP/s as written; from 64 input channels on the LDS weights win, +2 .. +18 % (AFF=1 tools/bench_wino.py)
   static const bool reg_weights = getenv("MSGM_WINO_REGW") != nullptr;    // A/B: the register weight ring everywhere
+  static const bool no_p32 = getenv("MSGM_WINO_NO_P32") != nullptr;       // A/B: the 32-channel layers without the persistent form
+  static const int p32_min = getenv("MSGM_WINO_P32_MIN") ? atoi(getenv("MSGM_WINO_P32_MIN")) : 1024;      // >= 4 tiles per workgroup (B = 32: 18.6 -> 18.5 ms)
+  if (!reg_weights && !no_p32 && !src1 && Ktot == 32 && CoutP == 32 && n_tiles >= p32_min) {
+    // one persistent workgroup per CU (>= 8 tiles each): weights resident in LDS, halo double-buffered
+    static const int once32 = [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wino_p32), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      return 0;
+    }();
+    (void)once32;
+    static const int n_cu = [] { int d = 0, n = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n > 0 ? n : 256; }();
+    const size_t lds32 = ((size_t)2 * 16 * 2 * 256 + 2 * 18 * 18 * CT_P) * sizeof(float);
+    hipLaunchKernelGGL(k_conv_wino_p32, dim3((unsigned)n_cu), dim3(256), lds32, S(stream), A, tiles_x, tiles_y, n_tiles);
+    return msgm_check_launch();
+  }
   if (reg_weights || Ktot < 64) {
     hipLaunchKernelGGL((k_conv_wino<2, false>), grid, dim3(256), lds, S(stream), A, tiles_x, tiles_y, n_tiles, gy, n_tiles);
     return msgm_check_launch();

@@ -297,7 +297,10 @@ def test_stride2_pair_op_fwd_bwd(kind, N, Cin, Cout, L):
                                                    (2, 16, 64, 64, False, True, False), (1, 16, 32, 96, False, False, True),
                                                    # the LDS-weight form (>= 64 input channels) with ragged 16-channel tails
                                                    (2, 16, 48, 64, True, False, True), (1, 32, 80, 32, False, False, False),
-                                                   (2, 16, 144, 96, True, True, True)])
+                                                   (2, 16, 144, 96, True, True, True),
+                                                   # >= 2048 tiles of a 32 -> 32 layer: the persistent form (weights resident in LDS), with a
+                                                   # tile count that does not divide over the workgroups, and with the folded upsample
+                                                   (130, 64, 32, 32, False, False, True), (520, 32, 32, 32, False, True, False)])
 def test_winograd_forward_equals_direct_conv(N, H, Ci, Co, two, ups, aff):
     """Winograd F(2x2,3x3) forward (sampler path) vs the direct halo-tile kernel on the same inputs and fused options:
     second source, folded 2x upsample, GroupNorm(+SiLU) input transform, bias, per-sample bias, residual.  Both are fp32;
@@ -601,7 +604,8 @@ def test_bf16_split_conv_is_fp32_grade(N, H, Ci, Co, two, ups, aff):
 
 
 @pytest.mark.parametrize("N,H,C0,C1,Co,ups", [(3, 32, 64, 0, 64, False), (2, 16, 128, 64, 128, False), (2, 64, 32, 0, 32, False),
-                                              (2, 16, 64, 0, 64, True), (2, 32, 64, 32, 32, False)])
+                                              (2, 16, 64, 0, 64, True), (2, 32, 64, 32, 32, False),
+                                              (128, 64, 32, 0, 32, False)])        # the persistent 32-channel form, forward and dgrad
 def test_winograd_training_forward_and_dgrad(N, H, C0, C1, Co, ups):
     """MSGM_TRAIN_WINO (ConvOpSet.pack_wino(train=True)): forward AND dgrad of a 3x3 stride-1 convolution on the Winograd
     kernel — the dgrad as a Winograd forward of gy with the flipped, transposed kernels — against the direct kernels of the same
