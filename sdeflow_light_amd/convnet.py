@@ -166,7 +166,7 @@ class ConvOp:
         W = self.weight.detach()
         jobs, off = [], 0
         for s, C in enumerate(self.srcC):
-            if C % 32 == 0 and self.Cout % 16 == 0 and not self.ups:
+            if C % 32 == 0 and self.Cout % 16 == 0:
                 if self.WdW[s] is None:
                     self.WdW[s] = torch.zeros(16 * pad16(C) * pad16(self.Cout), device=W.device)
                 jobs.append((W, off * self.s_col + 8, self.WdW[s], C, self.Cout, 0, 9, self.s_col, self.s_row, -1, pad16(C),
@@ -404,7 +404,11 @@ class ConvOp:
                        dbias=self.bias.grad.view(-1) if self.bias is not None else None, n_bias=n_bias)
         gd = ops.conv_geom(N, Ho, Wo, 2 * Hi, 2 * Wi, self.KH, self.KW, self.stride, self.pad, 1 - self.mode, 0)
         gup = torch.empty(N * 4 * Hi * Wi * C, device=dev)
-        ops.conv_forward(gd, gy, self.Cout, self.Wd[0], C, gup, CoutP=pad16(C))
+        g0 = ops.conv_geom(N, Ho, Wo, 2 * Hi, 2 * Wi, self.KH, self.KW, 1, 1, 0, 0) if (self.train_wino and self.WdW[0] is not None) else None
+        if g0 is not None and ops.conv_wino_supported(g0, self.Cout, 0, pad16(C)):
+            ops.conv_forward(g0, gy, self.Cout, self.WdW[0], C, gup, CoutP=pad16(C), wino=True)     # the dgrad on the 2x grid: a plain same-size conv
+        else:
+            ops.conv_forward(gd, gy, self.Cout, self.Wd[0], C, gup, CoutP=pad16(C))
         return ops.sum2x2(gup, N, Hi, Wi, C)
 
 

@@ -643,8 +643,7 @@ def test_winograd_training_forward_and_dgrad(N, H, C0, C1, Co, ups):
     e = [rel_l2(o1.cpu(), o0.cpu())] + [rel_l2(a.cpu(), b_.cpu()) for a, b_ in zip(d1, d0)]
     print(f"training Winograd N={N} {H}x{H} {C0}+{C1}->{Co} ups={ups}: forward / dgrad vs the direct kernels rel-L2 " + " ".join(f"{v:.1e}" for v in e))
     assert max(e) <= 2e-6
-    if not ups:
-        assert not torch.equal(d0[0], d1[0])               # the dgrad took the Winograd kernel too
+    assert not torch.equal(d0[0], d1[0])                   # the dgrad took the Winograd kernel too (folded upsample: on the 2x grid)
     # and against PyTorch fp32 (CPU)
     xs = [s_.view(N, Hi, Hi, c).permute(0, 3, 1, 2).cpu() for s_, c in zip(srcs, [C0, C1] if C1 else [C0])]
     xin = torch.cat(xs, 1).requires_grad_(True)
