@@ -100,7 +100,7 @@ def test_c4_shape_ssm_loss_and_all_gradients_vs_oracle(convs, monkeypatch):
     the default (3x3 forward + dgrad on the Winograd kernel, r3) and the direct kernels (MSGM_TRAIN_WINO=0).  On this
     ill-conditioned det_params fill (it amplifies every rounding ~1e3x) the direct kernels land at 1.07x the fp32 oracle's
     own distance from float64 (bound 2x), the Winograd transforms — which round about twice as much per convolution, still
-    in fp32 — at 2.2x (bound 3x); the well-conditioned reference fixture (g17, test_round3_gpu.py) holds its absolute
+    in fp32 — at 2.2x (bound 2.5x; worst single tensor 1.8x the oracle's worst, bound 4x as before); the well-conditioned reference fixture (g17, test_round3_gpu.py) holds its absolute
     tolerances on the default path."""
     if convs == "direct":
         monkeypatch.setenv("MSGM_TRAIN_WINO", "0")
@@ -115,7 +115,7 @@ def test_c4_shape_ssm_loss_and_all_gradients_vs_oracle(convs, monkeypatch):
     p = det_state_dict(unet2d_shapes(cfg))
     score = lambda prm, yy, tt: N.image_to_flat(N.unet2d_core_forward(prm, N.flat_to_image(yy, 64, 64, "F", 3), tt.reshape(-1), cfg), "F")
     ssm_parity_vs_fp64(gen, score, p, x, u, eps, uv, f"C4 shape (2-D U-Net 64x64x3, B=2), {convs} convolutions",
-                       grad_key=lambda k: k[len("core."):], **({} if convs == "direct" else dict(slack=3.0, slack_worst=6.0)))
+                       grad_key=lambda k: k[len("core."):], **({} if convs == "direct" else dict(slack=2.5)))
 
 
 def test_c3_shape_ssm_loss_and_all_gradients_vs_oracle():
