@@ -996,6 +996,37 @@ __global__ void __launch_bounds__(256) k_conv3x3_cout_small(ConvArgs A, int tile
   }
 }
 
+// The 4x4 input patch of a lane's Winograd tile (4 channels): tile (ty, tx) reads halo pixels (2ty + i, 2tx + j).  Columns 2, 3 of
+// tile tx ARE columns 0, 1 of tile tx + 1, which is the next lane of the same 16-lane row (lanes il = 0..7 hold tiles tx = 0..7 of
+// one tile row, il = 8..15 the next row): instead of reading them from LDS again the lane takes them from its neighbour's
+// registers (DPP row_shl:1); only the last tile of a row (tx = 7) still reads its own.  16 -> 9 ds_read_b128 worth of LDS traffic
+// per lane and group (the Winograd kernels with their weights in LDS are LDS-bandwidth-bound); the same values, bit for bit.
+// Measured (AFF=1 tools/bench_wino.py 1024): +2-3 % on the LDS-weight shapes (135 -> 138, 151 -> 155, 157 -> 160 TFLOP/s as written).
+__device__ __forceinline__ float dpp_from_next_lane(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101 /* row_shl:1 */, 0xf, 0xf, true));
+}
+template <int HW_>
+__device__ __forceinline__ void wino_patch_load(f32x4 (&d)[4][4], const float* __restrict__ p00, bool last_in_row) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    d[i][0] = *reinterpret_cast<const f32x4*>(p00 + (i * HW_ + 0) * CT_P);
+    d[i][1] = *reinterpret_cast<const f32x4*>(p00 + (i * HW_ + 1) * CT_P);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) d[i][2 + j][r] = dpp_from_next_lane(d[i][j][r]);
+  if (last_in_row) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      d[i][2] = *reinterpret_cast<const f32x4*>(p00 + (i * HW_ + 2) * CT_P);
+      d[i][3] = *reinterpret_cast<const f32x4*>(p00 + (i * HW_ + 3) * CT_P);
+    }
+  }
+}
+
 // ------------------------------------------------------------------ Winograd F(2x2, 3x3) forward (sampler path)
 // The reverse-SDE sampler spends 55 % of a step in stride-1 3x3 convolutions (C5, rocprofv3), a third of that in the
 // 32-output-channel layers where the direct halo-tile kernel reaches only ~65 TFLOP/s (the halo staging is amortised over
@@ -1137,10 +1168,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_wino(ConvArgs A, int tiles_x, i
         else if (more) wfill(ns, nc, ng, 0, (step + 1) & 1);
         if (half == 0) {
           // ---- the lane's 4x4 patch (4 channels) and its transform V = B^T d B, in place
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) d[i][j] = *reinterpret_cast<const f32x4*>(cur + pbase + (i * HW + j) * CT_P + 16 * grp);
+          wino_patch_load<HW>(d, cur + pbase + 16 * grp, tx == 7);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const f32x4 r0 = d[0][j] - d[2][j], r1 = d[1][j] + d[2][j], r2 = d[2][j] - d[1][j], r3 = d[1][j] - d[3][j];
@@ -1193,10 +1221,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_wino(ConvArgs A, int tiles_x, i
       for (int grp = 0; grp < ngrp; ++grp) {
         // ---- the lane's 4x4 patch (4 channels) and its transform V = B^T d B, in place
         f32x4 d[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) d[i][j] = *reinterpret_cast<const f32x4*>(cur + pbase + (i * HW + j) * CT_P + 16 * grp);
+        wino_patch_load<HW>(d, cur + pbase + 16 * grp, tx == 7);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const f32x4 r0 = d[0][j] - d[2][j], r1 = d[1][j] + d[2][j], r2 = d[2][j] - d[1][j], r3 = d[1][j] - d[3][j];
@@ -1401,6 +1426,7 @@ __global__ void __launch_bounds__(256, 1) k_conv_wino_p32(ConvArgs A, int tiles_
       // (computing group g + 1's transformed patch under group g's MFMAs — a second patch register set, no scheduling fences —
       // measured SLOWER, 0.625 -> 0.666 ms at 1024 x 64 x 64: hipcc bunches the loads and additions in front of the MFMAs anyway)
       f32x4 d[4][4];
+      // (plain reads here: this form is not LDS-bound, and the neighbour exchange of wino_patch_load measured 3 % slower)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
