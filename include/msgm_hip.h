@@ -487,9 +487,12 @@ size_t msgm_groupnorm_param_slots_bytes(int32_t Bp, int32_t P, int32_t C);
 int msgm_groupnorm_dual_backward_slots(const float* x0, int32_t C0, const float* x1, int32_t C1, const float* gamma,
                                        const float* beta, const float* stats, const float* gout, float* gx0, float* gx1,
                                        float* dgamma, float* dbeta, int32_t Bp, int32_t P, int32_t G, int32_t silu, float eps,
-                                       const float* residual, void* workspace, size_t workspace_bytes, float* pslots,
-                                       size_t pslots_bytes, msgm_reduce_job_t* jobs_out, int32_t* n_jobs_out,
+                                       const float* residual, const float* residual2, void* workspace, size_t workspace_bytes,
+                                       float* pslots, size_t pslots_bytes, msgm_reduce_job_t* jobs_out, int32_t* n_jobs_out,
                                        msgm_stream_t stream);
+/* residual2 (may be NULL; one source only): a SECOND tensor added to the input cotangent in the same apply pass — the cotangent
+ * that reached this tensor through the U-Net's skip stack (model/unet.py:514: the encoder activations feed the decoder as
+ * well), which was a separate `dh += skip` pass over the tensor for each of the nine encoder blocks. */
 
 /* GroupNorm statistics only, returned as the per-(sample, channel) affine map y = scale x + shift
  * (scale = gamma/sigma, shift = beta - mean scale; [Bp][C0+C1] each) for a consumer that applies it while reading

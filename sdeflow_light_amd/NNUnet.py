@@ -579,9 +579,9 @@ class VorticityUNet(nn.Module, FlatParamMixin):
     def _groupnorms(self):
         return [m for m in self.modules() if isinstance(m, nn.GroupNorm)]
 
-    def _gn_bwd(self, gnm, xin, stats, g, Bp, P, C, silu, residual=None):
+    def _gn_bwd(self, gnm, xin, stats, g, Bp, P, C, silu, residual=None, residual2=None):
         return ops.groupnorm_dual_backward(xin, gnm.weight.detach(), gnm.bias.detach(), stats, g, gnm.weight.grad, gnm.bias.grad,
-                                           Bp, P, C, gnm.num_groups, silu, residual=residual)
+                                           Bp, P, C, gnm.num_groups, silu, residual=residual, residual2=residual2)
 
     def _backward(self, tape, g, N, Bp):
         x = self._x
@@ -607,8 +607,15 @@ class VorticityUNet(nn.Module, FlatParamMixin):
                 dh2 = self._gn_bwd(rb.m.out_layers[0], h2, st2, dh3, Bp, P, rb.co, True)
                 (dh1,) = rb.conv1.backward(dh2, [h1], N, H, W, Bp, dsamp_bias=deo_all[rb.bank_i], emb_rows=er,
                                            bias_grad_elsewhere=True)
-                # identity skip: the `h + x` cotangent is added in the GroupNorm apply pass (no separate axpy)
-                dx = self._gn_bwd(rb.m.in_layers[0], xin, st1, dh1, Bp, P, rb.ci, True, residual=None if rb.skip is not None else dh)
+                # identity skip: the `h + x` cotangent is added in the GroupNorm apply pass (no separate axpy); so is the cotangent
+                # that reaches this block's INPUT through the skip stack, when the tensor was saved for the decoder (the
+                # "save_skip" record in front of this block: it was a separate `dh += skip` pass, nine per step)
+                sk = None
+                if i - 1 >= 1 and tape[i - 1][0] == "save_skip" and pend and not os.environ.get("MSGM_NO_SKIP_FOLD"):
+                    sk = pend.pop()
+                    i -= 1                                          # that record is consumed here
+                dx = self._gn_bwd(rb.m.in_layers[0], xin, st1, dh1, Bp, P, rb.ci, True, residual=None if rb.skip is not None else dh,
+                                  residual2=sk)
                 if rb.skip is not None:
                     rb.skip.backward(dh, [xin], N, H, W, Bp, dsrc=[dx], dacc=[True])
                 dh = dx
@@ -634,7 +641,12 @@ class VorticityUNet(nn.Module, FlatParamMixin):
                 dh = None
             elif kind == "down":
                 _, o, hin, H, W = r
-                (dh,) = o.backward(dh, [hin], N, H, W, Bp)
+                if i - 1 >= 1 and tape[i - 1][0] == "save_skip" and pend and not os.environ.get("MSGM_NO_SKIP_FOLD"):
+                    sk = pend.pop()                                 # the dgrad accumulates onto the skip-stack cotangent
+                    i -= 1
+                    (dh,) = o.backward(dh, [hin], N, H, W, Bp, dsrc=[sk], dacc=[True])
+                else:
+                    (dh,) = o.backward(dh, [hin], N, H, W, Bp)
             elif kind == "up":
                 _, o, hin, H, W = r
                 dh = o.backward_ups(dh, hin, N, H, W, Bp)

@@ -131,7 +131,7 @@ SIGNATURES = {
                                                 _P, _SZ, _P]),
     "msgm_groupnorm_param_slots_bytes": (_SZ, [_I32, _I32, _I32]),
     "msgm_groupnorm_dual_backward_slots": (C.c_int, [_P, _I32, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F,
-                                                     _P, _P, _SZ, _P, _SZ, C.POINTER(ReduceJobT), C.POINTER(C.c_int32), _P]),
+                                                     _P, _P, _P, _SZ, _P, _SZ, C.POINTER(ReduceJobT), C.POINTER(C.c_int32), _P]),
     "msgm_emb_bank_forward": (C.c_int, [_P, _I32, _I32, _P, _I32, _I32, _I32, _P]),
     "msgm_emb_bank_backward": (C.c_int, [_P, _I32, _I32, _P, _P, _I32, _I32, _I32, _P]),
     "msgm_bmm": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _F, _I32, _P]),

@@ -54,6 +54,7 @@ struct GnArgs {
   double* accf; // backward: the five moments summed over the slots, [Bp][G][8]
   float* pslots;// backward: dgamma | dbeta partials, [2][Bp * GN_SLOTS][C]
   const float* resid;   // backward apply: added to gx (skip-branch cotangent), may alias gx
+  const float* resid2;  // a second addend (the cotangent that reached this tensor through the U-Net's skip stack)
 };
 
 // Reduction tail of the reduce kernels: every thread holds V double partials per moment (channels V*cv .. V*cv+V-1 of pixel
@@ -430,6 +431,7 @@ __global__ void __launch_bounds__(256) k_gn_bwd_apply(GnArgs A) {
   // destination of the input cotangent: the source's own tensor when the input is a concatenation
   float* gbase = A.x1 ? ((V * cv >= A.C0) ? A.gx1 + (V * cv - A.C0) : A.gx + V * cv) : A.gx + V * cv;
   const float* rbase = A.resid ? A.resid + V * cv : nullptr;            // single-source only (host checks)
+  const float* rbase2 = A.resid2 ? A.resid2 + V * cv : nullptr;
   for (int p = p0 + pl; p < p1; p += PL) {
     const long e = ((long)b * P + p) * C + V * cv;
     const long ex = ((long)b * P + p) * sx.pitch;
@@ -464,11 +466,12 @@ __global__ void __launch_bounds__(256) k_gn_bwd_apply(GnArgs A) {
 #pragma unroll
       for (int k = 0; k < V; ++k) { o[k] = xb[k]; od[k] = xdb[k]; }
       if (rbase) { o += *reinterpret_cast<const f32x4*>(rbase + ex); od += *reinterpret_cast<const f32x4*>(rbase + ex + sx.half); }
+      if (rbase2) { o += *reinterpret_cast<const f32x4*>(rbase2 + ex); od += *reinterpret_cast<const f32x4*>(rbase2 + ex + sx.half); }
       *reinterpret_cast<f32x4*>(gbase + ex) = o;
       *reinterpret_cast<f32x4*>(gbase + ex + sx.half) = od;
     } else {
-      gbase[ex] = xb[0] + (rbase ? rbase[ex] : 0.f);
-      gbase[ex + sx.half] = xdb[0] + (rbase ? rbase[ex + sx.half] : 0.f);
+      gbase[ex] = xb[0] + (rbase ? rbase[ex] : 0.f) + (rbase2 ? rbase2[ex] : 0.f);
+      gbase[ex + sx.half] = xdb[0] + (rbase ? rbase[ex + sx.half] : 0.f) + (rbase2 ? rbase2[ex + sx.half] : 0.f);
     }
   }
 }
@@ -1245,11 +1248,11 @@ static int gn_backward_impl(const float* x, int32_t C0, const float* x1, int32_t
                             const float* stats, const float* gout, float* gx, float* gx1, float* dgamma, float* dbeta, int32_t Bp,
                             int32_t P, int32_t G, int32_t silu, float eps, const float* residual, void* workspace,
                             size_t workspace_bytes, msgm_stream_t stream, float* pslots_ext = nullptr, size_t pslots_bytes = 0,
-                            msgm_reduce_job_t* jobs_out = nullptr, int32_t* n_jobs_out = nullptr) {
+                            msgm_reduce_job_t* jobs_out = nullptr, int32_t* n_jobs_out = nullptr, const float* residual2 = nullptr) {
   if (!x || !gamma || !beta || !stats || !gout || !gx || !dgamma || !dbeta || !workspace || Bp <= 0 || P <= 0 || C <= 0 || G <= 0)
     return MSGM_E_BADARG;
   if (C % G || C > 256 || G > 64) return MSGM_E_UNSUPPORTED;
-  if (x1 && (!gx1 || residual || C0 % 4 || (C - C0) % 4 || C0 <= 0 || C0 >= C)) return MSGM_E_UNSUPPORTED;
+  if (x1 && (!gx1 || residual || residual2 || C0 % 4 || (C - C0) % 4 || C0 <= 0 || C0 >= C)) return MSGM_E_UNSUPPORTED;
   if (workspace_bytes < msgm_groupnorm_workspace(Bp, G)) return MSGM_E_WORKSPACE;
   GnArgs A{x, gamma, beta, nullptr, reinterpret_cast<double*>(workspace), const_cast<float*>(stats), P, C, G, Bp, 1, silu, 0,
            eps, gout, gx, dgamma, dbeta, x1, C0, gx1};
@@ -1265,6 +1268,7 @@ static int gn_backward_impl(const float* x, int32_t C0, const float* x1, int32_t
     A.pslots = pslots_ext;
   }
   A.resid = residual;
+  A.resid2 = residual2;
   if (C % 4 == 0) hipLaunchKernelGGL(k_gn_bwd_reduce<true>, dim3(Bp, nch), dim3(256), 0, S(stream), A);
   else hipLaunchKernelGGL(k_gn_bwd_reduce<false>, dim3(Bp, nch), dim3(256), 0, S(stream), A);
   if (pslots_ext) {
@@ -1293,13 +1297,13 @@ size_t msgm_groupnorm_param_slots_bytes(int32_t Bp, int32_t P, int32_t C) {
 int msgm_groupnorm_dual_backward_slots(const float* x0, int32_t C0, const float* x1, int32_t C1, const float* gamma,
                                        const float* beta, const float* stats, const float* gout, float* gx0, float* gx1,
                                        float* dgamma, float* dbeta, int32_t Bp, int32_t P, int32_t G, int32_t silu, float eps,
-                                       const float* residual, void* workspace, size_t workspace_bytes, float* pslots,
-                                       size_t pslots_bytes, msgm_reduce_job_t* jobs_out, int32_t* n_jobs_out,
+                                       const float* residual, const float* residual2, void* workspace, size_t workspace_bytes,
+                                       float* pslots, size_t pslots_bytes, msgm_reduce_job_t* jobs_out, int32_t* n_jobs_out,
                                        msgm_stream_t stream) {
   if (!pslots || !jobs_out || !n_jobs_out || (x1 ? C1 <= 0 : C1 != 0)) return MSGM_E_BADARG;
   *n_jobs_out = 0;
   return gn_backward_impl(x0, C0, x1, C0 + C1, gamma, beta, stats, gout, gx0, gx1, dgamma, dbeta, Bp, P, G, silu, eps, residual,
-                          workspace, workspace_bytes, stream, pslots, pslots_bytes, jobs_out, n_jobs_out);
+                          workspace, workspace_bytes, stream, pslots, pslots_bytes, jobs_out, n_jobs_out, residual2);
 }
 
 int msgm_groupnorm_dual_backward(const float* x, const float* gamma, const float* beta, const float* stats, const float* gout,

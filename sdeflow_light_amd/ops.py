@@ -736,7 +736,8 @@ def groupnorm_dual_forward(x, gamma, beta, Bp, P, C, G, dual, silu, stats=None, 
     return out
 
 
-def _gn_backward_slots(x0, C0, x1, C1, gamma, beta, stats, gout, gx0, gx1, dgamma, dbeta, Bp, P, G, silu, eps, residual, d):
+def _gn_backward_slots(x0, C0, x1, C1, gamma, beta, stats, gout, gx0, gx1, dgamma, dbeta, Bp, P, G, silu, eps, residual, d,
+                       residual2=None):
     """GroupNorm backward inside a DeferredReduces pass: the dgamma / dbeta partials go to the pass's arena and their
     slot-ordered sums join the pass's ONE batched reduction launch."""
     import ctypes as C_
@@ -747,28 +748,34 @@ def _gn_backward_slots(x0, C0, x1, C1, gamma, beta, stats, gout, gx0, gx1, dgamm
     jobs, nj = (L.ReduceJobT * 2)(), C_.c_int32(0)
     check(lib().msgm_groupnorm_dual_backward_slots(ptr(f32(x0)), C0, ptr(x1), C1, ptr(f32(gamma)), ptr(f32(beta)), ptr(f32(stats)),
                                                    ptr(f32(gout)), ptr(gx0), ptr(gx1), ptr(dgamma), ptr(dbeta), Bp, P, G,
-                                                   int(bool(silu)), float(eps), ptr(residual), ptr(ws), ws.numel() * 8, ps, nbytes,
+                                                   int(bool(silu)), float(eps), ptr(residual), ptr(residual2), ptr(ws), ws.numel() * 8, ps, nbytes,
                                                    jobs, C_.byref(nj), stream()), "msgm_groupnorm_dual_backward_slots")
     d.add(jobs, nj.value, (dgamma, dbeta))
 
 
-def groupnorm_dual_backward(x, gamma, beta, stats, gout, dgamma, dbeta, Bp, P, C, G, silu, gx=None, eps=1e-5, residual=None):
-    """``residual`` (same shape as x) is added to the returned cotangent in the apply pass (skip branch, no extra axpy)."""
+def groupnorm_dual_backward(x, gamma, beta, stats, gout, dgamma, dbeta, Bp, P, C, G, silu, gx=None, eps=1e-5, residual=None,
+                            residual2=None):
+    """``residual`` (same shape as x) is added to the returned cotangent in the apply pass (skip branch, no extra axpy);
+    ``residual2``: a second addend (the skip-stack cotangent) — in the same pass inside a DeferredReduces backward, by one
+    lincomb otherwise."""
     if x.numel() != 2 * Bp * P * C or gout.numel() != x.numel() or stats.numel() != Bp * G * 4:
         raise MsgmError("groupnorm backward: size mismatch")
     if dgamma.numel() != C or dbeta.numel() != C:
         raise MsgmError("groupnorm backward: dgamma/dbeta size")
     gx = gout if gx is None else gx
-    if residual is not None and residual.numel() != x.numel():
+    if (residual is not None and residual.numel() != x.numel()) or (residual2 is not None and residual2.numel() != x.numel()):
         raise MsgmError("groupnorm backward: residual size")
     d = DeferredReduces.active
     if d is not None and d.device == x.device:
-        _gn_backward_slots(x, C, None, 0, gamma, beta, stats, gout, gx, None, dgamma, dbeta, Bp, P, G, silu, eps, residual, d)
+        _gn_backward_slots(x, C, None, 0, gamma, beta, stats, gout, gx, None, dgamma, dbeta, Bp, P, G, silu, eps, residual, d,
+                           residual2=residual2)
         return gx
     ws = _gn_ws(Bp, G, x.device)
     check(lib().msgm_groupnorm_dual_backward(ptr(f32(x)), ptr(f32(gamma)), ptr(f32(beta)), ptr(f32(stats)), ptr(f32(gout)),
                                              ptr(gx), ptr(dgamma), ptr(dbeta), Bp, P, C, G, int(bool(silu)), float(eps),
                                              ptr(residual), ptr(ws), ws.numel() * 8, stream()), "msgm_groupnorm_dual_backward")
+    if residual2 is not None:
+        lincomb(gx, gx, 1.0, residual2, 1.0)
     return gx
 
 

@@ -56,6 +56,17 @@ def test_groupnorm_dual_forward_backward(C, H, silu):
     dga1 = torch.zeros(C, device=DEV)
     gx1 = ops.groupnorm_dual_backward(xs, gam.to(DEV), bet.to(DEV), stats, gout.clone(), dga1, torch.zeros(C, device=DEV), B, P, C, G, silu)
     assert torch.equal(gx2, gx1 + res) and torch.equal(dga2, dga1)     # (gout was overwritten in place by the first call above)
+    # a SECOND addend (the skip-stack cotangent of the U-Net's encoder tensors): in the same apply pass inside a batched-
+    # reduction backward, by one lincomb outside it — the same bits either way
+    res2 = torch.randn(2 * half, device=DEV)
+    dga3, dbe3 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    with ops.DeferredReduces.on(DEV):
+        gx3 = ops.groupnorm_dual_backward(xs, gam.to(DEV), bet.to(DEV), stats, gout.clone(), dga3, dbe3, B, P, C, G, silu,
+                                          residual=res, residual2=res2)
+    gx4 = ops.groupnorm_dual_backward(xs, gam.to(DEV), bet.to(DEV), stats, gout.clone(), torch.zeros(C, device=DEV),
+                                      torch.zeros(C, device=DEV), B, P, C, G, silu, residual=res, residual2=res2)
+    assert torch.equal(gx3, (gx1 + res) + res2) and torch.equal(gx4, gx3)
+    assert rel_l2(dga3.cpu(), dga1.cpu()) <= 1e-6 and rel_l2(dbe3.cpu(), dbe2.cpu()) <= 1e-6      # batched slot sums: another order
 
 
 def test_bmm_strided_and_softmax_dual():
